@@ -1,0 +1,16 @@
+"""MI355X-native message-passing hot path of g-adaptivity (GNN.py / GRAND_plus.py).
+
+Public surface mirrors the reference modules:
+    from g_adaptivity_amd import GNN, get_conv, GRAND_plusConv, GRAND_conv
+The arithmetic lives in `libgadapt_hip.so` (csrc/, C-ABI in include/gadapt_hip.h).
+"""
+from .conv import GRAND_conv, GRAND_plusConv
+from .gnn import GNN, build_conv_list, get_conv, get_dec, get_enc, get_mlp, get_nonlin
+from .graph import GraphCache, MeshGraph, prepare_edge_index
+from .mesh_graph import MeshData, MeshDataset, MeshLoader, collate, interval_mesh, square_mesh, synthetic_batch
+from .params import hot_path_opt
+
+__all__ = ['GNN', 'get_conv', 'build_conv_list', 'get_enc', 'get_dec', 'get_mlp', 'get_nonlin',
+           'GRAND_plusConv', 'GRAND_conv', 'MeshGraph', 'GraphCache', 'prepare_edge_index',
+           'MeshData', 'MeshDataset', 'MeshLoader', 'collate', 'interval_mesh', 'square_mesh',
+           'synthetic_batch', 'hot_path_opt']

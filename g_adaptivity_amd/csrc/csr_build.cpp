@@ -1,0 +1,41 @@
+// csr_build.cpp - one-time host build of the two CSR orientations of a batched mesh graph.
+//
+// Replaces the per-call gather/scatter index handling of PyG's MessagePassing.propagate
+// (/root/reference/src/GRAND_plus.py:233-234) - see include/gadapt_hip.h.  Stable counting
+// sorts: edges keep their input order inside a row, so the summation order of every
+// kernel is a pure function of the caller's edge list.
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+#include "gadapt_hip.h"
+
+extern "C" int gadapt_csr_build_host(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
+                                     int32_t* rowptr_t, int32_t* col_t, int32_t* eid_t,
+                                     int32_t* rowptr_s, int32_t* col_s, int32_t* perm_s) {
+    if (!src || !dst || n_edges < 0 || n_nodes <= 0 || n_nodes > INT32_MAX || n_edges > INT32_MAX ||
+        !rowptr_t || !col_t || !eid_t || !rowptr_s || !col_s || !perm_s)
+        return GADAPT_E_BADARG;
+    const int64_t N = n_nodes, E = n_edges;
+    for (int64_t i = 0; i <= N; ++i) rowptr_t[i] = rowptr_s[i] = 0;
+    for (int64_t e = 0; e < E; ++e) {
+        if (src[e] < 0 || src[e] >= N || dst[e] < 0 || dst[e] >= N) return GADAPT_E_RANGE;
+        rowptr_t[dst[e] + 1]++;
+        rowptr_s[src[e] + 1]++;
+    }
+    for (int64_t i = 0; i < N; ++i) { rowptr_t[i + 1] += rowptr_t[i]; rowptr_s[i + 1] += rowptr_s[i]; }
+    std::vector<int32_t> fill_t(rowptr_t, rowptr_t + N), fill_s(rowptr_s, rowptr_s + N);
+    // by target, stable in input order
+    for (int64_t e = 0; e < E; ++e) {
+        const int32_t slot = fill_t[dst[e]]++;
+        col_t[slot] = (int32_t)src[e];
+        eid_t[slot] = (int32_t)e;
+    }
+    // by source, stable in TARGET-SLOT order (so perm_s is monotone inside a row where possible)
+    for (int32_t slot = 0; slot < (int32_t)E; ++slot) {
+        const int64_t e = eid_t[slot];
+        const int32_t s = fill_s[src[e]]++;
+        col_s[s] = (int32_t)dst[e];
+        perm_s[s] = slot;
+    }
+    return GADAPT_OK;
+}

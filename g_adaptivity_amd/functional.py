@@ -1,0 +1,190 @@
+"""Autograd-facing wrappers over the C-ABI (include/gadapt_hip.h).
+
+`grand_euler_block` is the loop of `src/GNN.py:273-291` over GRAND / GRAND_plus layers
+(`src/GRAND_plus.py:204-343`) as one differentiable op: L fused forward launches, and in
+backward 2 launches per layer plus the small weight-gradient chain.  Tensors are only
+handed over as raw device pointers on the current HIP stream; nothing here computes on
+the CPU and nothing falls back to torch ops.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _native
+from ._native import check, current_stream, lib, ptr
+from .graph import MeshGraph
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _native.NativeError(f"{what}: the message-passing path runs on the MI355X only (got a {t.device} tensor); "
+                                  "there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: fp32 expected, got {t.dtype}")
+
+
+def composite_coeffs(wq, bq, wk):
+    """(A, p0) = (Wk^T Wq, Wk^T bq) on device via the native kernel (no autograd)."""
+    c = wq.shape[0]
+    a = torch.empty(c, c, device=wq.device, dtype=torch.float32)
+    p0 = torch.empty(c, device=wq.device, dtype=torch.float32)
+    check(lib().gadapt_coeffs_forward(ptr(wq), ptr(bq), ptr(wk), ptr(a), ptr(p0), c, current_stream(wq.device)),
+          'gadapt_coeffs_forward')
+    return a, p0
+
+
+class _GrandEulerBlock(torch.autograd.Function):
+    """x_L = Euler^L(x_0).  Parameters stacked per distinct layer: wq/wk [S,C,C], bq/bk [S,C],
+    S = 1 (share_conv) or L; layer_params [L,2] = (dt, score_scale)."""
+
+    @staticmethod
+    def forward(ctx, x0, wq, bq, wk, bk, layer_params, graph: MeshGraph, num_layers: int, want_alpha: bool):
+        for t, n in ((x0, 'x'), (wq, 'lin_query.weight'), (bq, 'lin_query.bias'), (wk, 'lin_key.weight'),
+                     (layer_params, 'layer_params')):
+            _require_gpu(t, n)
+        n, c = x0.shape
+        if n != graph.num_nodes:
+            raise ValueError(f"x has {n} rows but the graph has {graph.num_nodes} nodes")
+        if c not in _native.SUPPORTED_HIDDEN:
+            raise NotImplementedError(f"hidden_dim={c}: fused kernels are built for {_native.SUPPORTED_HIDDEN}")
+        L, S = int(num_layers), wq.shape[0]
+        assert S in (1, L) and layer_params.shape == (L, 2)
+        dev, st = x0.device, current_stream(x0.device)
+        wq, bq, wk = wq.contiguous(), bq.contiguous(), wk.contiguous()
+        layer_params = layer_params.contiguous()
+        a = torch.empty(S, c, c, device=dev, dtype=torch.float32)
+        p0 = torch.empty(S, c, device=dev, dtype=torch.float32)
+        for s in range(S):
+            check(lib().gadapt_coeffs_forward(ptr(wq[s]), ptr(bq[s]), ptr(wk[s]), ptr(a[s]), ptr(p0[s]), c, st),
+                  'gadapt_coeffs_forward')
+        need_grad = any(ctx.needs_input_grad[:6])
+        x_all = torch.empty(L + 1, n, c, device=dev, dtype=torch.float32)
+        x_all[0].copy_(x0)
+        keep_alpha = need_grad or want_alpha
+        alpha = torch.empty(L, max(graph.num_edges, 1), device=dev, dtype=torch.float32) if keep_alpha else None
+        check(lib().gadapt_block_forward(graph.c_ref, ptr(x_all), L, ptr(a), c * c if S > 1 else 0,
+                                         ptr(p0), c if S > 1 else 0, ptr(layer_params), ptr(alpha), c, st),
+              'gadapt_block_forward')
+        ctx.graph, ctx.L, ctx.S, ctx.c = graph, L, S, c
+        ctx.save_for_backward(x_all, alpha if need_grad else None, a, p0, wq, bq, wk, layer_params)
+        out = x_all[L]
+        if want_alpha:
+            ctx.mark_non_differentiable(alpha)
+            return out, alpha
+        return out, None
+
+    @staticmethod
+    def backward(ctx, g_top, _g_alpha):
+        x_all, alpha, a, p0, wq, bq, wk, layer_params = ctx.saved_tensors
+        graph, L, S, c = ctx.graph, ctx.L, ctx.S, ctx.c
+        n = graph.num_nodes
+        dev, st = g_top.device, current_stream(g_top.device)
+        g_top = g_top.contiguous()
+        need_x0 = ctx.needs_input_grad[0]
+        slab_floats = lib().gadapt_backward_slab_floats(n, c)
+        slab_rows = lib().gadapt_backward_slab_rows(n, c)
+        g_ws = torch.empty(2, n, c, device=dev, dtype=torch.float32)
+        dxd_ws = torch.empty(n, c, device=dev, dtype=torch.float32)
+        edge_ws = torch.empty(max(graph.num_edges, 1), 2, device=dev, dtype=torch.float32)
+        slab = torch.empty(S, slab_floats, device=dev, dtype=torch.float32)
+        d_lp = torch.zeros(L, 2, device=dev, dtype=torch.float32)
+        d_x0 = torch.empty(n, c, device=dev, dtype=torch.float32) if need_x0 else None
+        check(lib().gadapt_block_backward(graph.c_ref, ptr(x_all), ptr(alpha), ptr(g_top), L,
+                                          ptr(a), c * c if S > 1 else 0, ptr(p0), c if S > 1 else 0, ptr(layer_params),
+                                          ptr(g_ws), ptr(dxd_ws), ptr(edge_ws), ptr(slab), ptr(d_lp), ptr(d_x0), c, st),
+              'gadapt_block_backward')
+        scratch = torch.empty(32 * (c * c + c), device=dev, dtype=torch.float32)
+        d_a = torch.empty(c, c, device=dev, dtype=torch.float32)
+        d_p0 = torch.empty(c, device=dev, dtype=torch.float32)
+        d_wq, d_bq, d_wk, d_bk = (torch.empty_like(t) for t in (wq, bq, wk, bq))
+        for s in range(S):
+            check(lib().gadapt_slab_reduce(ptr(slab[s]), slab_rows, ptr(scratch), ptr(d_a), ptr(d_p0), c, st),
+                  'gadapt_slab_reduce')
+            check(lib().gadapt_coeffs_backward(ptr(wq[s]), ptr(bq[s]), ptr(wk[s]), ptr(d_a), ptr(d_p0),
+                                               ptr(d_wq[s]), ptr(d_bq[s]), ptr(d_wk[s]), ptr(d_bk[s]), c, st),
+                  'gadapt_coeffs_backward')
+        return d_x0, d_wq, d_bq, d_wk, d_bk, d_lp, None, None, None
+
+
+class _GrandResidual(torch.autograd.Function):
+    """res = A(x)x - x for one layer: the return value of `GRAND_plusConv.forward`
+    (`src/GRAND_plus.py:267`) / `GRAND_conv.forward` (`:380-382`)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, scale, graph: MeshGraph, want_alpha: bool):
+        for t, n in ((x, 'x'), (wq, 'lin_query.weight'), (bq, 'lin_query.bias'), (wk, 'lin_key.weight'), (scale, 'scale')):
+            _require_gpu(t, n)
+        n, c = x.shape
+        if n != graph.num_nodes:
+            raise ValueError(f"x has {n} rows but the graph has {graph.num_nodes} nodes")
+        if c not in _native.SUPPORTED_HIDDEN:
+            raise NotImplementedError(f"hidden_dim={c}: fused kernels are built for {_native.SUPPORTED_HIDDEN}")
+        dev, st = x.device, current_stream(x.device)
+        x, wq, bq, wk = x.contiguous(), wq.contiguous(), bq.contiguous(), wk.contiguous()
+        a, p0 = composite_coeffs(wq, bq, wk)
+        lp = torch.stack([torch.ones((), device=dev), scale.reshape(())]).contiguous()
+        need_grad = any(ctx.needs_input_grad[:6])
+        res = torch.empty_like(x)
+        alpha = torch.empty(max(graph.num_edges, 1), device=dev, dtype=torch.float32) if (need_grad or want_alpha) else None
+        check(lib().gadapt_layer_forward(graph.c_ref, ptr(x), ptr(res), ptr(a), ptr(p0), ptr(lp), ptr(alpha), 1, c, st),
+              'gadapt_layer_forward')
+        ctx.graph, ctx.c = graph, c
+        ctx.save_for_backward(x, alpha if need_grad else None, a, p0, wq, bq, wk, lp)
+        if want_alpha:
+            ctx.mark_non_differentiable(alpha)
+            return res, alpha
+        return res, None
+
+    @staticmethod
+    def backward(ctx, g, _g_alpha):
+        x, alpha, a, p0, wq, bq, wk, lp = ctx.saved_tensors
+        graph, c = ctx.graph, ctx.c
+        n = graph.num_nodes
+        dev, st = g.device, current_stream(g.device)
+        g = g.contiguous()
+        slab = torch.empty(lib().gadapt_backward_slab_floats(n, c), device=dev, dtype=torch.float32)
+        dxd_ws, d_x = torch.empty_like(x), torch.empty_like(x)
+        edge_ws = torch.empty(max(graph.num_edges, 1), 2, device=dev, dtype=torch.float32)
+        sums = torch.zeros(2, device=dev, dtype=torch.float32)
+        check(lib().gadapt_layer_backward(graph.c_ref, ptr(x), ptr(g), ptr(alpha), ptr(a), ptr(p0), ptr(lp), ptr(edge_ws),
+                                          ptr(dxd_ws), ptr(slab), 0, ptr(sums), ptr(d_x), 1, c, st), 'gadapt_layer_backward')
+        scratch = torch.empty(32 * (c * c + c), device=dev, dtype=torch.float32)
+        d_a, d_p0 = torch.empty(c, c, device=dev), torch.empty(c, device=dev)
+        d_wq, d_bq, d_wk, d_bk = (torch.empty_like(t) for t in (wq, bq, wk, bq))
+        check(lib().gadapt_slab_reduce(ptr(slab), lib().gadapt_backward_slab_rows(n, c), ptr(scratch), ptr(d_a), ptr(d_p0), c, st),
+              'gadapt_slab_reduce')
+        check(lib().gadapt_coeffs_backward(ptr(wq), ptr(bq), ptr(wk), ptr(d_a), ptr(d_p0), ptr(d_wq), ptr(d_bq), ptr(d_wk),
+                                           ptr(d_bk), c, st), 'gadapt_coeffs_backward')
+        return d_x, d_wq, d_bq, d_wk, d_bk, sums[1].reshape(()), None, None
+
+
+def grand_residual(x, wq, bq, wk, bk, scale: torch.Tensor, graph: MeshGraph, want_alpha: bool = False):
+    """(A(x)x - x [N,C], alpha [E] in target-CSR order or None); `scale` is a 0-d device tensor."""
+    return _GrandResidual.apply(x, wq, bq, wk, bk, scale, graph, want_alpha)
+
+
+def grand_euler_block(x0: torch.Tensor, wq, bq, wk, bk, layer_params: torch.Tensor, graph: MeshGraph,
+                      num_layers: int, want_alpha: bool = False):
+    """Returns (x_L [N,C], alpha [L,E] in target-CSR order or None)."""
+    return _GrandEulerBlock.apply(x0.contiguous(), wq, bq, wk, bk, layer_params, graph, num_layers, want_alpha)
+
+
+def score_scale(hidden_dim: int, temperature=None):
+    """1/(sqrt(C) T): `src/GRAND_plus.py:279` and `:35-37`."""
+    s = 1.0 / math.sqrt(hidden_dim)
+    return s if temperature is None else s / temperature
+
+
+def encode_linear(feats: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x0 = feats @ W^T (+b) through the native kernel (frozen encoder: no autograd)."""
+    _require_gpu(feats, 'features')
+    n, f = feats.shape
+    c = weight.shape[0]
+    x0 = torch.empty(n, c, device=feats.device, dtype=torch.float32)
+    check(lib().gadapt_encode_linear(ptr(feats.contiguous()), ptr(weight.contiguous()),
+                                     ptr(bias.contiguous()) if bias is not None else None,
+                                     ptr(x0), n, f, c, current_stream(feats.device)), 'gadapt_encode_linear')
+    return x0

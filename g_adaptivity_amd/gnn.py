@@ -1,0 +1,215 @@
+"""`GNN(dataset, opt)` with the reference's surface (`src/GNN.py:144-342`), MI355X-native inside.
+
+Same constructor, same `state_dict` keys (`enc.weight`, `conv_layers.{l}.lin_*`, `steps.{l}`),
+same `forward(data) -> x_phys [N,dim]`, same `end_MLmodel` stamp - but the per-forward host
+work of the reference (two `.item()` syncs, mask surgery, corner-loop Python, `src/GNN.py:192-218`)
+is done once per batch topology (`graph.GraphCache`), and the whole residual loop
+(`src/GNN.py:273-291`) is one differentiable call into the fused HIP kernels.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as Fn
+from .conv import GRAND_conv, GRAND_plusConv
+from .graph import MeshGraph, prepare_edge_index
+
+
+def get_nonlin(nonlin_type):
+    table = {'relu': nn.ReLU, 'elu': nn.ELU, 'selu': nn.SELU, 'tanh': nn.Tanh, 'sigmoid': nn.Sigmoid,
+             'leaky_relu': nn.LeakyReLU, 'identity': nn.Identity}
+    if nonlin_type not in table:
+        raise NotImplementedError                                        # GNN.py:64
+    return table[nonlin_type]()
+
+
+def get_mlp(in_dim, hid_dim, out_dim, nonlin_type):
+    act = get_nonlin(nonlin_type)
+    return nn.Sequential(nn.Linear(in_dim, hid_dim), act, nn.Linear(hid_dim, out_dim), act)
+
+
+def get_enc(opt, in_dim, out_dim, hid_dim=None, nonlin_type='relu'):
+    kind = opt['enc']
+    if kind == 'identity':
+        # frozen selector: copies the first min(in,out) inputs, zero elsewhere (GNN.py:75-90)
+        lin = nn.Linear(in_dim, out_dim, bias=False)
+        w = torch.zeros(out_dim, in_dim)
+        k = min(in_dim, out_dim)
+        w[torch.arange(k), torch.arange(k)] = 1.0
+        lin.weight.data = w
+        lin.weight.requires_grad = False
+        return lin
+    if kind == 'lin_layer':
+        return nn.Linear(in_dim, out_dim)
+    if kind == 'MLP':
+        return get_mlp(in_dim, in_dim if hid_dim is None else hid_dim, out_dim, nonlin_type)
+    raise NotImplementedError                                            # GNN.py:98
+
+
+def get_dec(opt, in_dim, out_dim, hid_dim=None, nonlin_type='relu'):
+    if opt['enc'] == 'identity':                                         # keyed on 'enc' in the reference too (GNN.py:102)
+        return nn.Identity()
+    return None
+
+
+def get_conv(opt, conv_type, in_dim, out_dim, feat_dim=None):
+    if conv_type == 'GRAND':
+        return GRAND_conv(opt, in_dim, out_dim, heads=1)
+    if conv_type == 'GRAND_plus':
+        return GRAND_plusConv(opt, in_dim, out_dim, global_feat_dim=feat_dim, heads=1, concat=False, beta=False,
+                              dropout=0.0, edge_dim=None, bias=False, root_weight=False)
+    if conv_type in ('GCN', 'GAT', 'TRANS', 'GAT_plus'):
+        raise NotImplementedError(f"conv_type={conv_type!r}: stock-PyG variants are a later scope row "
+                                  "(SURVEY.md §8(f) rank 3); GRAND and GRAND_plus are built")
+    raise NotImplementedError                                            # GNN.py:124
+
+
+def build_conv_list(opt):
+    shared = get_conv(opt, opt['conv_type'], opt['hidden_dim'], opt['hidden_dim'], opt['global_feat_dim']) \
+        if opt['share_conv'] else None
+    layers = [shared if opt['share_conv'] else
+              get_conv(opt, opt['conv_type'], opt['hidden_dim'], opt['hidden_dim'], opt['global_feat_dim'])
+              for _ in range(opt['num_layers'])]
+    return nn.ModuleList(layers)
+
+
+class GNN(nn.Module):
+    def __init__(self, dataset, opt):
+        super().__init__()
+        self.dataset = dataset
+        self.opt = opt
+        self.dim = dataset.num_x_comp_features
+        md = opt['mesh_dims']
+        self.mesh_dims = md if isinstance(md[0], int) else eval(md[0])    # params.get_arg_list (params.py:190-196)
+        self.in_dims = [self.dim]
+        for key, width in (('gnn_inc_feat_f', 1), ('gnn_inc_feat_uu', 1),
+                           ('gnn_inc_glob_feat_f', opt.get('global_feat_dim')),
+                           ('gnn_inc_glob_feat_uu', opt.get('global_feat_dim'))):
+            if opt.get(key):
+                self.in_dims.append(width)
+        if opt.get('gnn_inc_glob_feat_f') or opt.get('gnn_inc_glob_feat_uu'):
+            raise NotImplementedError("global CNN features (src/feature_extractors.py) are a later scope row "
+                                      "(SURVEY.md §8(f) rank 4)")
+        opt['hidden_dims_list'] = self.in_dims                            # GNN.py:161
+        in_dim, hid = sum(self.in_dims), opt['hidden_dim']
+        self.enc = get_enc(opt, in_dim, hid, nonlin_type=opt['non_lin'])
+        self.conv_layers = build_conv_list(opt)
+        self.non_lin = get_nonlin(opt['non_lin'])
+        self.dec = get_dec(opt, hid, self.dim, nonlin_type=opt['non_lin'])
+        if opt.get('learn_step'):
+            self.steps = nn.ParameterList([nn.Parameter(torch.tensor([opt['time_step']]))
+                                           for _ in range(opt['num_layers'])])       # GNN.py:179-180
+        q = torch.linspace(0, 1, opt.get('eval_quad_points', 101))
+        self.quad_points = q if self.dim == 1 else list(torch.meshgrid(q, q, indexing='ij'))
+        self.end_MLmodel = None
+        self._graphs: Dict[Tuple, MeshGraph] = {}
+        self._dt_const = None
+
+    # ------------------------------------------------------------------ graph cache
+    def _graph(self, data, num_nodes: int, device) -> MeshGraph:
+        corners = getattr(data, 'corner_nodes', None)
+        if corners is None:
+            ckey = ()
+        elif isinstance(corners, (list, tuple)):
+            ckey = tuple(int(v) for a in corners for v in np.asarray(a).reshape(-1))
+        else:
+            ckey = tuple(int(v) for v in np.asarray(corners).reshape(-1))
+        key = (num_nodes, int(data.edge_index.shape[1]), self.dim, ckey, bool(self.opt['fix_boundary']),
+               bool(self.opt.get('self_loops')), str(device))
+        g = self._graphs.get(key)
+        if g is None:
+            single = not isinstance(corners, (list, tuple))
+            if single and self.dim == 2 and corners is not None:
+                data.corner_nodes = [np.asarray(corners)]
+            ei = prepare_edge_index(data, self.dim, self.mesh_dims[0], self.opt['fix_boundary'],
+                                    bool(self.opt.get('self_loops')), num_nodes)
+            g = MeshGraph(ei.to(device), num_nodes, device)
+            if len(self._graphs) >= 32:
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = g
+        return g
+
+    def _layer_params(self, device) -> torch.Tensor:
+        """[L,2] = (dt_l, score_scale_l) on device; differentiable wrt `steps` / `sm_temp_a`."""
+        L = self.opt['num_layers']
+        if self.opt.get('learn_step'):
+            dts = torch.cat([s.reshape(1) for s in self.steps])
+        else:
+            if self._dt_const is None or self._dt_const.device != device or self._dt_const.numel() != L:
+                self._dt_const = torch.full((L,), float(self.opt['time_step']), device=device)
+            dts = self._dt_const
+        scales = torch.stack([layer._scale(device) for layer in self.conv_layers])
+        return torch.stack([dts, scales], dim=1)
+
+    def _fusable(self) -> bool:
+        o = self.opt
+        plain = o['conv_type'] == 'GRAND_plus' or (o['non_lin'] == 'identity')     # GNN.py:284-286 only for non-GRAND_plus
+        return bool(o['residual']) and plain and not (self.training and o.get('dropout', 0.0) > 0)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, data):
+        o = self.opt
+        dev = torch.device(o['device'])
+        x_comp = data.x_comp.to(dev, non_blocking=True)
+        if self.dim == 1 and x_comp.dim() == 1:
+            x_comp = x_comp.unsqueeze(-1)                                  # GNN.py:225-226
+        feats = [x_comp]
+        if o['gnn_inc_feat_f']:
+            f = data.f_tensor.to(dev, non_blocking=True)
+            feats.append((f / torch.max(f) if o.get('gnn_normalize') else f).unsqueeze(-1))    # GNN.py:230-233
+        if o['gnn_inc_feat_uu']:
+            uu = data.uu_tensor.to(dev, non_blocking=True)
+            feats.append((uu / torch.max(uu) if o.get('gnn_normalize') else uu).unsqueeze(-1))  # GNN.py:235-238
+        features = torch.cat(feats, dim=1).float()
+        n = features.shape[0]
+        graph = self._graph(data, n, dev)
+
+        if isinstance(self.enc, nn.Linear) and not self.enc.weight.requires_grad and self.enc.bias is None:
+            x = Fn.encode_linear(features, self.enc.weight)               # GNN.py:270
+        else:
+            x = self.enc(features)
+        x = F.dropout(x, o.get('dropout', 0.0), training=self.training)   # GNN.py:271
+
+        if self._fusable():
+            first = self.conv_layers[0]
+            if o['share_conv']:
+                wq, bq = first.lin_query.weight.unsqueeze(0), first.lin_query.bias.unsqueeze(0)
+                wk, bk = first.lin_key.weight.unsqueeze(0), first.lin_key.bias.unsqueeze(0)
+            else:
+                wq = torch.stack([l.lin_query.weight for l in self.conv_layers])
+                bq = torch.stack([l.lin_query.bias for l in self.conv_layers])
+                wk = torch.stack([l.lin_key.weight for l in self.conv_layers])
+                bk = torch.stack([l.lin_key.bias for l in self.conv_layers])
+            store = o['conv_type'] == 'GRAND' or isinstance(o.get('show_mesh_evol_plots'), bool)
+            x, alpha = Fn.grand_euler_block(x, wq, bq, wk, bk, self._layer_params(dev), graph,
+                                            o['num_layers'], want_alpha=store)
+            if store:                                                      # GRAND_plus.py:253-256, :381
+                for l, layer in enumerate(self.conv_layers):
+                    layer.stored_ei, layer._stored = graph.edge_index, (graph, alpha[l])
+        else:
+            for i, layer in enumerate(self.conv_layers):                  # GNN.py:273-296, layer by layer
+                if o['residual'] and o['conv_type'] == 'GRAND_plus':
+                    res = layer(x, graph.edge_index, features, getattr(self.dataset, 'mesh', None), graph=graph)
+                else:
+                    res = layer(x, graph.edge_index, graph=graph)
+                    res = self.non_lin(F.dropout(res, o.get('dropout', 0.0), training=self.training))
+                if o['residual']:
+                    x = x + (self.steps[i] if o.get('learn_step') else o['time_step']) * res
+                else:
+                    x = res
+
+        x = self.dec(x) if self.dec is not None else x                    # GNN.py:298
+        x_phys = x[:, :self.dim]                                          # GNN.py:299
+        if not self.training:
+            torch.cuda.current_stream(dev).synchronize()                  # the stamp is read as a latency (utils_eval.py:201)
+        self.end_MLmodel = time.time()                                    # GNN.py:301
+        if o['loss_type'] in ('mesh_loss', 'modular'):
+            return x_phys
+        raise NotImplementedError("loss_type='pde_loss': the differentiable-FEM tail (src/GNN.py:307-342) is outside "
+                                  "the message-passing path (SURVEY.md §2 row 2)")

@@ -1,0 +1,112 @@
+"""Device-resident CSR of a batched mesh graph + the reference's edge surgery.
+
+`prepare_edge_index` is the prologue of `GNN.forward` (`src/GNN.py:206-223`):
+boundary masks, corner / end-point self-loops, optional `self_loops`.  It is a
+pure function of the batch *topology*, which is identical for every batch of a
+fixed-size dataset (all samples share one mesh, `src/data.py:290`), so
+`GraphCache` runs it - and the CSR build behind it - once per topology instead
+of once per forward.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native
+from ._native import GadaptGraph
+
+
+def prepare_edge_index(data, dim: int, mesh_n: int, fix_boundary: bool, self_loops: bool,
+                       num_nodes: int) -> torch.Tensor:
+    """CPU int64 [2,E] edge list the conv layers see (`src/GNN.py:206-223`)."""
+    edge_index = data.edge_index.detach().cpu()
+    if fix_boundary:
+        keep = ~(data.to_boundary_edge_mask.cpu() | data.to_corner_nodes_mask.cpu()
+                 | data.diff_boundary_edges_mask.cpu())
+        edge_index = edge_index[:, keep]
+        num_in_batch = int(data.batch.max().item()) + 1
+        if dim == 1:
+            b = torch.arange(num_in_batch, dtype=torch.int64)
+            ends = torch.stack([b * mesh_n, (b + 1) * mesh_n - 1], dim=1).reshape(-1)     # GNN.py:210
+            loops = ends.repeat(2, 1)
+        else:
+            corner = torch.stack([torch.as_tensor(np.asarray(a), dtype=torch.int64) for a in data.corner_nodes])
+            counts = torch.bincount(data.batch.cpu(), minlength=num_in_batch)
+            offsets = torch.cumsum(counts, 0) - counts                                     # GNN.py:214-216
+            loops = (corner + offsets.unsqueeze(-1)).reshape(-1).repeat(2, 1)
+        edge_index = torch.cat([edge_index, loops], dim=1)
+    if self_loops:                                                                         # GNN.py:220-223
+        edge_index = edge_index[:, edge_index[0] != edge_index[1]]
+        ar = torch.arange(num_nodes, dtype=torch.int64)
+        edge_index = torch.cat([edge_index, ar.repeat(2, 1)], dim=1)
+    return edge_index.contiguous()
+
+
+class MeshGraph:
+    """Both CSR orientations of one edge list, int32, resident on `device`."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, device):
+        ei = edge_index.detach().to('cpu', torch.int64).contiguous()
+        n, e = int(num_nodes), int(ei.shape[1])
+        self.num_nodes, self.num_edges = n, e
+        self.device = torch.device(device)
+        rowptr_t = torch.empty(n + 1, dtype=torch.int32)
+        rowptr_s = torch.empty(n + 1, dtype=torch.int32)
+        col_t, eid_t, col_s, perm_s = (torch.empty(max(e, 1), dtype=torch.int32) for _ in range(4))
+        src, dst = ei[0].contiguous(), ei[1].contiguous()
+        rc = _native.lib().gadapt_csr_build_host(src.data_ptr(), dst.data_ptr(), e, n,
+                                                 rowptr_t.data_ptr(), col_t.data_ptr(), eid_t.data_ptr(),
+                                                 rowptr_s.data_ptr(), col_s.data_ptr(), perm_s.data_ptr())
+        if rc != 0:
+            raise _native.NativeError(f"gadapt_csr_build_host failed (code {rc}): edge endpoint outside [0,{n})?")
+        self.edge_index = edge_index                        # as given (original order/device)
+        self.rowptr_t, self.col_t, self.eid_t = (t.to(self.device) for t in (rowptr_t, col_t, eid_t))
+        self.rowptr_s, self.col_s, self.perm_s = (t.to(self.device) for t in (rowptr_s, col_s, perm_s))
+        self.max_in_degree = int((rowptr_t[1:] - rowptr_t[:-1]).max())
+        self.c_struct = GadaptGraph(n, e, self.rowptr_t.data_ptr(), self.col_t.data_ptr(),
+                                    self.rowptr_s.data_ptr(), self.col_s.data_ptr(), self.perm_s.data_ptr())
+        self.c_ref = C.byref(self.c_struct)
+
+    def alpha_to_edge_order(self, alpha_t: torch.Tensor) -> torch.Tensor:
+        """[.., E] attention in target-CSR order -> the caller's edge order."""
+        out = torch.empty_like(alpha_t)
+        out[..., self.eid_t.long()] = alpha_t
+        return out
+
+
+class GraphCache:
+    """edge list -> MeshGraph, keyed by content (shape + hash of the int64 bytes)."""
+
+    def __init__(self, capacity: int = 16):
+        self.capacity = capacity
+        self._store: Dict[Tuple, MeshGraph] = {}
+
+    @staticmethod
+    def _key(edge_index: torch.Tensor, num_nodes: int, device) -> Tuple:
+        ei = edge_index.detach()
+        if ei.device.type != 'cpu':
+            # device-side fingerprint without a full D2H copy: three order-sensitive checksums
+            w = torch.arange(1, ei.shape[1] + 1, device=ei.device, dtype=torch.int64)
+            fp = torch.stack([(ei[0] * w).sum(), (ei[1] * w).sum(), (ei[0] ^ (ei[1] << 1)).sum()]).tolist()
+            return (int(ei.shape[1]), int(num_nodes), str(device), tuple(fp))
+        return (int(ei.shape[1]), int(num_nodes), str(device), hash(ei.numpy().tobytes()))
+
+    def get(self, edge_index: torch.Tensor, num_nodes: int, device) -> MeshGraph:
+        key = self._key(edge_index, num_nodes, device)
+        g = self._store.get(key)
+        if g is None:
+            if len(self._store) >= self.capacity:
+                self._store.pop(next(iter(self._store)))
+            g = MeshGraph(edge_index, num_nodes, device)
+            self._store[key] = g
+        return g
+
+
+_default_cache = GraphCache()
+
+
+def graph_for(edge_index: torch.Tensor, num_nodes: int, device) -> MeshGraph:
+    return _default_cache.get(edge_index, num_nodes, device)

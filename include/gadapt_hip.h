@@ -1,0 +1,156 @@
+/*
+ * gadapt_hip.h - C-ABI of the MI355X-native g-adaptivity message-passing path.
+ *
+ * Plain pointers and sizes only: no torch types cross this boundary.  Every device
+ * pointer is fp32 / int32 HBM memory owned by the caller; `stream` is a hipStream_t
+ * passed as void*.  All entry points return 0 on success or a negative GADAPT_E_*
+ * code and never abort; `gadapt_last_error()` gives the message.  Nothing here
+ * allocates, frees or synchronises (graph-capture safe) except the *_host helpers.
+ *
+ * The reference (/root/reference, 100 % Python) has no FFI; each entry point cites
+ * the reference code whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Formulation.  One GRAND layer of the reference is
+ *     Q = x Wq^T + bq,  K = x Wk^T + bk,  s_ij = <Q_i,K_j>/sqrt(C)   (GRAND_plus.py:225-226,279)
+ *     alpha_ij = softmax_j(s_ij / T)  over edges j->i                 (GRAND_plus.py:326-333)
+ *     x'_i = x_i + dt * (sum_j alpha_ij x_j - x_i)                    (GRAND_plus.py:338-343,267; GNN.py:288-291)
+ * <Q_i,K_j> = P_i . x_j + <Q_i,bk>  with  P_i = A x_i + p0,  A = Wk^T Wq,  p0 = Wk^T bq;
+ * the second term does not depend on j and cancels in the softmax, so the kernels
+ * work from (A, p0): one [C,C] projection per node instead of two, and the edge walk
+ * gathers x_j only.
+ */
+#ifndef GADAPT_HIP_H
+#define GADAPT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GADAPT_OK            0
+#define GADAPT_E_BADARG     -1   /* null pointer, negative size, unsupported hidden_dim ... */
+#define GADAPT_E_LAUNCH     -2   /* hipGetLastError() after a launch */
+#define GADAPT_E_RANGE      -3   /* edge endpoint outside [0, n_nodes) */
+
+/* Hidden sizes the fused kernels are built for; others -> GADAPT_E_BADARG. */
+int  gadapt_supported_hidden_dim(int c);
+const char* gadapt_last_error(void);
+int  gadapt_abi_version(void);
+
+/* ------------------------------------------------------------------ graph
+ * Replaces the per-forward edge bookkeeping of PyG's MessagePassing.propagate
+ * (called at GRAND_plus.py:233-234) with a one-time CSR build.  Input is the
+ * edge list AFTER GNN.py:206-223 surgery, host memory, int64 as PyG holds it:
+ * src[e] -> dst[e].  Outputs (host, int32, caller-allocated):
+ *   rowptr_t[N+1], col_t[E] : in-edges grouped by target, col_t = source;
+ *   eid_t[E]                : original edge id of each target-ordered slot
+ *                             (alpha_out[slot] belongs to edge eid_t[slot]);
+ *   rowptr_s[N+1], col_s[E] : out-edges grouped by source, col_s = target;
+ *   perm_s[E]               : target-ordered slot of each source-ordered slot.
+ * Order inside a row is the input order (stable), so results are reproducible. */
+int gadapt_csr_build_host(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
+                          int32_t* rowptr_t, int32_t* col_t, int32_t* eid_t,
+                          int32_t* rowptr_s, int32_t* col_s, int32_t* perm_s);
+
+typedef struct gadapt_graph {
+    int32_t n_nodes;
+    int32_t n_edges;
+    const int32_t* rowptr_t;  /* device */
+    const int32_t* col_t;
+    const int32_t* rowptr_s;
+    const int32_t* col_s;
+    const int32_t* perm_s;
+} gadapt_graph;
+
+/* ------------------------------------------------------------------ weights
+ * A[o][c] = sum_r Wk[r][o] Wq[r][c],  p0[o] = sum_r Wk[r][o] bq[r].
+ * Wq,Wk are torch Linear weights [out,in] (GRAND_plus.py:146-147). */
+int gadapt_coeffs_forward(const float* wq, const float* bq, const float* wk,
+                          float* a_out, float* p0_out, int c, void* stream);
+/* Chain rule back to the Linear parameters.  dbk is written as exact zeros:
+ * d/dbk vanishes because softmax is shift-invariant per target. */
+int gadapt_coeffs_backward(const float* wq, const float* bq, const float* wk,
+                           const float* d_a, const float* d_p0,
+                           float* d_wq, float* d_bq, float* d_wk, float* d_bk, int c, void* stream);
+
+/* ------------------------------------------------------------------ encoder
+ * x0 = feats @ W^T (+ b): get_enc (GNN.py:72-98, call :270).  feats [N,F], W [C,F]. */
+int gadapt_encode_linear(const float* feats, const float* w, const float* b /*nullable*/,
+                         float* x0, int64_t n_nodes, int f, int c, void* stream);
+
+/* ------------------------------------------------------------------ one layer
+ * layer_params (device, 2 floats): {dt, score_scale} with score_scale = 1/(sqrt(C)*T).
+ * alpha_out (nullable) [E] in target order.  x_out must not alias x_in.
+ * residual_only = 0: x_out = x + dt*(A(x)x - x)   (conv + Euler update, GNN.py:288-291)
+ * residual_only = 1: x_out = A(x)x - x            (what GRAND_plusConv.forward returns,
+ *                                                  GRAND_plus.py:267; dt is ignored)   */
+int gadapt_layer_forward(const gadapt_graph* g, const float* x_in, float* x_out,
+                         const float* a, const float* p0, const float* layer_params,
+                         float* alpha_out, int residual_only, int c, void* stream);
+
+/* Workspace sizing for the backward: the target pass leaves one partial-sum row of
+ * (C*C + C) floats per workgroup ("slab"); rows depends on the node count only. */
+int     gadapt_backward_slab_rows(int64_t n_nodes, int c);
+int64_t gadapt_backward_slab_floats(int64_t n_nodes, int c);   /* rows * (C*C + C) */
+
+/* Backward of one layer, split in two launches:
+ *   target pass: per in-edge d(score), per node dP, weight-gradient partials, and
+ *                dxd = (1-dt) g + A^T dP;
+ *   source pass: g_out = dxd + sum over out-edges (alpha dt g_i + dscore A x_i ...) .
+ * g_in = dL/dx_out [N,C]; x_in = the layer's input; alpha = forward's alpha_out.
+ * edge_ws [E] float2, dxd_ws [N,C] scratch.  slab accumulates (accumulate!=0) or is
+ * overwritten.  sums_out (nullable, 2 floats per call, atomically accumulated):
+ * {d dt, d score_scale}.  Pass g_out = NULL to skip the source pass (layer 0 with a
+ * frozen encoder: GNN.py:82). */
+int gadapt_layer_backward(const gadapt_graph* g, const float* x_in, const float* g_in,
+                          const float* alpha, const float* a, const float* p0,
+                          const float* layer_params,
+                          float* edge_ws, float* dxd_ws, float* slab, int accumulate,
+                          float* sums_out, float* g_out, int residual_only, int c, void* stream);
+
+/* slab [n_rows][C*C+C] -> d_a [C*C], d_p0 [C].  scratch: 32*(C*C+C) floats. */
+int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch, float* d_a, float* d_p0, int c, void* stream);
+
+/* ------------------------------------------------------------------ L-step Euler block
+ * The loop of GNN.py:273-291 with weight sharing (GNN.py:131-141): x_all is
+ * [(L+1),N,C] with x_all[0] = encoder output on entry; layer l reads x_all[l],
+ * writes x_all[l+1].  a/p0/layer_params advance by *_stride floats per layer
+ * (0 = shared).  alpha_all (nullable) [L,E]. */
+int gadapt_block_forward(const gadapt_graph* g, float* x_all, int n_layers,
+                         const float* a, int64_t a_stride, const float* p0, int64_t p0_stride,
+                         const float* layer_params, float* alpha_all, int c, void* stream);
+
+/* Backward of the block.  g_top = dL/dx_all[L] (not modified).  g_ws: 2*N*C floats,
+ * dxd_ws: N*C, edge_ws: 2*E, slab: n_slots*gadapt_backward_slab_floats(N,c) with
+ * n_slots = 1 (shared weights) or L.  d_layer_params (nullable) [L,2] accumulates.
+ * d_x0 (nullable) [N,C] receives dL/dx_all[0]. */
+int gadapt_block_backward(const gadapt_graph* g, const float* x_all, const float* alpha_all,
+                          const float* g_top, int n_layers,
+                          const float* a, int64_t a_stride, const float* p0, int64_t p0_stride,
+                          const float* layer_params,
+                          float* g_ws, float* dxd_ws, float* edge_ws, float* slab,
+                          float* d_layer_params, float* d_x0, int c, void* stream);
+
+/* ------------------------------------------------------------------ loss seed
+ * mesh_loss (run_GNN.py:80-84,106): loss = mean |x_phys - target|^p, p = 2 (mse) or 1 (l1),
+ * x_phys = x_top[:, :d] (GNN.py:299).  Writes x_phys [N,d], g_top [N,C] (zero outside
+ * the first d columns, scaled by grad_scale/(N*d)) and atomically adds the summed loss
+ * (already divided by N*d) into loss_out[0] (caller zeroes it). */
+int gadapt_mesh_loss_seed(const float* x_top, const float* target, float* x_phys, float* g_top,
+                          float* loss_out, int64_t n_nodes, int d, int c, int l1, float grad_scale,
+                          void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * torch.optim.Adam(lr, weight_decay) step on a flat fp32 bucket (run_GNN.py:88,128-131):
+ * L2 weight decay added to the gradient, bias-corrected moments, eps outside the sqrt.
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce SUM). */
+int gadapt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GADAPT_HIP_H */

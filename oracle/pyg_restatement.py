@@ -1,0 +1,196 @@
+"""ORACLE - test infrastructure only, never on the product path.  PARITY UNPINNED.
+
+CPU restatement, in plain PyTorch ops, of the reference's message-passing hot
+path, executing the op sequence `torch_geometric==2.4.0` (pinned,
+`README.md:25`; NOT vendored under /root/reference and not installable here)
+would execute.  The reference has no tests, golden vectors or fixtures for
+this path and cannot be imported (ModuleNotFoundError:
+torch_geometric / torch_scatter / firedrake), so this oracle is pinned only by
+(i) an independent dense fp64 formulation (`oracle/dense_check.py`),
+(ii) `torch.autograd.gradcheck`, (iii) analytic known answers - see
+`tests/test_oracle.py`.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import this package.
+
+What each function follows (paths under /root/reference):
+
+* `pyg_softmax`            - `torch_geometric.utils.softmax` as called at
+                             `src/GRAND_plus.py:333` (and `:35-37` with temperature):
+                             scatter-max (detached) -> sub -> exp -> scatter-sum
+                             + 1e-16 -> gather -> div.
+* `grand_residual`         - `GRAND_plusConv.forward/.message`
+                             (`src/GRAND_plus.py:204-267`, `:269-343`) with the
+                             arguments `get_conv` passes (`src/GNN.py:117-119`):
+                             heads=1, concat=False, root_weight=False, edge_dim=None,
+                             dropout=0; identical maths to `GRAND_conv`
+                             (`src/GRAND_plus.py:366-382`).
+* `masked_edge_index`      - `GNN.forward` edge surgery (`src/GNN.py:206-218`).
+* `node_features`          - feature concat (`src/GNN.py:225-239`).
+* `identity_encoder_weight`- `get_enc` identity branch (`src/GNN.py:75-90`).
+* `OracleGNN`              - `GNN.__init__/forward` (`src/GNN.py:144-306`) for
+                             loss_type in {mesh_loss, modular}, enc='identity',
+                             conv_type in {GRAND_plus, GRAND}.
+"""
+from __future__ import annotations
+
+import math
+import time
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def pyg_softmax(src: torch.Tensor, index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """Segment softmax over entries sharing `index` (PyG 2.4.0 `utils.softmax`)."""
+    shape = [num_nodes] + list(src.shape[1:])
+    idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+    src_max = torch.full(shape, float('-inf'), dtype=src.dtype, device=src.device)
+    src_max = src_max.scatter_reduce(0, idx, src.detach(), reduce='amax', include_self=True)
+    out = (src - src_max.index_select(0, index)).exp()
+    out_sum = torch.zeros(shape, dtype=src.dtype, device=src.device).index_add_(0, index, out) + 1e-16
+    return out / out_sum.index_select(0, index)
+
+
+def grand_residual(x, edge_index, w_query, b_query, w_key, b_key,
+                   temperature: Optional[torch.Tensor | float] = None, return_attention: bool = False):
+    """One diffusion residual  A(x)x - x  (`src/GRAND_plus.py:225-267`).
+
+    x [N,C]; edge_index [2,E] int64, row 0 = source j, row 1 = target i.
+    """
+    n, c = x.shape
+    src, dst = edge_index[0], edge_index[1]
+    query = F.linear(x, w_query, b_query).view(-1, 1, c)        # :225
+    key = F.linear(x, w_key, b_key).view(-1, 1, c)              # :226
+    value = x.view(-1, 1, c)                                    # :150,:227 identity
+    query_i = query.index_select(0, dst)                        # propagate/_collect: _i <- edge_index[1]
+    key_j = key.index_select(0, src)                            #                     _j <- edge_index[0]
+    value_j = value.index_select(0, src)
+    alpha = (query_i * key_j).sum(dim=-1) / math.sqrt(c)        # :279
+    if temperature is not None:
+        alpha = alpha / temperature                             # :35-37,:326-329
+    alpha = pyg_softmax(alpha, dst, n)                          # :333
+    msg = value_j * alpha.view(-1, 1, 1)                        # :342
+    out = torch.zeros(n, 1, c, dtype=x.dtype, device=x.device).index_add_(0, dst, msg)   # aggr='add' :127
+    out = out.mean(dim=1)                                       # :242 (heads=1)
+    res = out - x                                               # :267
+    if return_attention:
+        return res, (alpha, query, key)
+    return res
+
+
+def masked_edge_index(data, dim: int, mesh_n: int, fix_boundary: bool = True) -> torch.Tensor:
+    """`src/GNN.py:206-218`: drop masked edges, append boundary/corner self-loops."""
+    edge_index = data.edge_index
+    if not fix_boundary:
+        return edge_index
+    mask = ~data.to_boundary_edge_mask * ~data.to_corner_nodes_mask * ~data.diff_boundary_edges_mask
+    edge_index = edge_index[:, mask]
+    num_in_batch = int(data.batch.max().item()) + 1
+    if dim == 1:
+        ends = torch.cat([torch.tensor([0 + b * mesh_n, (1 + b) * mesh_n - 1]) for b in range(num_in_batch)])
+        loops = ends.repeat(2, 1)
+    else:
+        import numpy as np
+        corner = torch.stack([torch.from_numpy(np.asarray(a)) for a in data.corner_nodes])      # [B,4]
+        counts = data.batch.unique(return_counts=True)[1]
+        cum = torch.cumsum(counts, dim=0)
+        corner = corner.clone()
+        corner[1:] += cum[:-1].unsqueeze(-1)
+        loops = corner.reshape(-1).repeat(2, 1)
+    return torch.cat([edge_index, loops.to(edge_index.device)], dim=1)
+
+
+def node_features(data, dim: int, inc_f: bool, inc_uu: bool, normalize: bool = False) -> torch.Tensor:
+    """`src/GNN.py:225-239`."""
+    x_comp = data.x_comp
+    if dim == 1:
+        x_comp = x_comp.unsqueeze(-1)
+    feats = x_comp
+    if inc_f:
+        f = data.f_tensor
+        if normalize:
+            f = f / torch.max(f)
+        feats = torch.cat([feats, f.unsqueeze(-1)], dim=1)
+    if inc_uu:
+        uu = data.uu_tensor
+        if normalize:
+            uu = uu / torch.max(uu)
+        feats = torch.cat([feats, uu.unsqueeze(-1)], dim=1)
+    return feats
+
+
+def identity_encoder_weight(in_dim: int, out_dim: int) -> torch.Tensor:
+    """Frozen `nn.Linear(in_dim,out_dim,bias=False).weight` of `src/GNN.py:75-90`."""
+    w = torch.zeros(out_dim, in_dim)
+    k = min(in_dim, out_dim)
+    w[:k, :k] = torch.eye(k)
+    return w
+
+
+_NONLIN = {'relu': F.relu, 'elu': F.elu, 'selu': F.selu, 'tanh': torch.tanh, 'sigmoid': torch.sigmoid,
+           'leaky_relu': F.leaky_relu, 'identity': lambda t: t}                           # get_nonlin, GNN.py:48-64
+
+
+class _QK(nn.Module):
+    """Parameter holder with the reference's state_dict names (`src/GRAND_plus.py:146-147,178`)."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.lin_key = nn.Linear(c, c)
+        self.lin_query = nn.Linear(c, c)
+        self.lin_skip = nn.Linear(c, c, bias=False)           # allocated, never used (root_weight=False)
+
+
+class OracleGNN(nn.Module):
+    """`GNN` (`src/GNN.py:144-306`) for enc='identity', GRAND/GRAND_plus, mesh_loss|modular."""
+
+    def __init__(self, dataset, opt):
+        super().__init__()
+        self.opt = opt
+        self.dim = dataset.num_x_comp_features
+        in_dim = self.dim + int(bool(opt['gnn_inc_feat_f'])) + int(bool(opt['gnn_inc_feat_uu']))
+        c = opt['hidden_dim']
+        assert opt['enc'] == 'identity' and opt['conv_type'] in ('GRAND', 'GRAND_plus')
+        self.enc = nn.Linear(in_dim, c, bias=False)
+        self.enc.weight.data = identity_encoder_weight(in_dim, c)
+        self.enc.weight.requires_grad = False
+        if opt['share_conv']:
+            shared = _QK(c)
+            self.conv_layers = nn.ModuleList([shared for _ in range(opt['num_layers'])])     # :131-141
+        else:
+            self.conv_layers = nn.ModuleList([_QK(c) for _ in range(opt['num_layers'])])
+        if opt.get('learn_step'):
+            self.steps = nn.ParameterList([nn.Parameter(torch.tensor([opt['time_step']]))
+                                           for _ in range(opt['num_layers'])])              # :179-180
+        self.end_MLmodel = None
+
+    def temperature(self):
+        t = self.opt.get('softmax_temp_type')
+        return self.opt['softmax_temp'] if t == 'fixed' else None
+
+    def forward(self, data, return_all: bool = False):
+        opt = self.opt
+        edge_index = masked_edge_index(data, self.dim, opt['mesh_dims'][0], opt['fix_boundary'])
+        feats = node_features(data, self.dim, opt['gnn_inc_feat_f'], opt['gnn_inc_feat_uu'],
+                              opt.get('gnn_normalize', False))
+        x = self.enc(feats.to(self.enc.weight.dtype))                                      # :270
+        alphas = []
+        for i, layer in enumerate(self.conv_layers):                                       # :273
+            res, (alpha, _, _) = grand_residual(x, edge_index, layer.lin_query.weight, layer.lin_query.bias,
+                                                layer.lin_key.weight, layer.lin_key.bias,
+                                                self.temperature(), return_attention=True)
+            if not (opt['residual'] and opt['conv_type'] == 'GRAND_plus'):
+                res = F.dropout(res, opt.get('dropout', 0.0), training=self.training)      # :285 / :295
+                res = _NONLIN[opt['non_lin']](res)                                         # :286 / :296
+            if opt['residual']:
+                step = self.steps[i] if opt.get('learn_step') else opt['time_step']
+                x = x + step * res                                                         # :288-291
+            else:
+                x = res                                                                    # :294-296
+            alphas.append(alpha)
+        x_phys = x[:, :self.dim]                                                           # :299
+        self.end_MLmodel = time.time()
+        if return_all:
+            return x_phys, x, alphas, edge_index
+        return x_phys

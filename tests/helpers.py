@@ -1,0 +1,34 @@
+"""Shared builders for the parity tests: same seeded inputs for the HIP path and the oracle."""
+import copy
+
+import torch
+
+from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt
+from oracle.pyg_restatement import OracleGNN
+
+
+def make_case(mesh_dims, batch, hidden, layers, conv_type='GRAND_plus', seed=0, **opt_over):
+    opt = hot_path_opt(mesh_dims=list(mesh_dims), hidden_dim=hidden, num_layers=layers, conv_type=conv_type, **opt_over)
+    ds = MeshDataset(mesh_dims, batch, seed=seed)
+    data = collate(ds.samples)
+    torch.manual_seed(seed)
+    oracle = OracleGNN(ds, dict(opt))
+    return opt, ds, data, oracle
+
+
+def hip_model_like(oracle, ds, opt, device):
+    o = dict(opt)
+    o['device'] = str(device)
+    model = GNN(ds, o).to(device)
+    missing, unexpected = model.load_state_dict(copy.deepcopy(oracle.state_dict()), strict=True)
+    return model
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b| (normwise) and the worst elementwise relative error where |b| > 1e-3 max|b|."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = b.abs().max().clamp_min(1e-300)
+    norm = ((a - b).abs().max() / scale).item()
+    big = b.abs() > 1e-3 * scale
+    elem = ((a - b).abs()[big] / b.abs()[big]).max().item() if big.any() else 0.0
+    return norm, elem
