@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""bench.py - meshes/sec, forward+backward(+optimizer step), 2-D Poisson 64x64 mesh graphs, batch 32 per GPU.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
+torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+
+A step = the reference's training iteration on one batch (`src/run_GNN.py:99-131`, mesh_loss):
+    optimizer.zero_grad(); out = model(data); loss = F.mse_loss(out, data.x_phys); loss.backward(); optimizer.step()
+with the batch resident in HBM.  Per-GPU work is fixed (32 meshes/rank): weak scaling; the only
+collective is the all-reduce of the flat gradient bucket.
+
+Extra objects on the JSON line:
+  roofline     - dominant hot kernel: algorithmic bytes per launch / its measured
+                 duration (HIP events on the launch stream, second instrumented pass of K steps).
+  cpu_baseline - the CPU oracle (PyG-equivalent op sequence in plain torch) on the host cores, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (mesh n, meshes per GPU, layers, hidden, conv_type, feature flags)
+    'poisson2d_64x64_b32_L4_C64': dict(n=64, batch=32, layers=4, hidden=64, conv='GRAND_plus', f=True, uu=True),
+    'poisson2d_32x32_b32_L4_C64': dict(n=32, batch=32, layers=4, hidden=64, conv='GRAND_plus', f=True, uu=True),
+    'burgers2d_64x64_b32_L6_C128': dict(n=64, batch=32, layers=6, hidden=128, conv='GRAND', f=False, uu=True),
+    'euler20_128x128_b16_C64': dict(n=128, batch=16, layers=20, hidden=64, conv='GRAND_plus', f=True, uu=True),
+}
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(kernel, n_nodes, n_edges, c):
+    """compulsory traffic of one layer launch over the whole batch (fp32, int32 CSR)."""
+    csr = 4 * (n_edges + n_nodes + 1)
+    if kernel == 'forward':            # read x, write x'
+        return 8 * n_nodes * c + csr
+    if kernel == 'backward_target':    # read g, read saved x  (+ CSR by target)
+        return 8 * n_nodes * c + csr
+    if kernel == 'backward_source':    # write dx               (+ CSR by source)
+        return 4 * n_nodes * c + csr
+    raise KeyError(kernel)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='poisson2d_64x64_b32_L4_C64', choices=list(WORKLOADS))
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt, _native
+    from g_adaptivity_amd.optim import FlatAdam
+
+    w = WORKLOADS[args.workload]
+    opt = hot_path_opt(mesh_dims=[w['n'], w['n']], hidden_dim=w['hidden'], num_layers=w['layers'], conv_type=w['conv'],
+                       gnn_inc_feat_f=w['f'], gnn_inc_feat_uu=w['uu'], device=str(dev), loss_type='mesh_loss',
+                       show_mesh_evol_plots='False')
+    ds = MeshDataset([w['n'], w['n']], w['batch'], seed=rank)        # every rank owns its own shard of meshes
+    data = collate(ds.samples).to(dev)
+    target = data.x_phys
+    torch.manual_seed(0)                                              # identical replicas
+    model = GNN(ds, opt).to(dev)
+    model.train()
+    optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'])
+
+    def fwd_bwd():
+        out = model(data)
+        loss = F.mse_loss(out, target)
+        loss.backward()
+        return loss
+
+    def eager_step():
+        optim.zero_grad()
+        loss = fwd_bwd()
+        optim.step()                                                  # all-reduce (N>1) + fused Adam
+        return loss
+
+    # first steps eagerly: builds the CSR cache and the flat bucket
+    for _ in range(2):
+        eager_step()
+    torch.cuda.synchronize()
+
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                optim.zero_grad(); fwd_bwd()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            optim.zero_grad()
+            with torch.cuda.graph(g):
+                static_loss = fwd_bwd()
+            graph = g
+        except Exception as e:                                        # stay correct: fall back to eager launches
+            print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            optim.grad_bucket.zero_()
+            graph.replay()                                            # forward + loss + backward as one hipGraph
+            optim.step()
+        else:
+            eager_step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    meshes = w['batch'] * world * args.steps
+    value = meshes / elapsed
+
+    # ---- instrumented pass (eager, HIP events around each hot-kernel launch)
+    roofline, kernels = None, {}
+    if rank == 0:
+        import ctypes as C
+        lib = _native.lib()
+        lib.gadapt_profile_reset(); lib.gadapt_profile_enable(1)
+        for _ in range(args.steps):
+            eager_step()
+        torch.cuda.synchronize()
+        lib.gadapt_profile_enable(0)
+        graph_obj = next(iter(model._graphs.values()))
+        n_nodes, n_edges = graph_obj.num_nodes, graph_obj.num_edges
+        for kid, name in enumerate(('forward', 'backward_target', 'backward_source')):
+            cap = 4 * args.steps * w['layers'] + 16
+            buf = (C.c_double * cap)()
+            cnt = lib.gadapt_profile_samples(kid, buf, cap)
+            xs = sorted(buf[i] for i in range(max(cnt, 0)))
+            if not xs:
+                continue
+            keep = xs[:max(1, (3 * len(xs)) // 4)]                    # drop launches that waited on the host
+            avg_ms = sum(keep) / len(keep)
+            by = algorithmic_bytes(name, n_nodes, n_edges, w['hidden'])
+            kernels[name] = {'launches_per_step': cnt // args.steps, 'avg_us': round(avg_ms * 1e3, 2),
+                             'alg_bytes_per_launch': by, 'achieved_GBs': round(by / (avg_ms * 1e-3) / 1e9, 1)}
+        lib.gadapt_profile_reset()
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]['avg_us'] * kernels[k]['launches_per_step'])
+            kd = kernels[dom]
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')   # filled from separate rocprofv3 --pmc passes
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+                except Exception:
+                    traffic = None
+            roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': kd['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(kd['achieved_GBs'] / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                        'avg_launch_us': kd['avg_us'], 'alg_bytes_per_launch': kd['alg_bytes_per_launch']}
+
+    # ---- CPU baseline: the oracle on the host cores, same workload, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.pyg_restatement import OracleGNN
+        cdata = collate(ds.samples)
+        ctarget = cdata.x_phys
+        copt = dict(opt); copt['device'] = 'cpu'
+        torch.manual_seed(0)
+        oracle = OracleGNN(ds, copt)
+        oracle.train()
+
+        def cpu_step():
+            oracle.zero_grad()
+            F.mse_loss(oracle(cdata), ctarget).backward()
+
+        cpu_step()
+        t1 = time.perf_counter(); cpu_step(); one = time.perf_counter() - t1
+        iters = max(2, min(50, int(args.cpu_seconds / max(one, 1e-3))))
+        t1 = time.perf_counter()
+        for _ in range(iters):
+            cpu_step()
+        ct = time.perf_counter() - t1
+        cpu = {'value': round(w['batch'] * iters / ct, 2), 'unit': 'meshes/s', 'cores': torch.get_num_threads(),
+               'host_cpus': os.cpu_count(), 'kind': 'port',
+               'sample': f"{iters} fwd+bwd steps of the same {w['batch']}-mesh batch ({ct:.1f} s), CPU restatement of the "
+                         f"reference path (PyG-equivalent op sequence), no optimizer step"}
+
+    if rank == 0:
+        line = {
+            'metric': 'meshes/sec fwd+bwd, 2D Poisson 64x64 mesh graph, batch 32, 1/2/4/8 GPU',
+            'value': round(value, 1), 'unit': 'meshes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'mesh': f"{w['n']}x{w['n']}", 'meshes_per_gpu': w['batch'],
+                       'global_batch': w['batch'] * world, 'mp_layers': w['layers'], 'hidden': w['hidden'],
+                       'conv_type': w['conv'], 'parallelism': f'dp{world}',
+                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'launch': 'hipgraph' if graph is not None else 'eager'},
+            'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

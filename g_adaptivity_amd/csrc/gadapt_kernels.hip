@@ -42,6 +42,54 @@ extern "C" int gadapt_supported_hidden_dim(int c) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// optional per-kernel timing (bench/roofline only): HIP events on the launch stream around every
+// hot-kernel launch.  Off by default; when off the launch path touches none of this.
+// ------------------------------------------------------------------------------------------------
+#include <vector>
+struct ProfRec { int id; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+struct ProfScope {
+    hipStream_t st; int idx = -1;
+    ProfScope(int id, hipStream_t s) : st(s) {
+        if (!g_prof_on) return;
+        ProfRec r{id, nullptr, nullptr};
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        (void)hipEventRecord(r.a, st);
+        g_prof.push_back(r);
+        idx = (int)g_prof.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, st); }
+};
+extern "C" int gadapt_profile_enable(int on) { g_prof_on = (on != 0); return GADAPT_OK; }
+extern "C" int gadapt_profile_read(int kernel_id, double* total_ms, int* count) {
+    if (!total_ms || !count) return fail(GADAPT_E_BADARG, "profile_read: null pointer");
+    double tot = 0.0; int n = 0;
+    for (auto& r : g_prof) {
+        if (r.id != kernel_id) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; ++n; }
+    }
+    *total_ms = tot; *count = n;
+    return GADAPT_OK;
+}
+extern "C" int gadapt_profile_samples(int kernel_id, double* out_ms, int cap) {
+    if (!out_ms || cap < 0) return fail(GADAPT_E_BADARG, "profile_samples: bad argument");
+    int n = 0;
+    for (auto& r : g_prof) {
+        if (r.id != kernel_id) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && n < cap) out_ms[n++] = ms;
+    }
+    return n;
+}
+extern "C" int gadapt_profile_reset(void) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    return GADAPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // compile-time geometry
 // ------------------------------------------------------------------------------------------------
 template <int C> struct Cfg {
@@ -772,6 +820,7 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
     using K = Cfg<C>;
     FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, alpha_out, g->n_nodes, (g->n_nodes + K::TM - 1) / K::TM, residual_only};
     allow_lds(grand_fwd_kernel<C>, K::LDS_BYTES);
+    ProfScope prof(0, st);
     hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), K::LDS_BYTES, st, p);
     return check_launch("grand_fwd_kernel");
 }
@@ -783,12 +832,17 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     BwdTArgs pt{x_in, g_in, alpha, a, lp, g->rowptr_t, g->col_t, reinterpret_cast<float2*>(edge_ws), dxd, slab, sums_out,
                 g->n_nodes, n_tiles, accumulate, residual_only};
     allow_lds(grand_bwd_target_kernel<C>, K::LDS_BYTES);
-    hipLaunchKernelGGL(grand_bwd_target_kernel<C>, dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), K::LDS_BYTES, st, pt);
-    int rc = check_launch("grand_bwd_target_kernel");
+    int rc;
+    {
+        ProfScope prof(1, st);
+        hipLaunchKernelGGL(grand_bwd_target_kernel<C>, dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), K::LDS_BYTES, st, pt);
+        rc = check_launch("grand_bwd_target_kernel");
+    }
     if (rc || !g_out) return rc;
     BwdSArgs ps{x_in, g_in, reinterpret_cast<const float2*>(edge_ws), dxd, a, p0, g->rowptr_s, g->col_s, g->perm_s, g_out,
                 g->n_nodes, n_tiles};
     allow_lds(grand_bwd_source_kernel<C>, K::LDS_BYTES);
+    ProfScope prof(2, st);
     hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), K::LDS_BYTES, st, ps);
     return check_launch("grand_bwd_source_kernel");
 }

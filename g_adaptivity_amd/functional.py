@@ -41,7 +41,7 @@ class _GrandEulerBlock(torch.autograd.Function):
     S = 1 (share_conv) or L; layer_params [L,2] = (dt, score_scale)."""
 
     @staticmethod
-    def forward(ctx, x0, wq, bq, wk, bk, layer_params, graph: MeshGraph, num_layers: int, want_alpha: bool):
+    def forward(ctx, x0, wq, bq, wk, bk, layer_params, graph: MeshGraph, num_layers: int, want_alpha: bool, x_all=None):
         for t, n in ((x0, 'x'), (wq, 'lin_query.weight'), (bq, 'lin_query.bias'), (wk, 'lin_key.weight'),
                      (layer_params, 'layer_params')):
             _require_gpu(t, n)
@@ -61,8 +61,12 @@ class _GrandEulerBlock(torch.autograd.Function):
             check(lib().gadapt_coeffs_forward(ptr(wq[s]), ptr(bq[s]), ptr(wk[s]), ptr(a[s]), ptr(p0[s]), c, st),
                   'gadapt_coeffs_forward')
         need_grad = any(ctx.needs_input_grad[:6])
-        x_all = torch.empty(L + 1, n, c, device=dev, dtype=torch.float32)
-        x_all[0].copy_(x0)
+        if x_all is None:                      # else: caller's [(L+1),N,C] buffer whose slot 0 already holds x0
+            x_all = torch.empty(L + 1, n, c, device=dev, dtype=torch.float32)
+            x_all[0].copy_(x0)
+        else:
+            x_all = x_all[0]                   # boxed in a list so autograd does not track it as an input
+            assert x_all.shape == (L + 1, n, c) and x_all.is_contiguous() and x_all.data_ptr() == x0.data_ptr()
         keep_alpha = need_grad or want_alpha
         alpha = torch.empty(L, max(graph.num_edges, 1), device=dev, dtype=torch.float32) if keep_alpha else None
         check(lib().gadapt_block_forward(graph.c_ref, ptr(x_all), L, ptr(a), c * c if S > 1 else 0,
@@ -106,7 +110,7 @@ class _GrandEulerBlock(torch.autograd.Function):
             check(lib().gadapt_coeffs_backward(ptr(wq[s]), ptr(bq[s]), ptr(wk[s]), ptr(d_a), ptr(d_p0),
                                                ptr(d_wq[s]), ptr(d_bq[s]), ptr(d_wk[s]), ptr(d_bk[s]), c, st),
                   'gadapt_coeffs_backward')
-        return d_x0, d_wq, d_bq, d_wk, d_bk, d_lp, None, None, None
+        return d_x0, d_wq, d_bq, d_wk, d_bk, d_lp, None, None, None, None
 
 
 class _GrandResidual(torch.autograd.Function):
@@ -167,9 +171,13 @@ def grand_residual(x, wq, bq, wk, bk, scale: torch.Tensor, graph: MeshGraph, wan
 
 
 def grand_euler_block(x0: torch.Tensor, wq, bq, wk, bk, layer_params: torch.Tensor, graph: MeshGraph,
-                      num_layers: int, want_alpha: bool = False):
-    """Returns (x_L [N,C], alpha [L,E] in target-CSR order or None)."""
-    return _GrandEulerBlock.apply(x0.contiguous(), wq, bq, wk, bk, layer_params, graph, num_layers, want_alpha)
+                      num_layers: int, want_alpha: bool = False, x_all: Optional[torch.Tensor] = None):
+    """Returns (x_L [N,C], alpha [L,E] in target-CSR order or None).
+
+    `x_all` (optional): a contiguous [(L+1),N,C] buffer whose slot 0 IS `x0` (same memory); the
+    layers then write straight into it and no copy of x0 is made."""
+    return _GrandEulerBlock.apply(x0.contiguous(), wq, bq, wk, bk, layer_params, graph, num_layers, want_alpha,
+                                  None if x_all is None else [x_all])
 
 
 def score_scale(hidden_dim: int, temperature=None):
@@ -178,12 +186,14 @@ def score_scale(hidden_dim: int, temperature=None):
     return s if temperature is None else s / temperature
 
 
-def encode_linear(feats: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+def encode_linear(feats: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x0 = feats @ W^T (+b) through the native kernel (frozen encoder: no autograd)."""
     _require_gpu(feats, 'features')
     n, f = feats.shape
     c = weight.shape[0]
-    x0 = torch.empty(n, c, device=feats.device, dtype=torch.float32)
+    x0 = torch.empty(n, c, device=feats.device, dtype=torch.float32) if out is None else out
+    assert x0.shape == (n, c) and x0.is_contiguous()
     check(lib().gadapt_encode_linear(ptr(feats.contiguous()), ptr(weight.contiguous()),
                                      ptr(bias.contiguous()) if bias is not None else None,
                                      ptr(x0), n, f, c, current_stream(feats.device)), 'gadapt_encode_linear')

@@ -110,6 +110,7 @@ class GNN(nn.Module):
         self.end_MLmodel = None
         self._graphs: Dict[Tuple, MeshGraph] = {}
         self._dt_const = None
+        self._lp_const = None
 
     # ------------------------------------------------------------------ graph cache
     def _graph(self, data, num_nodes: int, device) -> MeshGraph:
@@ -138,6 +139,12 @@ class GNN(nn.Module):
     def _layer_params(self, device) -> torch.Tensor:
         """[L,2] = (dt_l, score_scale_l) on device; differentiable wrt `steps` / `sm_temp_a`."""
         L = self.opt['num_layers']
+        learnable = self.opt.get('learn_step') or self.opt.get('softmax_temp_type') == 'learnable_a'
+        if not learnable:
+            if self._lp_const is None or self._lp_const.device != device:
+                sc = Fn.score_scale(self.opt['hidden_dim'], self.conv_layers[0]._temperature())
+                self._lp_const = torch.tensor([[float(self.opt['time_step']), sc]] * L, device=device, dtype=torch.float32)
+            return self._lp_const
         if self.opt.get('learn_step'):
             dts = torch.cat([s.reshape(1) for s in self.steps])
         else:
@@ -170,13 +177,21 @@ class GNN(nn.Module):
         n = features.shape[0]
         graph = self._graph(data, n, dev)
 
+        fusable = self._fusable()
+        x_all = None
         if isinstance(self.enc, nn.Linear) and not self.enc.weight.requires_grad and self.enc.bias is None:
-            x = Fn.encode_linear(features, self.enc.weight)               # GNN.py:270
+            if fusable and not (self.training and o.get('dropout', 0.0) > 0):
+                # encoder output lands in slot 0 of the block's activation buffer: no copy
+                x_all = torch.empty(o['num_layers'] + 1, n, o['hidden_dim'], device=dev, dtype=torch.float32)
+                x = Fn.encode_linear(features, self.enc.weight, out=x_all[0])              # GNN.py:270
+            else:
+                x = Fn.encode_linear(features, self.enc.weight)
         else:
             x = self.enc(features)
-        x = F.dropout(x, o.get('dropout', 0.0), training=self.training)   # GNN.py:271
+        if x_all is None:
+            x = F.dropout(x, o.get('dropout', 0.0), training=self.training)               # GNN.py:271
 
-        if self._fusable():
+        if fusable:
             first = self.conv_layers[0]
             if o['share_conv']:
                 wq, bq = first.lin_query.weight.unsqueeze(0), first.lin_query.bias.unsqueeze(0)
@@ -188,7 +203,7 @@ class GNN(nn.Module):
                 bk = torch.stack([l.lin_key.bias for l in self.conv_layers])
             store = o['conv_type'] == 'GRAND' or isinstance(o.get('show_mesh_evol_plots'), bool)
             x, alpha = Fn.grand_euler_block(x, wq, bq, wk, bk, self._layer_params(dev), graph,
-                                            o['num_layers'], want_alpha=store)
+                                            o['num_layers'], want_alpha=store, x_all=x_all)
             if store:                                                      # GRAND_plus.py:253-256, :381
                 for l, layer in enumerate(self.conv_layers):
                     layer.stored_ei, layer._stored = graph.edge_index, (graph, alpha[l])

@@ -150,6 +150,15 @@ int gadapt_adam_step(float* param, const float* grad, float* exp_avg, float* exp
                      int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------ timing (bench only)
+ * When enabled, every launch of the three hot kernels is bracketed by hipEvents on its
+ * stream; kernel_id 0 = forward, 1 = backward target pass, 2 = backward source pass.
+ * gadapt_profile_read synchronises on the recorded events (host helper, not capturable). */
+int gadapt_profile_enable(int on);
+int gadapt_profile_read(int kernel_id, double* total_ms, int* count);
+int gadapt_profile_samples(int kernel_id, double* out_ms, int cap);   /* returns the number written */
+int gadapt_profile_reset(void);
+
 #ifdef __cplusplus
 }
 #endif
