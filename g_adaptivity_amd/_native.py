@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgadapt_hip.so')
+LIB_PATH = os.environ.get('GADAPT_LIB') or os.path.join(_HERE, 'libgadapt_hip.so')   # override: A/B builds only
 
 SUPPORTED_HIDDEN = (4, 8, 16, 32, 64, 128)
 
@@ -16,7 +16,7 @@ SUPPORTED_HIDDEN = (4, 8, 16, 32, 64, 128)
 class GadaptGraph(C.Structure):
     _fields_ = [('n_nodes', C.c_int32), ('n_edges', C.c_int32),
                 ('rowptr_t', C.c_void_p), ('col_t', C.c_void_p),
-                ('rowptr_s', C.c_void_p), ('col_s', C.c_void_p), ('perm_s', C.c_void_p)]
+                ('rowptr_s', C.c_void_p), ('col_s', C.c_void_p), ('perm_s', C.c_void_p), ('tpos_s', C.c_void_p)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -27,7 +27,7 @@ PROTOTYPES = {
     'gadapt_supported_hidden_dim': (_I, [_I]),
     'gadapt_last_error': (C.c_char_p, []),
     'gadapt_abi_version': (_I, []),
-    'gadapt_csr_build_host': (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P]),
+    'gadapt_csr_build_host': (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P]),
     'gadapt_coeffs_forward': (_I, [_P, _P, _P, _P, _P, _I, _P]),
     'gadapt_coeffs_backward': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'gadapt_encode_linear': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
@@ -44,6 +44,7 @@ PROTOTYPES = {
     'gadapt_profile_read': (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'gadapt_profile_samples': (_I, [_I, C.POINTER(C.c_double), _I]),
     'gadapt_profile_reset': (_I, []),
+    'gadapt_debug_occupancy': (_I, [_I, C.POINTER(C.c_int)]),
 }
 
 _lib = None

@@ -11,9 +11,9 @@
 
 extern "C" int gadapt_csr_build_host(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
                                      int32_t* rowptr_t, int32_t* col_t, int32_t* eid_t,
-                                     int32_t* rowptr_s, int32_t* col_s, int32_t* perm_s) {
+                                     int32_t* rowptr_s, int32_t* col_s, int32_t* perm_s, int32_t* tpos_s) {
     if (!src || !dst || n_edges < 0 || n_nodes <= 0 || n_nodes > INT32_MAX || n_edges > INT32_MAX ||
-        !rowptr_t || !col_t || !eid_t || !rowptr_s || !col_s || !perm_s)
+        !rowptr_t || !col_t || !eid_t || !rowptr_s || !col_s || !perm_s || !tpos_s)
         return GADAPT_E_BADARG;
     const int64_t N = n_nodes, E = n_edges;
     for (int64_t i = 0; i <= N; ++i) rowptr_t[i] = rowptr_s[i] = 0;
@@ -36,6 +36,7 @@ extern "C" int gadapt_csr_build_host(const int64_t* src, const int64_t* dst, int
         const int32_t s = fill_s[src[e]]++;
         col_s[s] = (int32_t)dst[e];
         perm_s[s] = slot;
+        tpos_s[slot] = s;
     }
     return GADAPT_OK;
 }

@@ -23,6 +23,16 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define GADAPT_MAXD 8           // in/out degree handled from registers; larger rows take the loop path
+// minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
+#ifndef GADAPT_WAVES_FWD
+#define GADAPT_WAVES_FWD 4
+#endif
+#ifndef GADAPT_WAVES_BWD_T
+#define GADAPT_WAVES_BWD_T 2
+#endif
+#ifndef GADAPT_WAVES_BWD_S
+#define GADAPT_WAVES_BWD_S 2
+#endif
 #define GADAPT_SLAB_CHUNKS 32   // second-level partials of the slab reduction
 
 // ------------------------------------------------------------------------------------------------
@@ -45,6 +55,7 @@ extern "C" int gadapt_supported_hidden_dim(int c) {
 // optional per-kernel timing (bench/roofline only): HIP events on the launch stream around every
 // hot-kernel launch.  Off by default; when off the launch path touches none of this.
 // ------------------------------------------------------------------------------------------------
+#include <type_traits>
 #include <vector>
 struct ProfRec { int id; hipEvent_t a, b; };
 static bool g_prof_on = false;
@@ -102,7 +113,11 @@ template <int C> struct Cfg {
     static constexpr int TILE_FLOATS = TM * LD;
     static constexpr int CB = C / 32;                  // 32-wide column blocks (MFMA path)
     static constexpr int RB = TM / 32;                 // 32-high row blocks
-    static constexpr int LDS_BYTES = 2 * TILE_FLOATS * 4;
+    static constexpr int CAP = 7 * TM;                 // CSR entries of one tile staged in LDS (rest read from HBM)
+    static constexpr int COLN = CAP + 64;              // + padding: reads up to MAXD past a row's end stay in
+                                                       //   bounds and return a valid node id (weight 0)
+    // LDS: two [TM][LD] tiles, rowptr[TM+1] (padded to TM+4), col[COLN], aux[AUXW*COLN]
+    static constexpr int lds_bytes(int auxw) { return (2 * TILE_FLOATS + (TM + 4) + COLN + auxw * COLN) * 4; }
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -112,10 +127,31 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
 __device__ __forceinline__ void axpy4(float4& y, float a, const float4& x) {
     y.x = fmaf(a, x.x, y.x); y.y = fmaf(a, x.y, y.y); y.z = fmaf(a, x.z, y.z); y.w = fmaf(a, x.w, y.w);
 }
+
+// Sum over the LPN lanes that share a node, result in every lane.  DPP row operations (no LDS
+// crossbar): quad_perm xor-1 / xor-2, row_half_mirror, row_mirror; the 32-lane case adds one
+// ds_swizzle (xor 16).
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(float, moved);
+}
 template <int LPN> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int m = 1; m < LPN; m <<= 1) v += __shfl_xor(v, m, 64);
+    if constexpr (LPN >= 2) v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    if constexpr (LPN >= 4) v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    if constexpr (LPN >= 8) v = dpp_add<0x141>(v);     // row_half_mirror
+    if constexpr (LPN >= 16) v = dpp_add<0x140>(v);    // row_mirror
+    if constexpr (LPN >= 32) v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
     return v;
+}
+
+// Row gather with a 32-bit byte offset (the launcher checks N*C*4 < 4 GiB).
+template <int C> __device__ __forceinline__ float4 ld_row4(const float* __restrict__ base, int row, int sub) {
+    const uint32_t off = (uint32_t)row * (uint32_t)(C * 4) + (uint32_t)sub * 16u;
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off);
+}
+template <int C> __device__ __forceinline__ void st_row4(float* __restrict__ base, int row, int sub, const float4& v) {
+    const uint32_t off = (uint32_t)row * (uint32_t)(C * 4) + (uint32_t)sub * 16u;
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + off) = v;
 }
 
 // Tiles [t, t_end) step `step` for this workgroup.  Workgroups with equal blockIdx%8 are observed to
@@ -145,11 +181,14 @@ template <int C, bool TRANS> struct TileGemm {
     float bias;
     int cb, rb0, lane;
 
-    __device__ __forceinline__ void load(const float* __restrict__ M, const float* __restrict__ bias_vec,
-                                         int lane_, int wave) {
+    __device__ __forceinline__ void init(int lane_, int wave) {
         lane = lane_;
         cb = wave % K::CB;
         rb0 = wave / K::CB;
+    }
+    // Issue the B-operand loads ([C,C] matrix: L2-resident, same lines for every workgroup).  Called per
+    // tile, ahead of the barrier that precedes run(), so the fragments occupy registers only around the GEMM.
+    __device__ __forceinline__ void load(const float* __restrict__ M, const float* __restrict__ bias_vec) {
         const int h = lane >> 5, j = cb * 32 + (lane & 31);
 #pragma unroll
         for (int q = 0; q < C / 8; ++q) {
@@ -197,16 +236,187 @@ template <int C> __device__ __forceinline__ void stage_tile(const float* __restr
                                                             int node0, int n_nodes, int tid) {
     using K = Cfg<C>;
     constexpr int V = C / 4;
-    const float4* src4 = reinterpret_cast<const float4*>(src);
 #pragma unroll
     for (int idx = tid; idx < K::TM * V; idx += 256) {
         const int r = idx / V, c4 = idx % V;
         const int node = node0 + r;
         float4 v = f4zero();
-        if (node < n_nodes) v = src4[(size_t)node * V + c4];
+        if (node < n_nodes) v = ld_row4<C>(src, node, c4);
         *reinterpret_cast<float4*>(tile + r * K::LD + 4 * c4) = v;
     }
 }
+
+// The tile's slice of one CSR orientation in LDS: rowptr[TM+1], col[CAP] and AUXW per-edge words.
+// A tile whose slice does not fit (more than CAP entries) or that has a row longer than MAXD is flagged
+// "slow" for the whole workgroup and walks the HBM copy with plain loops instead.
+template <int C, int AUXW> struct TileCsr {
+    using K = Cfg<C>;
+    int* rp; int* col; float* aux;
+    const int32_t* rowptr_g; const int32_t* col_g; const float* aux_g;
+    int ebase, parity;
+
+    __device__ __forceinline__ void bind(float* lds_after_tiles, const int32_t* rowptr_g_, const int32_t* col_g_, const float* aux_g_) {
+        rp = reinterpret_cast<int*>(lds_after_tiles);
+        col = rp + (K::TM + 4);
+        aux = reinterpret_cast<float*>(col + K::COLN);
+        rowptr_g = rowptr_g_; col_g = col_g_; aux_g = aux_g_;
+    }
+    // Returns the tile's largest row length (block-uniform), or -1 for a slow tile (a row longer than
+    // MAXD, or more than CAP entries).  Acts as the workgroup barrier after staging.
+    // (block-wide bitwise OR through two alternating LDS words: __syncthreads_or is only a logical OR)
+    __device__ __forceinline__ void init(int tid) {
+        if (tid == 0) { rp[K::TM + 1] = 0; rp[K::TM + 2] = 0; }
+        parity = 0;
+        __syncthreads();
+    }
+    __device__ __forceinline__ int stage(int node0, int n_nodes, int tid) {
+        int bits = 0;
+        for (int idx = tid; idx <= K::TM; idx += 256) {
+            const int lo = rowptr_g[min(node0 + idx, n_nodes)];
+            rp[idx] = lo;
+            if (idx < K::TM) bits |= 1 << min(rowptr_g[min(node0 + idx + 1, n_nodes)] - lo, GADAPT_MAXD + 1);
+        }
+        ebase = rowptr_g[node0];
+        const int total = rowptr_g[min(node0 + K::TM, n_nodes)] - ebase;
+        const int cnt = min(total, K::CAP);
+        for (int idx = tid; idx < cnt + GADAPT_MAXD; idx += 256) col[idx] = (idx < cnt) ? col_g[ebase + idx] : node0;
+        if constexpr (AUXW > 0)
+            for (int idx = tid; idx < AUXW * (cnt + GADAPT_MAXD); idx += 256)
+                aux[idx] = (idx < AUXW * cnt) ? aux_g[(size_t)AUXW * ebase + idx] : 0.f;
+        if (total > K::CAP) bits |= 1 << (GADAPT_MAXD + 1);
+        int* flag = rp + K::TM + 1 + parity;
+        if (bits) atomicOr(flag, bits);
+        __syncthreads();
+        bits = *flag;
+        parity ^= 1;
+        if (tid == 0) rp[K::TM + 1 + parity] = 0;               // next tile's word; its last readers passed a barrier already
+        if (bits >> (GADAPT_MAXD + 1)) return -1;
+        return 31 - __builtin_clz(bits | 1);
+    }
+};
+
+// value held for edge `sub` of this lane's node, picked from a group-uniform array (the asm keeps it a
+// select chain: hipcc otherwise spills the array to scratch and indexes it)
+template <int N> __device__ __forceinline__ float pick(const float (&v)[N], int sub) {
+    float r = v[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) { r = (sub == k) ? v[k] : r; asm volatile("" : "+v"(r)); }
+    return r;
+}
+// Sum over the node's lanes for N independent values at once, stage by stage, so that consecutive DPP
+// instructions are independent (a dependent DPP chain pays 2 wait states per step).
+template <int LPN, int N> __device__ __forceinline__ void group_sum_n(float (&v)[N]) {
+    if constexpr (LPN >= 2) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = dpp_add<0xB1>(v[k]);
+    }
+    if constexpr (LPN >= 4) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = dpp_add<0x4E>(v[k]);
+    }
+    if constexpr (LPN >= 8) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = dpp_add<0x141>(v[k]);
+    }
+    if constexpr (LPN >= 16) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = dpp_add<0x140>(v[k]);
+    }
+    if constexpr (LPN >= 32) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v[k]), 0x401F));
+    }
+}
+template <int V> struct IntTag { static constexpr int value = V; };
+// Software pipeline over the ITERS node slots of a tile: rows of slot it+1 are requested before slot it
+// is consumed.  `before_first` runs after the first request (e.g. the MFMA phase).  The widest row
+// bound keeps a single buffer: two would cost a wave of occupancy for every tile shape.
+template <int ITERS, typename BufT, typename Fetch, typename Consume, typename Mid>
+__device__ __forceinline__ void run_pipeline(Fetch&& fetch, Consume&& consume, Mid&& before_first) {
+    if constexpr (BufT::N <= 6) {
+        BufT b0, b1;
+        fetch(b0, 0);
+        before_first();
+#pragma unroll
+        for (int it = 0; it < ITERS; it += 2) {
+            if (it + 1 < ITERS) fetch(b1, it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(b0, it);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 < ITERS) {
+                if (it + 2 < ITERS) fetch(b0, it + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(b1, it + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        BufT b0;
+        fetch(b0, 0);
+        before_first();
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            consume(b0, it);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 < ITERS) fetch(b0, it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+// Run f with the smallest compiled row-length bound that covers dmax (block-uniform).
+template <typename F> __device__ __forceinline__ void dispatch_dmax(int dmax, F&& f) {
+    if (dmax <= 2) f(IntTag<2>{});
+    else if (dmax <= 6) f(IntTag<6>{});
+    else f(IntTag<GADAPT_MAXD>{});
+}
+
+// One node's in-edge rows (+ its own gradient row) for the target pass.
+template <int NROWS> struct TBuf {
+    static constexpr int N = NROWS;
+    float4 r[NROWS]; float4 g;
+    int deg, el0;
+};
+// One node's out-edge rows for the source pass: g_i and x_i of every target i.
+template <int NROWS> struct SBuf {
+    static constexpr int N = NROWS;
+    float4 g[NROWS], x[NROWS];
+    int deg, el0;
+};
+// One node's in-edge rows, fetched ahead of use.
+template <int NROWS> struct RowBuf {
+    static constexpr int N = NROWS;
+    float4 r[NROWS];
+    int deg, el0;          // degree (0 for nodes past N; > MAXD flags the slow path), first entry (tile-local)
+};
+
+// In-kernel phase stamps: diagnostic builds only (-DGADAPT_STAMPS); never compiled into the shipped library.
+#ifdef GADAPT_STAMPS
+static unsigned long long* g_stamp_buf = nullptr;
+extern "C" int gadapt_debug_set_stamp_buffer(void* p) { g_stamp_buf = static_cast<unsigned long long*>(p); return 0; }
+#define GADAPT_STAMP_L(buf, slot_)                                                                 \
+    do {                                                                                           \
+        if ((buf) && threadIdx.x == 256) {                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+            (buf)[(size_t)blockIdx.x * 32 + (slot_)] = t_;                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+    } while (0)
+#define GADAPT_STAMP(buf, slot_)                                                                   \
+    do {                                                                                           \
+        if ((buf) && threadIdx.x == 0) {                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+            (buf)[(size_t)blockIdx.x * 32 + (slot_)] = t_;                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+    } while (0)
+#else
+#define GADAPT_STAMP(buf, slot_) do { } while (0)
+#define GADAPT_STAMP_L(buf, slot_) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -217,26 +427,27 @@ struct FwdArgs {
     const int32_t* rowptr; const int32_t* col;
     float* alpha_out;
     int n_nodes, n_tiles, residual_only;
+    unsigned long long* stamps;
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void grand_fwd_kernel(FwdArgs p) {
+__global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArgs p) {
     using K = Cfg<C>;
     extern __shared__ float4 smem4[];
     float* xs = reinterpret_cast<float*>(smem4);
     float* ps = xs + K::TILE_FLOATS;
+    TileCsr<C, 0> csr;
+    csr.bind(ps + K::TILE_FLOATS, p.rowptr, p.col, nullptr);
+    csr.init(threadIdx.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
     const float dt = p.lp[0], sc = p.lp[1];
-    const float4* xin4 = reinterpret_cast<const float4*>(p.x_in);
-    float4* xout4 = reinterpret_cast<float4*>(p.x_out);
-    constexpr int V = C / 4;
 
     TileGemm<C, false> gemm;
     float arow[K::MFMA ? 1 : 4][K::MFMA ? 1 : C];
     float4 p0v = f4zero();
     if constexpr (K::MFMA) {
-        gemm.load(p.A, p.p0, lane, wave);
+        gemm.init(lane, wave);
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -245,89 +456,435 @@ __global__ __launch_bounds__(256) void grand_fwd_kernel(FwdArgs p) {
         p0v = *reinterpret_cast<const float4*>(p.p0 + 4 * sub);
     }
 
+    auto projected = [&](int li) {                               // P_i = A x_i + p0 for this lane's 4 channels
+        float4 Pi;
+        if constexpr (K::MFMA) {
+            Pi = *reinterpret_cast<const float4*>(ps + li * K::LD + 4 * sub);
+        } else {
+            Pi = p0v;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float xc = xs[li * K::LD + c];
+                Pi.x = fmaf(arow[0][c], xc, Pi.x); Pi.y = fmaf(arow[1][c], xc, Pi.y);
+                Pi.z = fmaf(arow[2][c], xc, Pi.z); Pi.w = fmaf(arow[3][c], xc, Pi.w);
+            }
+        }
+        return Pi;
+    };
+    auto finish = [&](int li, int i, const float4& m) {          // res = m - x (GRAND_plus.py:267); x + dt*res (GNN.py:291)
+        const float4 xi = *reinterpret_cast<const float4*>(xs + li * K::LD + 4 * sub);
+        float4 o;
+        o.x = m.x - xi.x; o.y = m.y - xi.y; o.z = m.z - xi.z; o.w = m.w - xi.w;
+        if (!p.residual_only) {
+            o.x = fmaf(dt, o.x, xi.x); o.y = fmaf(dt, o.y, xi.y); o.z = fmaf(dt, o.z, xi.z); o.w = fmaf(dt, o.w, xi.w);
+        }
+        st_row4<C>(p.x_out, i, sub, o);
+    };
+
+    // Fast path, row length bounded by the compile-time DM: every lane issues exactly DM gathers (slots past
+    // its own row length re-read the row's last neighbour and get weight 0), so there is no divergence.
+    auto fetch = [&](auto& b, int node0, int it) {
+        constexpr int DM = std::remove_reference_t<decltype(b)>::N;
+        const int li = it * K::SLOTS + slot;
+        const int i = node0 + li;
+        b.el0 = csr.rp[li] - csr.ebase;
+        b.deg = (i < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) b.r[k] = ld_row4<C>(p.x_in, csr.col[b.el0 + k], sub);   // k >= deg: some valid row, weight 0
+    };
+
+    auto consume = [&](const auto& b, int node0, int it) {
+        constexpr int DM = std::remove_reference_t<decltype(b)>::N;
+        const int li = it * K::SLOTS + slot;
+        const int i = node0 + li;
+        const float4 Pi = projected(li);
+        const int deg = b.deg;
+        float s[DM];
+#pragma unroll
+        for (int k = 0; k < DM; ++k) s[k] = dot4(Pi, b.r[k]);
+        group_sum_n<K::LPN>(s);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            s[k] = (k < deg) ? s[k] * sc : -INFINITY;
+            mx = fmaxf(mx, s[k]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            s[k] = (k < deg) ? __expf(s[k] - mx) : 0.f;         // deg == 0: mx = -inf, nothing is summed
+            den += s[k];
+        }
+        const float inv = __builtin_amdgcn_rcpf(den + 1e-16f);  // PyG softmax epsilon
+        float4 m = f4zero();
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            s[k] *= inv;
+            axpy4(m, s[k], b.r[k]);
+        }
+        if (p.alpha_out) {
+            if constexpr (K::LPN >= DM) {
+                const float mine = pick(s, sub);
+                if (sub < deg) p.alpha_out[csr.ebase + b.el0 + sub] = mine;
+            } else {
+#pragma unroll
+                for (int k = 0; k < DM; ++k)
+                    if (k < deg && (k % K::LPN) == sub) p.alpha_out[csr.ebase + b.el0 + k] = s[k];
+            }
+        }
+        if (i < p.n_nodes) finish(li, i, m);
+    };
+
+    // any row length, CSR straight from HBM: three sweeps over the row
+    auto slow_node = [&](int node0, int it) {
+        const int li = it * K::SLOTS + slot;
+        const int i = node0 + li;
+        if (i >= p.n_nodes) return;
+        const float4 Pi = projected(li);
+        const int e0 = p.rowptr[i], deg = p.rowptr[i + 1] - e0;
+        float mx = -INFINITY;
+        for (int k = 0; k < deg; ++k)
+            mx = fmaxf(mx, group_sum<K::LPN>(dot4(Pi, ld_row4<C>(p.x_in, p.col[e0 + k], sub))) * sc);
+        float den = 0.f;
+        for (int k = 0; k < deg; ++k)
+            den += __expf(group_sum<K::LPN>(dot4(Pi, ld_row4<C>(p.x_in, p.col[e0 + k], sub))) * sc - mx);
+        const float inv = 1.0f / (den + 1e-16f);
+        float4 m = f4zero();
+        for (int k = 0; k < deg; ++k) {
+            const float4 v = ld_row4<C>(p.x_in, p.col[e0 + k], sub);
+            const float a = __expf(group_sum<K::LPN>(dot4(Pi, v)) * sc - mx) * inv;
+            axpy4(m, a, v);
+            if (p.alpha_out && (k % K::LPN) == sub) p.alpha_out[e0 + k] = a;
+        }
+        finish(li, i, m);
+    };
+
     const TileRange tr = tile_range(p.n_tiles);
     for (int t = tr.t; t < tr.t_end; t += tr.step) {
         const int node0 = t * K::TM;
+        const int tslot = ((t - tr.t) / tr.step) * 8;           // stamps of the first 4 tiles of this workgroup
+        GADAPT_STAMP(p.stamps, tslot + 0);
+        if constexpr (K::MFMA) gemm.load(p.A, p.p0);
         stage_tile<C>(p.x_in, xs, node0, p.n_nodes, tid);
-        __syncthreads();
-        if constexpr (K::MFMA) {
-            gemm.run(xs, ps);
-            __syncthreads();
-        }
-#pragma unroll 1
-        for (int it = 0; it < K::ITERS; ++it) {
-            const int li = it * K::SLOTS + slot;
-            const int i = node0 + li;
-            if (i >= p.n_nodes) continue;
-            float4 Pi;
+        const int dmax = csr.stage(node0, p.n_nodes, tid);      // barrier inside
+        GADAPT_STAMP(p.stamps, tslot + 1);
+        if (dmax >= 0) {
+            dispatch_dmax(dmax, [&](auto tag) {
+                run_pipeline<K::ITERS, RowBuf<decltype(tag)::value>>(
+                    [&](auto& b, int it) { fetch(b, node0, it); },
+                    [&](const auto& b, int it) { consume(b, node0, it); GADAPT_STAMP(p.stamps, tslot + 3 + it); },
+                    [&]() {                                      // neighbour rows are in flight under the MFMA phase
+                        if constexpr (K::MFMA) { gemm.run(xs, ps); __syncthreads(); }
+                        GADAPT_STAMP(p.stamps, tslot + 2);
+                    });
+            });
+        } else {
             if constexpr (K::MFMA) {
-                Pi = *reinterpret_cast<const float4*>(ps + li * K::LD + 4 * sub);
-            } else {
-                Pi = p0v;
+                gemm.run(xs, ps);
+                __syncthreads();
+            }
+#pragma unroll 1
+            for (int it = 0; it < K::ITERS; ++it) slow_node(node0, it);
+        }
+        __syncthreads();
+        GADAPT_STAMP(p.stamps, tslot + 7);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// forward, matrix-core path (C >= 32): loader wave + compute waves
+//
+// A workgroup is 5 waves.  Waves 0-3 compute: P = x A^T + p0 on the matrix cores (B fragments from L2 in
+// two halves), written IN PLACE over the x tile, then the edge walk.  Wave 4 only moves data: while the
+// compute waves work on tile k it fetches tile k+1 (x rows + the CSR slice) into the other LDS buffer and
+// derives the tile's row-length bound, so HBM latency is hidden behind MFMA/VALU work instead of being
+// serialised with it (measured: staging alone was 18 of 40 us when every wave staged, then computed).
+// LDS tiles are unpadded with 16-byte chunks XOR-swizzled by row (conflict-free for every access below).
+// Raw s_barrier + lgkmcnt(0): the loader's global loads stay in flight across the barriers.
+// ------------------------------------------------------------------------------------------------
+#ifndef GADAPT_WAVES_FWD_MFMA
+#define GADAPT_WAVES_FWD_MFMA 4
+#endif
+template <int C> struct Swz {
+    static constexpr int V = C / 4;
+    static __device__ __forceinline__ int off4(int row, int c4) { return row * C + ((c4 ^ (row & (V - 1))) << 2); }
+    static __device__ __forceinline__ int off(int row, int col) { return off4(row, col >> 2) | (col & 3); }
+};
+__device__ __forceinline__ void wg_barrier() {                 // LDS traffic of this wave done, then rendezvous
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// LDS image of one tile: x rows (later P rows), rowptr, col, and the row-length bound
+template <int C, int AUXW> struct TileSlot {
+    using K = Cfg<C>;
+    static constexpr int X_FLOATS = K::TM * C;
+    static constexpr int WORDS = X_FLOATS + (K::TM + 4) + K::COLN + AUXW * K::COLN;
+    float* x; int* rp; int* col; float* aux;
+    __device__ __forceinline__ void bind(float* base) {
+        x = base; rp = reinterpret_cast<int*>(base + X_FLOATS); col = rp + (K::TM + 4);
+        aux = reinterpret_cast<float*>(col + K::COLN);
+    }
+    __device__ __forceinline__ int ebase() const { return rp[0]; }
+    __device__ __forceinline__ int dmax() const { return rp[K::TM + 1]; }     // -1: slow tile
+};
+template <int NROWS> struct FBuf {
+    static constexpr int N = NROWS;
+    float4 r[NROWS]; float4 self;
+    int deg, el0;
+};
+
+// Loader wave: global -> registers -> LDS for one tile.  Rows past N are zero.  64 lanes.  The first
+// chunk of loads is issued BEFORE the compute waves' mid-tile barriers (the loader just arrives at them
+// with the loads in flight); the rest follows in chunks of at most 8 float4 per lane.
+template <int C, int AUXW>
+__device__ __forceinline__ void loader_fetch_tile(const float* __restrict__ xsrc, const int32_t* __restrict__ rowptr_g,
+                                                  const int32_t* __restrict__ col_g, const float* __restrict__ aux_g,
+                                                  int node0, int n_nodes, int lane, const TileSlot<C, AUXW>& dst, int n_mid_barriers) {
+    using K = Cfg<C>;
+    using S = Swz<C>;
+    constexpr int V = C / 4;
+    constexpr int XN = K::TM * V / 64;                          // float4 per lane for the x tile
+    constexpr int XCH = XN < 8 ? XN : 8;
+    constexpr int RN = (K::TM + 1 + 63) / 64;
+    constexpr int CN = K::COLN / 64;
+    float4 xv[XCH];
+    int rpv[RN], cv[CN];
+    auto x_load = [&](int c0) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float xc = xs[li * K::LD + c];
-                    Pi.x = fmaf(arow[0][c], xc, Pi.x); Pi.y = fmaf(arow[1][c], xc, Pi.y);
-                    Pi.z = fmaf(arow[2][c], xc, Pi.z); Pi.w = fmaf(arow[3][c], xc, Pi.w);
+        for (int q = 0; q < XCH; ++q) {
+            const int idx = (c0 + q) * 64 + lane, r = idx / V, c4 = idx % V;
+            xv[q] = (node0 + r < n_nodes) ? ld_row4<C>(xsrc, node0 + r, c4) : f4zero();
+        }
+    };
+    auto x_store = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < XCH; ++q) {
+            const int idx = (c0 + q) * 64 + lane, r = idx / V, c4 = idx % V;
+            *reinterpret_cast<float4*>(dst.x + S::off4(r, c4)) = xv[q];
+        }
+    };
+    x_load(0);
+#pragma unroll
+    for (int q = 0; q < RN; ++q) rpv[q] = rowptr_g[min(node0 + min(q * 64 + lane, K::TM), n_nodes)];
+    const int ebase = rowptr_g[node0];
+    const int total = rowptr_g[min(node0 + K::TM, n_nodes)] - ebase;
+    const int cnt = min(total, K::CAP);
+#pragma unroll
+    for (int q = 0; q < CN; ++q) cv[q] = (q * 64 + lane < cnt) ? col_g[ebase + q * 64 + lane] : node0;   // padding: a valid node
+    for (int b = 0; b < n_mid_barriers; ++b) __builtin_amdgcn_s_barrier();
+    x_store(0);
+#pragma unroll 1
+    for (int c0 = XCH; c0 < XN; c0 += XCH) { x_load(c0); x_store(c0); }
+    int bits = 0;
+#pragma unroll
+    for (int q = 0; q < RN; ++q) {
+        const int idx = q * 64 + lane;
+        if (idx <= K::TM) dst.rp[idx] = rpv[q];
+        // row length of node idx = rowptr[idx+1]-rowptr[idx]; the neighbour lane holds rowptr[idx+1]
+        int nxt = __shfl_down(rpv[q], 1, 64);
+        if (q + 1 < RN) { const int wrap = __shfl(rpv[q + 1 < RN ? q + 1 : q], 0, 64); if (lane == 63) nxt = wrap; }
+        if (idx < K::TM) bits |= 1 << min(max(nxt - rpv[q], 0), GADAPT_MAXD + 1);
+    }
+#pragma unroll
+    for (int q = 0; q < CN; ++q) dst.col[q * 64 + lane] = cv[q];
+    if constexpr (AUXW > 0) {
+#pragma unroll 1
+        for (int q = 0; q < AUXW * CN; ++q) {
+            const int idx = q * 64 + lane;
+            dst.aux[idx] = (idx < AUXW * cnt) ? aux_g[(size_t)AUXW * ebase + idx] : 0.f;
+        }
+    }
+    if (total > K::CAP) bits |= 1 << (GADAPT_MAXD + 1);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) bits |= __shfl_xor(bits, m, 64);
+    if (lane == 0) dst.rp[K::TM + 1] = (bits >> (GADAPT_MAXD + 1)) ? -1 : 31 - __builtin_clz(bits | 1);
+}
+
+template <int C>
+__global__ __launch_bounds__(320, GADAPT_WAVES_FWD_MFMA) void grand_fwd_mfma_kernel(FwdArgs p) {
+    using K = Cfg<C>;
+    using S = Swz<C>;
+    static_assert(K::MFMA, "matrix-core path");
+    extern __shared__ float4 smem4[];
+    float* lds = reinterpret_cast<float*>(smem4);
+    auto slot_of = [&](int which) { TileSlot<C, 0> s_; s_.bind(lds + which * TileSlot<C, 0>::WORDS); return s_; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const TileRange tr = tile_range(p.n_tiles);
+
+    if (wave == 4) {
+        // ------------------------------------------------------------------ loader wave
+        if (tr.t < tr.t_end) loader_fetch_tile<C, 0>(p.x_in, p.rowptr, p.col, nullptr, tr.t * K::TM, p.n_nodes, lane, slot_of(0), 0);
+        wg_barrier();                                            // first tile staged
+        int cur = 0;
+        for (int t = tr.t; t < tr.t_end; t += tr.step, cur ^= 1) {
+            const int lslot = 16 + ((t - tr.t) / tr.step) * 4;
+            GADAPT_STAMP_L(p.stamps, lslot + 0);
+            if (t + tr.step < tr.t_end)
+                loader_fetch_tile<C, 0>(p.x_in, p.rowptr, p.col, nullptr, (t + tr.step) * K::TM, p.n_nodes, lane, slot_of(cur ^ 1), 2);
+            else { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+            GADAPT_STAMP_L(p.stamps, lslot + 1);
+            wg_barrier();                                        // end of tile: next slot is staged
+            GADAPT_STAMP_L(p.stamps, lslot + 2);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    const int slot = tid / K::LPN, sub = tid % K::LPN;
+    const int h = lane >> 5, r31 = lane & 31;
+    const float dt = p.lp[0], sc = p.lp[1];
+    constexpr int BPW = (K::CB * K::RB) / 4;                    // 32x32 output blocks per wave
+    const int cb = wave % K::CB, rb0 = wave / K::CB;
+    const int j = cb * 32 + r31;
+
+    auto finish = [&](int i, const float4& xi, const float4& m) {
+        float4 o;                                                // res = m - x (GRAND_plus.py:267); x + dt*res (GNN.py:291)
+        o.x = m.x - xi.x; o.y = m.y - xi.y; o.z = m.z - xi.z; o.w = m.w - xi.w;
+        if (!p.residual_only) {
+            o.x = fmaf(dt, o.x, xi.x); o.y = fmaf(dt, o.y, xi.y); o.z = fmaf(dt, o.z, xi.z); o.w = fmaf(dt, o.w, xi.w);
+        }
+        st_row4<C>(p.x_out, i, sub, o);
+    };
+
+    GADAPT_STAMP(p.stamps, 31);
+#ifdef GADAPT_STAMPS
+    if (p.stamps && threadIdx.x == 0) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        p.stamps[(size_t)blockIdx.x * 32 + 30] = ((unsigned long long)hwid << 32) | xcc;
+    }
+#endif
+    wg_barrier();                                                // first tile staged
+    int cur = 0;
+    for (int t = tr.t; t < tr.t_end; t += tr.step, cur ^= 1) {
+        const int node0 = t * K::TM;
+        const TileSlot<C, 0> ts = slot_of(cur);
+        float* xs = ts.x;
+        const int tslot = ((t - tr.t) / tr.step) * 8;
+        GADAPT_STAMP(p.stamps, tslot + 0);
+        // ---- P = x A^T + p0 on the matrix cores, B fragments in two halves
+        f32x16 acc[BPW];
+#pragma unroll
+        for (int b = 0; b < BPW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float bf[C / 4];
+#pragma unroll
+            for (int q = 0; q < C / 16; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(p.A + (size_t)j * C + 8 * (half * (C / 16) + q) + 4 * h);
+                bf[4 * q + 0] = v.x; bf[4 * q + 1] = v.y; bf[4 * q + 2] = v.z; bf[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int b = 0; b < BPW; ++b) {
+                const int row = (rb0 + b * (4 / K::CB)) * 32 + r31;
+#pragma unroll
+                for (int q = 0; q < C / 16; ++q) {
+                    const int qq = half * (C / 16) + q;
+                    const float4 a = *reinterpret_cast<const float4*>(xs + S::off4(row, 2 * qq + h));
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bf[4 * q + 0], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bf[4 * q + 1], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bf[4 * q + 2], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bf[4 * q + 3], acc[b], 0, 0, 0);
                 }
             }
-            const int e0 = p.rowptr[i], deg = p.rowptr[i + 1] - e0;
-            float4 m = f4zero();
-            if (deg <= GADAPT_MAXD) {
-                float4 xj[GADAPT_MAXD];
-                float s[GADAPT_MAXD];
+        }
+        const float bias = p.p0[j];
+        GADAPT_STAMP(p.stamps, tslot + 1);
+        wg_barrier();                                           // (mid 1) every wave has read its x rows
 #pragma unroll
-                for (int k = 0; k < GADAPT_MAXD; ++k) {
-                    xj[k] = f4zero();
-                    if (k < deg) xj[k] = xin4[(size_t)p.col[e0 + k] * V + sub];
-                }
+        for (int b = 0; b < BPW; ++b) {
+            const int rbase = (rb0 + b * (4 / K::CB)) * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+                xs[S::off(row, j)] = acc[b][r] + bias;
+            }
+        }
+        wg_barrier();                                           // (mid 2) P tile complete
+        GADAPT_STAMP(p.stamps, tslot + 2);
+        // ---- edge walk
+        const int ebase = ts.ebase();
+        const int dmax = ts.dmax();
+        if (dmax >= 0) {
+            dispatch_dmax(dmax, [&](auto tag) {
+                constexpr int DM = decltype(tag)::value;
+                auto fetch = [&](FBuf<DM>& b, int it) {
+                    const int li = it * K::SLOTS + slot;
+                    const int i = node0 + li;
+                    const int self = min(i, p.n_nodes - 1);
+                    b.el0 = ts.rp[li] - ebase;
+                    b.deg = (i < p.n_nodes) ? ts.rp[li + 1] - ts.rp[li] : 0;
+                    b.self = ld_row4<C>(p.x_in, self, sub);
+#pragma unroll
+                    for (int k = 0; k < DM; ++k) b.r[k] = ld_row4<C>(p.x_in, ts.col[b.el0 + k], sub);   // k >= deg: valid row, weight 0
+                };
+                auto consume = [&](const FBuf<DM>& b, int it) {
+                    const int li = it * K::SLOTS + slot;
+                    const int i = node0 + li;
+                    const int deg = b.deg;
+                    const float4 Pi = *reinterpret_cast<const float4*>(xs + S::off4(li, sub));
+                    float s[DM];
+#pragma unroll
+                    for (int k = 0; k < DM; ++k) s[k] = dot4(Pi, b.r[k]);
+                    group_sum_n<K::LPN>(s);
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < DM; ++k) {
+                        s[k] = (k < deg) ? s[k] * sc : -INFINITY;
+                        mx = fmaxf(mx, s[k]);
+                    }
+                    float den = 0.f;
+#pragma unroll
+                    for (int k = 0; k < DM; ++k) {
+                        s[k] = (k < deg) ? __expf(s[k] - mx) : 0.f;
+                        den += s[k];
+                    }
+                    const float inv = __builtin_amdgcn_rcpf(den + 1e-16f);  // PyG softmax epsilon
+                    float4 m = f4zero();
+#pragma unroll
+                    for (int k = 0; k < DM; ++k) {
+                        s[k] *= inv;
+                        axpy4(m, s[k], b.r[k]);
+                    }
+                    if (p.alpha_out) {
+                        const float mine = pick(s, sub);         // LPN >= 8 >= DM on this path
+                        if (sub < deg) p.alpha_out[ebase + b.el0 + sub] = mine;
+                    }
+                    if (i < p.n_nodes) finish(i, b.self, m);
+                    GADAPT_STAMP(p.stamps, tslot + 3 + (it & 3));
+                };
+                run_pipeline<K::ITERS, FBuf<DM>>(fetch, consume, [&]() {});
+            });
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < K::ITERS; ++it) {              // any row length, CSR straight from HBM
+                const int li = it * K::SLOTS + slot;
+                const int i = node0 + li;
+                if (i >= p.n_nodes) continue;
+                const float4 Pi = *reinterpret_cast<const float4*>(xs + S::off4(li, sub));
+                const int e0 = p.rowptr[i], deg = p.rowptr[i + 1] - e0;
                 float mx = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < GADAPT_MAXD; ++k) {
-                    s[k] = group_sum<K::LPN>(dot4(Pi, xj[k])) * sc;
-                    if (k < deg) mx = fmaxf(mx, s[k]);
-                }
+                for (int k = 0; k < deg; ++k)
+                    mx = fmaxf(mx, group_sum<K::LPN>(dot4(Pi, ld_row4<C>(p.x_in, p.col[e0 + k], sub))) * sc);
                 float den = 0.f;
-#pragma unroll
-                for (int k = 0; k < GADAPT_MAXD; ++k) {
-                    s[k] = (k < deg) ? __expf(s[k] - mx) : 0.f;
-                    den += s[k];
-                }
-                const float inv = 1.0f / (den + 1e-16f);       // PyG softmax epsilon
-#pragma unroll
-                for (int k = 0; k < GADAPT_MAXD; ++k) {
-                    const float a = s[k] * inv;
-                    axpy4(m, a, xj[k]);
-                    if (p.alpha_out && k < deg && (k % K::LPN) == sub) p.alpha_out[e0 + k] = a;
-                }
-            } else {
-                float mx = -INFINITY;
-                for (int k = 0; k < deg; ++k) {
-                    const float4 v = xin4[(size_t)p.col[e0 + k] * V + sub];
-                    mx = fmaxf(mx, group_sum<K::LPN>(dot4(Pi, v)) * sc);
-                }
-                float den = 0.f;
-                for (int k = 0; k < deg; ++k) {
-                    const float4 v = xin4[(size_t)p.col[e0 + k] * V + sub];
-                    den += __expf(group_sum<K::LPN>(dot4(Pi, v)) * sc - mx);
-                }
+                for (int k = 0; k < deg; ++k)
+                    den += __expf(group_sum<K::LPN>(dot4(Pi, ld_row4<C>(p.x_in, p.col[e0 + k], sub))) * sc - mx);
                 const float inv = 1.0f / (den + 1e-16f);
+                float4 m = f4zero();
                 for (int k = 0; k < deg; ++k) {
-                    const float4 v = xin4[(size_t)p.col[e0 + k] * V + sub];
+                    const float4 v = ld_row4<C>(p.x_in, p.col[e0 + k], sub);
                     const float a = __expf(group_sum<K::LPN>(dot4(Pi, v)) * sc - mx) * inv;
                     axpy4(m, a, v);
                     if (p.alpha_out && (k % K::LPN) == sub) p.alpha_out[e0 + k] = a;
                 }
+                finish(i, ld_row4<C>(p.x_in, i, sub), m);
             }
-            const float4 xi = *reinterpret_cast<const float4*>(xs + li * K::LD + 4 * sub);
-            float4 o;                                            // res = m - x (GRAND_plus.py:267); x + dt*res (GNN.py:291)
-            o.x = m.x - xi.x; o.y = m.y - xi.y; o.z = m.z - xi.z; o.w = m.w - xi.w;
-            if (!p.residual_only) {
-                o.x = fmaf(dt, o.x, xi.x); o.y = fmaf(dt, o.y, xi.y); o.z = fmaf(dt, o.z, xi.z); o.w = fmaf(dt, o.w, xi.w);
-            }
-            xout4[(size_t)i * V + sub] = o;
         }
-        __syncthreads();
+        wg_barrier();                                           // end of tile: this slot may be refilled
+        GADAPT_STAMP(p.stamps, tslot + 7);
     }
 }
 
@@ -337,33 +894,31 @@ __global__ __launch_bounds__(256) void grand_fwd_kernel(FwdArgs p) {
 struct BwdTArgs {
     const float* x_in; const float* g_in; const float* alpha;
     const float* A; const float* lp;
-    const int32_t* rowptr; const int32_t* col;
+    const int32_t* rowptr; const int32_t* col; const int32_t* tpos;
     float2* edge_ws; float* dxd; float* slab; float* sums_out;
     int n_nodes, n_tiles, accumulate, residual_only;
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void grand_bwd_target_kernel(BwdTArgs p) {
+__global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kernel(BwdTArgs p) {
     using K = Cfg<C>;
     extern __shared__ float4 smem4[];
     float* xs = reinterpret_cast<float*>(smem4);
     float* ds = xs + K::TILE_FLOATS;                            // dP tile
+    TileCsr<C, 1> csr;                                          // aux = forward alpha (target order)
+    csr.bind(ds + K::TILE_FLOATS, p.rowptr, p.col, p.alpha);
+    csr.init(threadIdx.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
     // out = base*x + dt*(m - x): Euler step (base 1) or bare residual (base 0, dt 1)
     const float dt = p.residual_only ? 1.0f : p.lp[0], sc = p.lp[1];
     const float w1 = (p.residual_only ? 0.0f : 1.0f) - dt;
-    const float4* xin4 = reinterpret_cast<const float4*>(p.x_in);
-    const float4* gin4 = reinterpret_cast<const float4*>(p.g_in);
-    float4* dxd4 = reinterpret_cast<float4*>(p.dxd);
-    constexpr int V = C / 4;
     constexpr int ROW = C * C + C;                              // slab row: dA then dp0
 
-    // ---- per-kernel resident state
     TileGemm<C, true> gemm;                                     // dxd = dP A
     float acol[K::MFMA ? 1 : 4][K::MFMA ? 1 : C];               // VALU: A[o][4sub+t]
     if constexpr (K::MFMA) {
-        gemm.load(p.A, nullptr, lane, wave);
+        gemm.init(lane, wave);
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -386,68 +941,110 @@ __global__ __launch_bounds__(256) void grand_bwd_target_kernel(BwdTArgs p) {
     float4 dp0acc = f4zero();
     float sum_ddt = 0.f, sum_dsc = 0.f;
 
+    auto finish = [&](int li, int i, const float4& gi, const float4& m, const float4& dP) {
+        if (i < p.n_nodes) {
+            // d dt = sum_i <g_i, m_i - x_i>   (GNN.py:288-289 learn_step); every lane adds its 4 channels
+            const float4 xi = *reinterpret_cast<const float4*>(xs + li * K::LD + 4 * sub);
+            sum_ddt += gi.x * (m.x - xi.x) + gi.y * (m.y - xi.y) + gi.z * (m.z - xi.z) + gi.w * (m.w - xi.w);
+            dp0acc.x += dP.x; dp0acc.y += dP.y; dp0acc.z += dP.z; dp0acc.w += dP.w;
+        }
+        *reinterpret_cast<float4*>(ds + li * K::LD + 4 * sub) = dP;
+    };
+
+    auto fetch = [&](auto& b, int node0, int it) {
+        constexpr int DM = std::remove_reference_t<decltype(b)>::N;
+        const int li = it * K::SLOTS + slot;
+        const int i = node0 + li;
+        const int self = min(i, p.n_nodes - 1);
+        b.el0 = csr.rp[li] - csr.ebase;
+        b.deg = (i < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
+        b.g = ld_row4<C>(p.g_in, self, sub);
+#pragma unroll
+        for (int k = 0; k < DM; ++k) b.r[k] = ld_row4<C>(p.x_in, csr.col[b.el0 + k], sub);   // k >= deg: some valid row, weight 0
+    };
+
+    auto consume = [&](const auto& b, int node0, int it) {
+        constexpr int DM = std::remove_reference_t<decltype(b)>::N;
+        const int li = it * K::SLOTS + slot;
+        const int i = node0 + li;
+        const int deg = b.deg, e0 = b.el0;
+        float4 gi = b.g;
+        if (i >= p.n_nodes) gi = f4zero();
+        float4 dm; dm.x = dt * gi.x; dm.y = dt * gi.y; dm.z = dt * gi.z; dm.w = dt * gi.w;
+        float a[DM], da[DM];
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            const float av = csr.aux[e0 + k];
+            a[k] = (k < deg) ? av : 0.f;
+            da[k] = dot4(dm, b.r[k]);
+        }
+        group_sum_n<K::LPN>(da);
+        float D = 0.f;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) D = fmaf(a[k], da[k], D);
+        float4 dP = f4zero(), m = f4zero();
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            const float dsp = a[k] * (da[k] - D);                   // d(score'), score' = sc * <P_i,x_j>
+            da[k] = dsp * sc;                                       // reuse: d<P_i,x_j>
+            axpy4(dP, da[k], b.r[k]);
+            axpy4(m, a[k], b.r[k]);
+            if (p.sums_out) { if (a[k] > 0.f) sum_dsc = fmaf(dsp, __logf(a[k]), sum_dsc); }
+        }
+        if constexpr (K::LPN >= DM) {
+            const float am = pick(a, sub), dm_ = pick(da, sub);
+            if (sub < deg) p.edge_ws[p.tpos[csr.ebase + e0 + sub]] = make_float2(am * dt, dm_);
+        } else {
+#pragma unroll
+            for (int k = 0; k < DM; ++k)
+                if (k < deg && (k % K::LPN) == sub) p.edge_ws[p.tpos[csr.ebase + e0 + k]] = make_float2(a[k] * dt, da[k]);
+        }
+        finish(li, i, gi, m, dP);
+    };
+
+    auto slow_node = [&](int node0, int it) {
+        const int li = it * K::SLOTS + slot;
+        const int i = node0 + li;
+        float4 dP = f4zero(), m = f4zero(), gi = f4zero();
+        if (i < p.n_nodes) {
+            gi = ld_row4<C>(p.g_in, i, sub);
+            float4 dm; dm.x = dt * gi.x; dm.y = dt * gi.y; dm.z = dt * gi.z; dm.w = dt * gi.w;
+            const int e0 = p.rowptr[i], deg = p.rowptr[i + 1] - e0;
+            float D = 0.f;
+            for (int k = 0; k < deg; ++k)
+                D = fmaf(p.alpha[e0 + k], group_sum<K::LPN>(dot4(dm, ld_row4<C>(p.x_in, p.col[e0 + k], sub))), D);
+            for (int k = 0; k < deg; ++k) {
+                const float4 v = ld_row4<C>(p.x_in, p.col[e0 + k], sub);
+                const float ak = p.alpha[e0 + k];
+                const float dsp = ak * (group_sum<K::LPN>(dot4(dm, v)) - D);
+                const float dss = dsp * sc;
+                axpy4(dP, dss, v);
+                axpy4(m, ak, v);
+                if (ak > 0.f) sum_dsc = fmaf(dsp, __logf(ak), sum_dsc);
+                if ((k % K::LPN) == sub) p.edge_ws[p.tpos[e0 + k]] = make_float2(ak * dt, dss);
+            }
+        }
+        finish(li, i, gi, m, dP);
+    };
+
     const TileRange tr = tile_range(p.n_tiles);
     for (int t = tr.t; t < tr.t_end; t += tr.step) {
         const int node0 = t * K::TM;
         stage_tile<C>(p.x_in, xs, node0, p.n_nodes, tid);
+        const int dmax = csr.stage(node0, p.n_nodes, tid);      // barrier inside
         // ---- edge phase: dP_i per node -> LDS
+        if (dmax >= 0) {
+            dispatch_dmax(dmax, [&](auto tag) {
+                run_pipeline<K::ITERS, TBuf<decltype(tag)::value>>(
+                    [&](auto& b, int it) { fetch(b, node0, it); },
+                    [&](const auto& b, int it) { consume(b, node0, it); },
+                    [&]() {});
+            });
+        } else {
 #pragma unroll 1
-        for (int it = 0; it < K::ITERS; ++it) {
-            const int li = it * K::SLOTS + slot;
-            const int i = node0 + li;
-            float4 dP = f4zero();
-            if (i < p.n_nodes) {
-                const float4 gi = gin4[(size_t)i * V + sub];
-                float4 dm; dm.x = dt * gi.x; dm.y = dt * gi.y; dm.z = dt * gi.z; dm.w = dt * gi.w;
-                const int e0 = p.rowptr[i], deg = p.rowptr[i + 1] - e0;
-                float4 m = f4zero();
-                if (deg <= GADAPT_MAXD) {
-                    float4 xj[GADAPT_MAXD];
-                    float a[GADAPT_MAXD], da[GADAPT_MAXD];
-#pragma unroll
-                    for (int k = 0; k < GADAPT_MAXD; ++k) {
-                        xj[k] = f4zero(); a[k] = 0.f;
-                        if (k < deg) { xj[k] = xin4[(size_t)p.col[e0 + k] * V + sub]; a[k] = p.alpha[e0 + k]; }
-                    }
-                    float D = 0.f;
-#pragma unroll
-                    for (int k = 0; k < GADAPT_MAXD; ++k) {
-                        da[k] = group_sum<K::LPN>(dot4(dm, xj[k]));
-                        D = fmaf(a[k], da[k], D);
-                    }
-#pragma unroll
-                    for (int k = 0; k < GADAPT_MAXD; ++k) {
-                        const float dsp = a[k] * (da[k] - D);           // d(score'), score' = sc * <P_i,x_j>
-                        const float dss = dsp * sc;
-                        axpy4(dP, dss, xj[k]);
-                        axpy4(m, a[k], xj[k]);
-                        if (a[k] > 0.f) sum_dsc = fmaf(dsp, __logf(a[k]), sum_dsc);
-                        if (k < deg && (k % K::LPN) == sub) p.edge_ws[e0 + k] = make_float2(a[k] * dt, dss);
-                    }
-                } else {
-                    float D = 0.f;
-                    for (int k = 0; k < deg; ++k) {
-                        const float4 v = xin4[(size_t)p.col[e0 + k] * V + sub];
-                        D = fmaf(p.alpha[e0 + k], group_sum<K::LPN>(dot4(dm, v)), D);
-                    }
-                    for (int k = 0; k < deg; ++k) {
-                        const float4 v = xin4[(size_t)p.col[e0 + k] * V + sub];
-                        const float ak = p.alpha[e0 + k];
-                        const float dsp = ak * (group_sum<K::LPN>(dot4(dm, v)) - D);
-                        const float dss = dsp * sc;
-                        axpy4(dP, dss, v);
-                        axpy4(m, ak, v);
-                        if (ak > 0.f) sum_dsc = fmaf(dsp, __logf(ak), sum_dsc);
-                        if ((k % K::LPN) == sub) p.edge_ws[e0 + k] = make_float2(ak * dt, dss);
-                    }
-                }
-                // d dt = sum_i <g_i, m_i - x_i>   (GNN.py:288-289 learn_step); every lane adds its 4 channels
-                const float4 xi = xin4[(size_t)i * V + sub];
-                sum_ddt += gi.x * (m.x - xi.x) + gi.y * (m.y - xi.y) + gi.z * (m.z - xi.z) + gi.w * (m.w - xi.w);
-                dp0acc.x += dP.x; dp0acc.y += dP.y; dp0acc.z += dP.z; dp0acc.w += dP.w;
-            }
-            *reinterpret_cast<float4*>(ds + li * K::LD + 4 * sub) = dP;
+            for (int it = 0; it < K::ITERS; ++it) slow_node(node0, it);
         }
+        if constexpr (K::MFMA) gemm.load(p.A, nullptr);         // in flight under the barrier and the dA pass
         __syncthreads();
         // ---- dA partial:  dA[o][c] += sum_node dP[node][o] x[node][c]
         if constexpr (K::MFMA) {
@@ -490,7 +1087,7 @@ __global__ __launch_bounds__(256) void grand_bwd_target_kernel(BwdTArgs p) {
             gemm.run(ds, xs);                                   // xs is dead after the dA pass
             __syncthreads();
         }
-#pragma unroll 1
+#pragma unroll
         for (int it = 0; it < K::ITERS; ++it) {
             const int li = it * K::SLOTS + slot;
             const int i = node0 + li;
@@ -507,9 +1104,9 @@ __global__ __launch_bounds__(256) void grand_bwd_target_kernel(BwdTArgs p) {
                     r.z = fmaf(d, acol[2][o], r.z); r.w = fmaf(d, acol[3][o], r.w);
                 }
             }
-            const float4 gi = gin4[(size_t)i * V + sub];
+            const float4 gi = ld_row4<C>(p.g_in, i, sub);
             r.x = fmaf(w1, gi.x, r.x); r.y = fmaf(w1, gi.y, r.y); r.z = fmaf(w1, gi.z, r.z); r.w = fmaf(w1, gi.w, r.w);
-            dxd4[(size_t)i * V + sub] = r;
+            st_row4<C>(p.dxd, i, sub, r);
         }
         __syncthreads();
     }
@@ -581,31 +1178,29 @@ __global__ __launch_bounds__(256) void grand_bwd_target_kernel(BwdTArgs p) {
 // backward, source pass
 // ------------------------------------------------------------------------------------------------
 struct BwdSArgs {
-    const float* x_in; const float* g_in; const float2* edge_ws; const float* dxd;
+    const float* x_in; const float* g_in; const float* edge_ws; const float* dxd;
     const float* A; const float* p0;
-    const int32_t* rowptr; const int32_t* col; const int32_t* perm;
+    const int32_t* rowptr; const int32_t* col;
     float* g_out;
     int n_nodes, n_tiles;
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void grand_bwd_source_kernel(BwdSArgs p) {
+__global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kernel(BwdSArgs p) {
     using K = Cfg<C>;
     extern __shared__ float4 smem4[];
     float* ys = reinterpret_cast<float*>(smem4);
     float* os = ys + K::TILE_FLOATS;
+    TileCsr<C, 2> csr;                                          // aux = {alpha*dt, d<P,x>} per out-edge (source order)
+    csr.bind(os + K::TILE_FLOATS, p.rowptr, p.col, p.edge_ws);
+    csr.init(threadIdx.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
-    const float4* xin4 = reinterpret_cast<const float4*>(p.x_in);
-    const float4* gin4 = reinterpret_cast<const float4*>(p.g_in);
-    const float4* dxd4 = reinterpret_cast<const float4*>(p.dxd);
-    float4* gout4 = reinterpret_cast<float4*>(p.g_out);
-    constexpr int V = C / 4;
 
     TileGemm<C, false> gemm;                                    // os = y A^T
     float arow[K::MFMA ? 1 : 4][K::MFMA ? 1 : C];
     if constexpr (K::MFMA) {
-        gemm.load(p.A, nullptr, lane, wave);
+        gemm.init(lane, wave);
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -614,47 +1209,69 @@ __global__ __launch_bounds__(256) void grand_bwd_source_kernel(BwdSArgs p) {
     }
     const float4 p0v = *reinterpret_cast<const float4*>(p.p0 + 4 * sub);
 
+    auto fetch = [&](auto& b, int node0, int it) {
+        constexpr int DM = std::remove_reference_t<decltype(b)>::N;
+        const int li = it * K::SLOTS + slot;
+        const int j = node0 + li;
+        const int self = min(j, p.n_nodes - 1);
+        b.el0 = csr.rp[li] - csr.ebase;
+        b.deg = (j < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            const int i = csr.col[b.el0 + k];                    // k >= deg: some valid row, weight 0
+            b.g[k] = ld_row4<C>(p.g_in, i, sub);
+            b.x[k] = ld_row4<C>(p.x_in, i, sub);
+        }
+    };
+    auto consume = [&](const auto& b, int it, float4& z, float& sig) {
+        constexpr int DM = std::remove_reference_t<decltype(b)>::N;
+        const int li = it * K::SLOTS + slot;
+        float4 y = f4zero();
+        z = f4zero(); sig = 0.f;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            float2 ev = *reinterpret_cast<const float2*>(csr.aux + 2 * (b.el0 + k));
+            if (k >= b.deg) ev = make_float2(0.f, 0.f);
+            axpy4(z, ev.x, b.g[k]); axpy4(y, ev.y, b.x[k]); sig += ev.y;
+        }
+        *reinterpret_cast<float4*>(ys + li * K::LD + 4 * sub) = y;
+    };
+    auto slow_node = [&](int node0, int it, float4& z, float& sig) {
+        const int li = it * K::SLOTS + slot;
+        const int j = node0 + li;
+        float4 y = f4zero();
+        z = f4zero(); sig = 0.f;
+        if (j < p.n_nodes) {
+            const int e0 = p.rowptr[j], deg = p.rowptr[j + 1] - e0;
+            for (int k = 0; k < deg; ++k) {
+                const int i = p.col[e0 + k];
+                const float2 ev = *reinterpret_cast<const float2*>(p.edge_ws + 2 * (size_t)(e0 + k));
+                axpy4(z, ev.x, ld_row4<C>(p.g_in, i, sub));
+                axpy4(y, ev.y, ld_row4<C>(p.x_in, i, sub));
+                sig += ev.y;
+            }
+        }
+        *reinterpret_cast<float4*>(ys + li * K::LD + 4 * sub) = y;
+    };
+
     const TileRange tr = tile_range(p.n_tiles);
     for (int t = tr.t; t < tr.t_end; t += tr.step) {
         const int node0 = t * K::TM;
+        const int dmax = csr.stage(node0, p.n_nodes, tid);      // barrier inside
         float4 zr[K::ITERS];
         float sg[K::ITERS];
+        if (dmax >= 0) {
+            dispatch_dmax(dmax, [&](auto tag) {
+                run_pipeline<K::ITERS, SBuf<decltype(tag)::value>>(
+                    [&](auto& b, int it) { fetch(b, node0, it); },
+                    [&](const auto& b, int it) { consume(b, it, zr[it], sg[it]); },
+                    [&]() {});
+            });
+        } else {
 #pragma unroll
-        for (int it = 0; it < K::ITERS; ++it) {
-            const int li = it * K::SLOTS + slot;
-            const int j = node0 + li;
-            float4 z = f4zero(), y = f4zero();
-            float sig = 0.f;
-            if (j < p.n_nodes) {
-                const int e0 = p.rowptr[j], deg = p.rowptr[j + 1] - e0;
-                if (deg <= GADAPT_MAXD) {
-                    float4 gi[GADAPT_MAXD], xi[GADAPT_MAXD];
-                    float2 ev[GADAPT_MAXD];
-#pragma unroll
-                    for (int k = 0; k < GADAPT_MAXD; ++k) {
-                        gi[k] = f4zero(); xi[k] = f4zero(); ev[k] = make_float2(0.f, 0.f);
-                        if (k < deg) {
-                            const int i = p.col[e0 + k];
-                            ev[k] = p.edge_ws[p.perm[e0 + k]];
-                            gi[k] = gin4[(size_t)i * V + sub];
-                            xi[k] = xin4[(size_t)i * V + sub];
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < GADAPT_MAXD; ++k) { axpy4(z, ev[k].x, gi[k]); axpy4(y, ev[k].y, xi[k]); sig += ev[k].y; }
-                } else {
-                    for (int k = 0; k < deg; ++k) {
-                        const int i = p.col[e0 + k];
-                        const float2 ev = p.edge_ws[p.perm[e0 + k]];
-                        axpy4(z, ev.x, gin4[(size_t)i * V + sub]);
-                        axpy4(y, ev.y, xin4[(size_t)i * V + sub]);
-                        sig += ev.y;
-                    }
-                }
-            }
-            *reinterpret_cast<float4*>(ys + li * K::LD + 4 * sub) = y;
-            zr[it] = z; sg[it] = sig;
+            for (int it = 0; it < K::ITERS; ++it) slow_node(node0, it, zr[it], sg[it]);
         }
+        if constexpr (K::MFMA) gemm.load(p.A, nullptr);         // in flight under the barrier
         __syncthreads();
         if constexpr (K::MFMA) {
             gemm.run(ys, os);
@@ -677,12 +1294,12 @@ __global__ __launch_bounds__(256) void grand_bwd_source_kernel(BwdSArgs p) {
                     r.z = fmaf(arow[2][c], yc, r.z); r.w = fmaf(arow[3][c], yc, r.w);
                 }
             }
-            const float4 d = dxd4[(size_t)j * V + sub];
+            const float4 d = ld_row4<C>(p.dxd, j, sub);
             const float4 z = zr[it];
             const float s = sg[it];
             r.x = (r.x + fmaf(s, p0v.x, z.x)) + d.x; r.y = (r.y + fmaf(s, p0v.y, z.y)) + d.y;
             r.z = (r.z + fmaf(s, p0v.z, z.z)) + d.z; r.w = (r.w + fmaf(s, p0v.w, z.w)) + d.w;
-            gout4[(size_t)j * V + sub] = r;
+            st_row4<C>(p.g_out, j, sub, r);
         }
         __syncthreads();
     }
@@ -809,6 +1426,9 @@ static inline int grid_for(int n_tiles, int max_blocks) {
     return g;
 }
 #define GADAPT_FWD_MAX_BLOCKS 1024
+#ifndef GADAPT_FWD_MFMA_MAX_BLOCKS
+#define GADAPT_FWD_MFMA_MAX_BLOCKS 512   /* measured residency of the 5-wave workgroups: 2 per CU x 256 CUs */
+#endif
 #define GADAPT_BWD_T_MAX_BLOCKS 512      /* target pass grid = slab row count */
 
 template <typename KernelT> static void allow_lds(KernelT k, int bytes) {
@@ -818,10 +1438,20 @@ template <typename KernelT> static void allow_lds(KernelT k, int bytes) {
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                                        const float* lp, float* alpha_out, int residual_only, hipStream_t st) {
     using K = Cfg<C>;
-    FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, alpha_out, g->n_nodes, (g->n_nodes + K::TM - 1) / K::TM, residual_only};
-    allow_lds(grand_fwd_kernel<C>, K::LDS_BYTES);
+    FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, alpha_out, g->n_nodes, (g->n_nodes + K::TM - 1) / K::TM, residual_only, nullptr};
+#ifdef GADAPT_STAMPS
+    p.stamps = g_stamp_buf;
+#endif
     ProfScope prof(0, st);
-    hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), K::LDS_BYTES, st, p);
+    if constexpr (K::MFMA) {
+        constexpr int lds = 2 * TileSlot<C, 0>::WORDS * 4;
+        allow_lds(grand_fwd_mfma_kernel<C>, lds);
+        hipLaunchKernelGGL(grand_fwd_mfma_kernel<C>, dim3(grid_for(p.n_tiles, GADAPT_FWD_MFMA_MAX_BLOCKS)), dim3(320), lds, st, p);
+    } else {
+        constexpr int lds = K::lds_bytes(0);
+        allow_lds(grand_fwd_kernel<C>, lds);
+        hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds, st, p);
+    }
     return check_launch("grand_fwd_kernel");
 }
 template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha,
@@ -829,21 +1459,21 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
                                        int accumulate, float* sums_out, float* g_out, int residual_only, hipStream_t st) {
     using K = Cfg<C>;
     const int n_tiles = (g->n_nodes + K::TM - 1) / K::TM;
-    BwdTArgs pt{x_in, g_in, alpha, a, lp, g->rowptr_t, g->col_t, reinterpret_cast<float2*>(edge_ws), dxd, slab, sums_out,
+    BwdTArgs pt{x_in, g_in, alpha, a, lp, g->rowptr_t, g->col_t, g->tpos_s, reinterpret_cast<float2*>(edge_ws), dxd, slab, sums_out,
                 g->n_nodes, n_tiles, accumulate, residual_only};
-    allow_lds(grand_bwd_target_kernel<C>, K::LDS_BYTES);
+    constexpr int lds_t = K::lds_bytes(1), lds_s = K::lds_bytes(2);
+    allow_lds(grand_bwd_target_kernel<C>, lds_t);
     int rc;
     {
         ProfScope prof(1, st);
-        hipLaunchKernelGGL(grand_bwd_target_kernel<C>, dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), K::LDS_BYTES, st, pt);
+        hipLaunchKernelGGL(grand_bwd_target_kernel<C>, dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
         rc = check_launch("grand_bwd_target_kernel");
     }
     if (rc || !g_out) return rc;
-    BwdSArgs ps{x_in, g_in, reinterpret_cast<const float2*>(edge_ws), dxd, a, p0, g->rowptr_s, g->col_s, g->perm_s, g_out,
-                g->n_nodes, n_tiles};
-    allow_lds(grand_bwd_source_kernel<C>, K::LDS_BYTES);
+    BwdSArgs ps{x_in, g_in, edge_ws, dxd, a, p0, g->rowptr_s, g->col_s, g_out, g->n_nodes, n_tiles};
+    allow_lds(grand_bwd_source_kernel<C>, lds_s);
     ProfScope prof(2, st);
-    hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), K::LDS_BYTES, st, ps);
+    hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds_s, st, ps);
     return check_launch("grand_bwd_source_kernel");
 }
 
@@ -858,14 +1488,33 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
         default: return fail(GADAPT_E_BADARG, "hidden_dim must be one of 4, 8, 16, 32, 64, 128");  \
     }
 
-static int check_graph(const gadapt_graph* g) {
+static int check_graph(const gadapt_graph* g, int c) {
     if (!g || g->n_nodes <= 0 || g->n_edges < 0 || !g->rowptr_t || !g->col_t) return fail(GADAPT_E_BADARG, "bad graph");
+    if ((int64_t)g->n_nodes * c * 4 >= ((int64_t)1 << 32)) return fail(GADAPT_E_BADARG, "n_nodes*C*4 must stay below 4 GiB (32-bit row offsets)");
     return GADAPT_OK;
+}
+
+// Diagnostic: what the runtime says about residency (blocks per CU) of the three hot kernels for hidden size c.
+extern "C" int gadapt_debug_occupancy(int c, int* out3) {
+    if (!out3) return fail(GADAPT_E_BADARG, "occupancy: null");
+    out3[0] = out3[1] = out3[2] = -1;
+#define GADAPT_OCC(CC)                                                                                                  \
+    case CC: {                                                                                                          \
+        using K = Cfg<CC>;                                                                                              \
+        if constexpr (K::MFMA) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_mfma_kernel<CC>, 320, 2 * TileSlot<CC, 0>::WORDS * 4); \
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_kernel<CC>, 256, K::lds_bytes(0)); \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC>, 256, K::lds_bytes(1)); \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], grand_bwd_source_kernel<CC>, 256, K::lds_bytes(2)); \
+        return GADAPT_OK;                                                                                               \
+    }
+    switch (c) { GADAPT_OCC(4) GADAPT_OCC(8) GADAPT_OCC(16) GADAPT_OCC(32) GADAPT_OCC(64) GADAPT_OCC(128) default: break; }
+#undef GADAPT_OCC
+    return fail(GADAPT_E_BADARG, "occupancy: unsupported hidden_dim");
 }
 
 extern "C" int gadapt_layer_forward(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                                     const float* layer_params, float* alpha_out, int residual_only, int c, void* stream) {
-    if (int rc = check_graph(g)) return rc;
+    if (int rc = check_graph(g, c)) return rc;
     if (!x_in || !x_out || !a || !p0 || !layer_params || x_in == x_out) return fail(GADAPT_E_BADARG, "layer_forward: null or aliased pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     GADAPT_DISPATCH_C(c, launch_fwd<CC>(g, x_in, x_out, a, p0, layer_params, alpha_out, residual_only, st));
@@ -884,10 +1533,10 @@ extern "C" int64_t gadapt_backward_slab_floats(int64_t n_nodes, int c) {
 extern "C" int gadapt_layer_backward(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha,
                                      const float* a, const float* p0, const float* layer_params, float* edge_ws, float* dxd_ws,
                                      float* slab, int accumulate, float* sums_out, float* g_out, int residual_only, int c, void* stream) {
-    if (int rc = check_graph(g)) return rc;
+    if (int rc = check_graph(g, c)) return rc;
     if (!x_in || !g_in || !alpha || !a || !p0 || !layer_params || !edge_ws || !dxd_ws || !slab)
         return fail(GADAPT_E_BADARG, "layer_backward: null pointer");
-    if (g_out && (!g->rowptr_s || !g->col_s || !g->perm_s)) return fail(GADAPT_E_BADARG, "layer_backward: source CSR missing");
+    if (!g->tpos_s || (g_out && (!g->rowptr_s || !g->col_s))) return fail(GADAPT_E_BADARG, "layer_backward: source CSR missing");
     if (g_out == g_in || g_out == dxd_ws) return fail(GADAPT_E_BADARG, "layer_backward: g_out aliases an input");
     hipStream_t st = static_cast<hipStream_t>(stream);
     GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, residual_only, st));
@@ -949,7 +1598,7 @@ extern "C" int gadapt_adam_step(float* param, const float* grad, float* exp_avg,
 // ------------------------------------------------------------------------------------------------
 extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int n_layers, const float* a, int64_t a_stride,
                                     const float* p0, int64_t p0_stride, const float* layer_params, float* alpha_all, int c, void* stream) {
-    if (int rc = check_graph(g)) return rc;
+    if (int rc = check_graph(g, c)) return rc;
     if (!x_all || n_layers <= 0 || !a || !p0 || !layer_params) return fail(GADAPT_E_BADARG, "block_forward: bad argument");
     const size_t nc = (size_t)g->n_nodes * c;
     for (int l = 0; l < n_layers; ++l) {
@@ -964,7 +1613,7 @@ extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, 
                                      const float* a, int64_t a_stride, const float* p0, int64_t p0_stride, const float* layer_params,
                                      float* g_ws, float* dxd_ws, float* edge_ws, float* slab, float* d_layer_params, float* d_x0,
                                      int c, void* stream) {
-    if (int rc = check_graph(g)) return rc;
+    if (int rc = check_graph(g, c)) return rc;
     if (!x_all || !alpha_all || !g_top || n_layers <= 0 || !a || !p0 || !layer_params || !g_ws || !dxd_ws || !edge_ws || !slab)
         return fail(GADAPT_E_BADARG, "block_backward: bad argument");
     const size_t nc = (size_t)g->n_nodes * c;

@@ -55,19 +55,20 @@ class MeshGraph:
         self.device = torch.device(device)
         rowptr_t = torch.empty(n + 1, dtype=torch.int32)
         rowptr_s = torch.empty(n + 1, dtype=torch.int32)
-        col_t, eid_t, col_s, perm_s = (torch.empty(max(e, 1), dtype=torch.int32) for _ in range(4))
+        col_t, eid_t, col_s, perm_s, tpos_s = (torch.empty(max(e, 1), dtype=torch.int32) for _ in range(5))
         src, dst = ei[0].contiguous(), ei[1].contiguous()
         rc = _native.lib().gadapt_csr_build_host(src.data_ptr(), dst.data_ptr(), e, n,
                                                  rowptr_t.data_ptr(), col_t.data_ptr(), eid_t.data_ptr(),
-                                                 rowptr_s.data_ptr(), col_s.data_ptr(), perm_s.data_ptr())
+                                                 rowptr_s.data_ptr(), col_s.data_ptr(), perm_s.data_ptr(), tpos_s.data_ptr())
         if rc != 0:
             raise _native.NativeError(f"gadapt_csr_build_host failed (code {rc}): edge endpoint outside [0,{n})?")
         self.edge_index = edge_index                        # as given (original order/device)
         self.rowptr_t, self.col_t, self.eid_t = (t.to(self.device) for t in (rowptr_t, col_t, eid_t))
-        self.rowptr_s, self.col_s, self.perm_s = (t.to(self.device) for t in (rowptr_s, col_s, perm_s))
+        self.rowptr_s, self.col_s, self.perm_s, self.tpos_s = (t.to(self.device) for t in (rowptr_s, col_s, perm_s, tpos_s))
         self.max_in_degree = int((rowptr_t[1:] - rowptr_t[:-1]).max())
         self.c_struct = GadaptGraph(n, e, self.rowptr_t.data_ptr(), self.col_t.data_ptr(),
-                                    self.rowptr_s.data_ptr(), self.col_s.data_ptr(), self.perm_s.data_ptr())
+                                    self.rowptr_s.data_ptr(), self.col_s.data_ptr(), self.perm_s.data_ptr(),
+                                    self.tpos_s.data_ptr())
         self.c_ref = C.byref(self.c_struct)
 
     def alpha_to_edge_order(self, alpha_t: torch.Tensor) -> torch.Tensor:

@@ -48,11 +48,12 @@ int  gadapt_abi_version(void);
  *   eid_t[E]                : original edge id of each target-ordered slot
  *                             (alpha_out[slot] belongs to edge eid_t[slot]);
  *   rowptr_s[N+1], col_s[E] : out-edges grouped by source, col_s = target;
- *   perm_s[E]               : target-ordered slot of each source-ordered slot.
+ *   perm_s[E]               : target-ordered slot of each source-ordered slot;
+ *   tpos_s[E]               : its inverse - source-ordered slot of each target-ordered slot.
  * Order inside a row is the input order (stable), so results are reproducible. */
 int gadapt_csr_build_host(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes,
                           int32_t* rowptr_t, int32_t* col_t, int32_t* eid_t,
-                          int32_t* rowptr_s, int32_t* col_s, int32_t* perm_s);
+                          int32_t* rowptr_s, int32_t* col_s, int32_t* perm_s, int32_t* tpos_s);
 
 typedef struct gadapt_graph {
     int32_t n_nodes;
@@ -62,6 +63,7 @@ typedef struct gadapt_graph {
     const int32_t* rowptr_s;
     const int32_t* col_s;
     const int32_t* perm_s;
+    const int32_t* tpos_s;
 } gadapt_graph;
 
 /* ------------------------------------------------------------------ weights
@@ -100,7 +102,7 @@ int64_t gadapt_backward_slab_floats(int64_t n_nodes, int c);   /* rows * (C*C + 
  *                dxd = (1-dt) g + A^T dP;
  *   source pass: g_out = dxd + sum over out-edges (alpha dt g_i + dscore A x_i ...) .
  * g_in = dL/dx_out [N,C]; x_in = the layer's input; alpha = forward's alpha_out.
- * edge_ws [E] float2, dxd_ws [N,C] scratch.  slab accumulates (accumulate!=0) or is
+ * edge_ws [E] float2 (filled in source order through tpos_s), dxd_ws [N,C] scratch.  slab accumulates (accumulate!=0) or is
  * overwritten.  sums_out (nullable, 2 floats per call, atomically accumulated):
  * {d dt, d score_scale}.  Pass g_out = NULL to skip the source pass (layer 0 with a
  * frozen encoder: GNN.py:82). */
@@ -158,6 +160,8 @@ int gadapt_profile_enable(int on);
 int gadapt_profile_read(int kernel_id, double* total_ms, int* count);
 int gadapt_profile_samples(int kernel_id, double* out_ms, int cap);   /* returns the number written */
 int gadapt_profile_reset(void);
+/* Diagnostic: runtime-reported workgroups per CU of {forward, backward target, backward source}. */
+int gadapt_debug_occupancy(int c, int* out3);
 
 #ifdef __cplusplus
 }
