@@ -18,6 +18,13 @@ import torch
 from ._native import check, current_stream, lib, ptr
 
 
+def shard_range(n_items: int, rank: int, world: int):
+    """[lo, hi) of the meshes rank `rank` owns: contiguous, sizes differ by at most one."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
 class FlatAdam:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, process_group=None, reduce_op: str = 'mean'):

@@ -79,6 +79,13 @@ def grand_residual(x, edge_index, w_query, b_query, w_key, b_key,
     return res
 
 
+def with_self_loops(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """`remove_self_loops` then `add_self_loops` (PyG utils; `src/GNN.py:220-223`): loops appended as arange(N)."""
+    edge_index = edge_index[:, edge_index[0] != edge_index[1]]
+    loop = torch.arange(num_nodes, dtype=edge_index.dtype, device=edge_index.device)
+    return torch.cat([edge_index, loop.unsqueeze(0).repeat(2, 1)], dim=1)
+
+
 def masked_edge_index(data, dim: int, mesh_n: int, fix_boundary: bool = True) -> torch.Tensor:
     """`src/GNN.py:206-218`: drop masked edges, append boundary/corner self-loops."""
     edge_index = data.edge_index
@@ -172,6 +179,8 @@ class OracleGNN(nn.Module):
     def forward(self, data, return_all: bool = False):
         opt = self.opt
         edge_index = masked_edge_index(data, self.dim, opt['mesh_dims'][0], opt['fix_boundary'])
+        if opt.get('self_loops'):
+            edge_index = with_self_loops(edge_index, data.x_comp.shape[0])                 # :220-223
         feats = node_features(data, self.dim, opt['gnn_inc_feat_f'], opt['gnn_inc_feat_uu'],
                               opt.get('gnn_normalize', False))
         x = self.enc(feats.to(self.enc.weight.dtype))                                      # :270

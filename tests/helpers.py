@@ -32,3 +32,16 @@ def rel_err(a, b):
     big = b.abs() > 1e-3 * scale
     elem = ((a - b).abs()[big] / b.abs()[big]).max().item() if big.any() else 0.0
     return norm, elem
+
+
+def oracle_fp64_twin(oracle, ds, opt, data, tgt):
+    """Same weights and inputs in fp64, forward + mse backward: bounds the fp32 oracle's own rounding."""
+    import torch.nn.functional as F
+    o64 = OracleGNN(ds, dict(opt)).double()
+    o64.load_state_dict({k: v.double() for k, v in oracle.state_dict().items()})
+    d64 = data.clone()
+    for k in ('x_comp', 'f_tensor', 'uu_tensor'):
+        setattr(d64, k, getattr(d64, k).double())
+    ref64 = o64(d64)
+    F.mse_loss(ref64, tgt.double()).backward()
+    return o64, ref64

@@ -1,0 +1,74 @@
+"""N > 1 path on CPU (gloo, world_size 2): shard the mesh batch by rank, all-reduce ONE flat gradient bucket,
+and check the averaged bucket equals the full-batch gradient.  Compute on the ranks is the CPU oracle (tests
+may use it); what is under test is the sharding and the bucket/all-reduce logic of g_adaptivity_amd.optim."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from g_adaptivity_amd import MeshDataset, collate, hot_path_opt
+from g_adaptivity_amd.optim import FlatAdam, shard_range
+from oracle.pyg_restatement import OracleGNN
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _loss_grads(model, ds, idx):
+    data = collate([ds.samples[i] for i in idx])
+    model.zero_grad()
+    F.mse_loss(model(data), data.x_phys).backward()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    opt = hot_path_opt(mesh_dims=[9, 9], hidden_dim=8, num_layers=2)
+    ds = MeshDataset([9, 9], 8, seed=0)
+    torch.manual_seed(0)
+    model = OracleGNN(ds, opt)
+    lo, hi = shard_range(len(ds), rank, world)
+    _loss_grads(model, ds, range(lo, hi))
+    optim = FlatAdam(model.parameters(), lr=1e-3)
+    optim._build()                                         # flat bucket over the parameters that received a gradient
+    assert optim.grad_bucket.numel() == 2 * (8 * 8 + 8)    # lin_skip / enc never get one
+    n = optim.all_reduce()
+    assert n == world
+    if rank == 0:
+        out.put((optim.grad_bucket / n).clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_flat_bucket_allreduce_equals_full_batch_gradient():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    reduced = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    opt = hot_path_opt(mesh_dims=[9, 9], hidden_dim=8, num_layers=2)
+    ds = MeshDataset([9, 9], 8, seed=0)
+    torch.manual_seed(0)
+    model = OracleGNN(ds, opt)
+    _loss_grads(model, ds, range(8))                       # equal shard sizes: mean of shard means = full-batch mean
+    lay = model.conv_layers[0]
+    full = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+    assert full.numel() == reduced.numel()
+    assert torch.allclose(reduced, full, rtol=1e-4, atol=1e-9)
+
+
+def test_shard_range_partitions():
+    for n, w in ((256, 8), (10, 3), (5, 8)):
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

@@ -1,0 +1,226 @@
+"""GPU tests of the operator surface, the small kernels, edge cases and full-size properties (pytest -m gpu)."""
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from g_adaptivity_amd import GNN, GRAND_conv, GRAND_plusConv, MeshDataset, MeshGraph, collate, hot_path_opt
+from g_adaptivity_amd import functional as Fn
+from g_adaptivity_amd.optim import FlatAdam
+from helpers import hip_model_like, make_case, rel_err
+from oracle.pyg_restatement import grand_residual
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz')))
+
+
+def _random_layer(C, seed, dev=None):
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / math.sqrt(C)
+    ws = [(torch.rand(C, C, generator=g) * 2 - 1) * k, (torch.rand(C, generator=g) * 2 - 1) * k,
+          (torch.rand(C, C, generator=g) * 2 - 1) * k, (torch.rand(C, generator=g) * 2 - 1) * k]
+    return [w.to(dev) if dev else w for w in ws]
+
+
+def _random_graph(n, e, seed, max_in=None):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(0, n, (e,), generator=g)
+    return torch.stack([src, dst])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [4, 8, 16, 32, 64, 128])
+@pytest.mark.parametrize("kind", ["mesh", "random_long_rows", "ragged"])
+def test_conv_residual_forward_backward_dense_x(gpu_device, C, kind):
+    """Operator-level drop-in: GRAND_plusConv.forward(x, edge_index) on dense random x (all C columns live),
+    including rows with > 8 in-edges (loop path), isolated nodes, and N not a multiple of the tile."""
+    if kind == "mesh":
+        ds = MeshDataset([13, 13], 3, seed=2)
+        from oracle.pyg_restatement import masked_edge_index
+        ei = masked_edge_index(collate(ds.samples), 2, 13)
+        n = 3 * 169
+    elif kind == "random_long_rows":
+        n = 333
+        ei = _random_graph(n, 5000, 7)                      # mean in-degree 15: every tile takes the loop path
+    else:
+        n = 1000
+        ei = torch.cat([_random_graph(n, 2500, 9), torch.tensor([[5] * 40, list(range(40))])], dim=1)
+        ei = ei[:, ei[1] != 17]                             # node 17 has no in-edge at all
+    wq, bq, wk, bk = _random_layer(C, 3)
+    x = torch.randn(n, C, generator=torch.Generator().manual_seed(4))
+    up = torch.randn(n, C, generator=torch.Generator().manual_seed(5))
+
+    xr = x.clone().requires_grad_(True)
+    pr = [w.clone().requires_grad_(True) for w in (wq, bq, wk, bk)]
+    ref, (alpha_ref, q_ref, k_ref) = grand_residual(xr, ei, pr[0], pr[1], pr[2], pr[3], return_attention=True)
+    (ref * up).sum().backward()
+    x64 = x.double().requires_grad_(True)
+    p64 = [w.double().requires_grad_(True) for w in (wq, bq, wk, bk)]
+    ref64 = grand_residual(x64, ei, *p64)
+    (ref64 * up.double()).sum().backward()
+
+    opt = hot_path_opt(hidden_dim=C, show_mesh_evol_plots=True, device=str(gpu_device))
+    conv = GRAND_plusConv(opt, C, C, global_feat_dim=8, heads=1, concat=False, beta=False, dropout=0.0, edge_dim=None,
+                          bias=False, root_weight=False).to(gpu_device)
+    with torch.no_grad():
+        conv.lin_query.weight.copy_(wq); conv.lin_query.bias.copy_(bq); conv.lin_key.weight.copy_(wk); conv.lin_key.bias.copy_(bk)
+    xh = x.to(gpu_device).requires_grad_(True)
+    res, (ei_out, (alpha, q, k)) = conv(xh, ei.to(gpu_device), None, None, return_attention_weights=True)
+    (res * up.to(gpu_device)).sum().backward()
+    torch.cuda.synchronize()
+
+    assert rel_err(res, ref64)[0] <= 1e-5, rel_err(res, ref64)
+    assert rel_err(alpha.view(-1), alpha_ref.view(-1))[0] <= 1e-5
+    assert rel_err(conv.stored_alpha.view(-1), alpha_ref.view(-1))[0] <= 1e-5 and conv.stored_ei is not None
+    assert rel_err(q, q_ref)[0] <= 1e-5 and rel_err(k, k_ref)[0] <= 1e-5
+    assert rel_err(xh.grad, x64.grad)[0] <= 1e-4, rel_err(xh.grad, x64.grad)
+    for got, want in ((conv.lin_query.weight.grad, p64[0].grad), (conv.lin_query.bias.grad, p64[1].grad),
+                      (conv.lin_key.weight.grad, p64[2].grad)):
+        assert rel_err(got, want)[0] <= 1e-4, rel_err(got, want)
+
+
+@pytest.mark.gpu
+def test_grand_conv_surface(gpu_device):
+    C = 64
+    opt = hot_path_opt(hidden_dim=C, device=str(gpu_device))
+    conv = GRAND_conv(opt, C, C, heads=1).to(gpu_device)
+    ei = _random_graph(200, 900, 1).to(gpu_device)
+    x = torch.randn(200, C, device=gpu_device)
+    res = conv(x, ei)
+    ref = grand_residual(x.cpu(), ei.cpu(), conv.lin_query.weight.detach().cpu(), conv.lin_query.bias.detach().cpu(),
+                         conv.lin_key.weight.detach().cpu(), conv.lin_key.bias.detach().cpu())
+    assert rel_err(res, ref)[0] <= 1e-5
+    assert conv.stored_alpha.shape == (900, 1) and conv.stored_ei is ei
+
+
+@pytest.mark.gpu
+def test_learnable_step_and_temperature_gradients(gpu_device):
+    opt, ds, data, oracle = make_case((12, 12), 2, 64, 3, learn_step=True, softmax_temp_type='fixed', softmax_temp=1.5)
+    model = hip_model_like(oracle, ds, opt, gpu_device)
+    tgt = data.x_phys
+    F.mse_loss(oracle(data), tgt).backward()
+    F.mse_loss(model(data.clone().to(gpu_device)), tgt.to(gpu_device)).backward()
+    for l in range(3):
+        want, got = oracle.steps[l].grad, model.steps[l].grad
+        assert rel_err(got, want)[0] <= 1e-4, (l, got, want)
+    # temperature as a parameter: d/dT through the score scale
+    C = 32
+    wq, bq, wk, bk = _random_layer(C, 11)
+    ei = _random_graph(300, 1500, 12)
+    x = torch.randn(300, C, generator=torch.Generator().manual_seed(13))
+    T = torch.tensor(1.7, dtype=torch.float64, requires_grad=True)
+    ref = grand_residual(x.double(), ei, wq.double(), bq.double(), wk.double(), bk.double(), temperature=T)
+    ref.square().sum().backward()
+    o = hot_path_opt(hidden_dim=C, softmax_temp_type='learnable_a', device=str(gpu_device))
+    conv = GRAND_plusConv(o, C, C, heads=1, concat=False, root_weight=False, bias=False).to(gpu_device)
+    with torch.no_grad():
+        conv.lin_query.weight.copy_(wq); conv.lin_query.bias.copy_(bq); conv.lin_key.weight.copy_(wk); conv.lin_key.bias.copy_(bk)
+        conv.sm_temp_a.fill_(1.7)
+    conv(x.to(gpu_device), ei.to(gpu_device)).square().sum().backward()
+    assert rel_err(conv.sm_temp_a.grad.view(-1), T.grad.view(-1))[0] <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:2] for p in GOLDEN])
+def test_golden_fixtures(gpu_device, path):
+    g = np.load(path, allow_pickle=False)
+    mesh_dims = [int(v) for v in g['mesh_dims']]
+    C, L = int(g['hidden']), int(g['layers'])
+    graph = MeshGraph(torch.from_numpy(g['edge_index']), g['x_comp'].shape[0], gpu_device)
+    x_comp = torch.from_numpy(g['x_comp'])
+    feats = torch.stack(([x_comp] if x_comp.dim() == 1 else list(x_comp.T)) + [torch.from_numpy(g['f']), torch.from_numpy(g['uu'])], 1)
+    enc = torch.zeros(C, feats.shape[1]); enc[torch.arange(feats.shape[1]), torch.arange(feats.shape[1])] = 1
+    x0 = Fn.encode_linear(feats.to(gpu_device), enc.to(gpu_device))
+    params = [torch.from_numpy(g[k]).to(gpu_device).unsqueeze(0).requires_grad_(True) for k in ('wq', 'bq', 'wk', 'bk')]
+    lp = torch.tensor([[0.1, 1.0 / math.sqrt(C)]] * L, device=gpu_device)
+    xL, alpha = Fn.grand_euler_block(x0, *params, lp, graph, L, want_alpha=True)
+    d = len(mesh_dims)
+    tgt = torch.from_numpy(g['target']).reshape(-1, d).to(gpu_device)
+    F.mse_loss(xL[:, :d], tgt).backward()
+    assert rel_err(xL[:, :d], torch.from_numpy(g['x_phys_f64']))[0] <= 1e-5
+    assert rel_err(graph.alpha_to_edge_order(alpha[-1]), torch.from_numpy(g['alpha_last_f64']))[0] <= 1e-5
+    for p, k in zip(params[:3], ('d_wq_f64', 'd_bq_f64', 'd_wk_f64')):
+        assert rel_err(p.grad[0], torch.from_numpy(g[k]))[0] <= 1e-4, k
+
+
+@pytest.mark.gpu
+def test_flat_adam_matches_torch_adam(gpu_device):
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(64, 64, device=gpu_device)), torch.nn.Parameter(torch.randn(64, device=gpu_device)),
+          torch.nn.Parameter(torch.randn(3, device=gpu_device))]           # the last one never gets a gradient
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ours, ref = FlatAdam(ps, lr=1e-2, weight_decay=0.01), torch.optim.Adam(qs, lr=1e-2, weight_decay=0.01)
+    for step in range(5):
+        gs = [torch.randn_like(ps[0]), torch.randn_like(ps[1])]
+        ours.zero_grad(); ref.zero_grad()
+        for p, q, g in zip(ps, qs, gs):
+            if p.grad is None: p.grad = g.clone()
+            else: p.grad.add_(g)
+            q.grad = g.clone()
+        ours.step(); ref.step()
+    torch.cuda.synchronize()
+    for p, q in zip(ps, qs):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)
+    assert ours.grad_bucket.numel() == 64 * 64 + 64
+
+
+@pytest.mark.gpu
+def test_mesh_loss_seed_kernel(gpu_device):
+    from g_adaptivity_amd._native import check, current_stream, lib, ptr
+    n, C, d = 1000, 64, 2
+    x = torch.randn(n, C, device=gpu_device); tgt = torch.randn(n, d, device=gpu_device)
+    for l1 in (0, 1):
+        xp = torch.empty(n, d, device=gpu_device); g = torch.empty(n, C, device=gpu_device); loss = torch.zeros(1, device=gpu_device)
+        check(lib().gadapt_mesh_loss_seed(ptr(x), ptr(tgt), ptr(xp), ptr(g), ptr(loss), n, d, C, l1, 1.0, current_stream(gpu_device)), 'seed')
+        xr = x.clone().requires_grad_(True)
+        ref = (F.l1_loss if l1 else F.mse_loss)(xr[:, :d], tgt)
+        ref.backward()
+        assert torch.equal(xp, x[:, :d]) and torch.allclose(loss[0], ref, rtol=1e-5)
+        assert torch.allclose(g, xr.grad, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_full_size_properties(gpu_device):
+    """BASELINE config sizes (64x64, batch 32, C=64, L=4), too big for the oracle to be quick: size-independent
+    properties instead - attention rows sum to 1, corner nodes fixed, boundary nodes stay on their side,
+    edge-order permutation invariance, dt = 0 is the identity, replay determinism."""
+    n, B, C, L = 64, 32, 64, 4
+    opt = hot_path_opt(mesh_dims=[n, n], hidden_dim=C, num_layers=L, device=str(gpu_device), show_mesh_evol_plots=True)
+    ds = MeshDataset([n, n], B, seed=0)
+    data = collate(ds.samples).to(gpu_device)
+    torch.manual_seed(0)
+    model = GNN(ds, opt).to(gpu_device).eval()
+    with torch.no_grad():
+        out = model(data)
+        out2 = model(data)
+    assert torch.equal(out, out2)                                        # deterministic
+    x0 = data.x_comp
+    graph = next(iter(model._graphs.values()))
+    layer = model.conv_layers[0]
+    alpha = layer.stored_alpha.view(-1)
+    rows = torch.zeros(graph.num_nodes, device=gpu_device).index_add_(0, graph.edge_index[1].to(gpu_device), alpha)
+    assert (rows - 1).abs().max().item() <= 2e-6
+    corners = torch.cat([torch.as_tensor(c) + b * n * n for b, c in enumerate(data.corner_nodes)]).to(gpu_device)
+    assert torch.equal(out[corners], x0[corners])
+    for col, val in ((0, 0.0), (0, 1.0), (1, 0.0), (1, 1.0)):
+        side = x0[:, col] == val
+        assert (out[side, col] - x0[side, col]).abs().max().item() <= 1e-6
+    # permuted edge list -> same result within fp32 reassociation
+    perm = torch.randperm(graph.num_edges, generator=torch.Generator().manual_seed(1))
+    g2 = MeshGraph(graph.edge_index.cpu()[:, perm], graph.num_nodes, gpu_device)
+    wq, bq, wk, bk = (layer.lin_query.weight.unsqueeze(0), layer.lin_query.bias.unsqueeze(0), layer.lin_key.weight.unsqueeze(0),
+                      layer.lin_key.bias.unsqueeze(0))
+    lp = torch.tensor([[0.1, 1 / 8.0]] * L, device=gpu_device)
+    feats = torch.cat([x0, data.f_tensor[:, None], data.uu_tensor[:, None]], 1)
+    xin = Fn.encode_linear(feats, model.enc.weight)
+    with torch.no_grad():
+        a, _ = Fn.grand_euler_block(xin, wq, bq, wk, bk, lp, graph, L)
+        b, _ = Fn.grand_euler_block(xin, wq, bq, wk, bk, lp, g2, L)
+        z, _ = Fn.grand_euler_block(xin, wq, bq, wk, bk, torch.tensor([[0.0, 1 / 8.0]] * L, device=gpu_device), graph, L)
+    assert torch.equal(a[:, :2], out) and torch.equal(z, xin)
+    for col in range(4):                                                 # live columns: x, y, f, uu
+        assert rel_err(a[:, col], b[:, col])[0] <= 1e-5

@@ -1,54 +1,67 @@
 """HIP path vs the CPU oracle on the same seeded inputs (run on the MI355X: pytest -m gpu).
 
-Tolerances (BASELINE.json north_star / BASELINE.md): predicted node coordinates within 1e-5
-relative fp32; parameter gradients within 1e-4 relative.
+Tolerances (BASELINE.json north_star / BASELINE.md): predicted node coordinates within 1e-5 relative fp32;
+parameter gradients within 1e-4 relative.  Gradients are measured against the oracle's fp64 twin - the fp32
+oracle's own rounding error reaches 2e-4 on the ill-conditioned 1-D case - and, as a second check, against
+the fp32 oracle with that measured rounding error as allowance.
 """
 import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import hip_model_like, make_case, rel_err
+from helpers import hip_model_like, make_case, oracle_fp64_twin, rel_err
 
 COORD_TOL = 1e-5
 GRAD_TOL = 1e-4
 
 CASES = [
-    # mesh_dims, batch, hidden, layers, conv_type
-    ((32,), 8, 8, 1, 'GRAND'),            # BASELINE config 1 (1-D plumbing)
-    ((11, 11), 2, 8, 4, 'GRAND_plus'),    # the reference's shipped default (params.py:37,130-134)
-    ((11, 11), 3, 4, 2, 'GRAND_plus'),
-    ((15, 15), 2, 16, 3, 'GRAND_plus'),
-    ((12, 12), 3, 32, 2, 'GRAND_plus'),
-    ((32, 32), 2, 64, 4, 'GRAND_plus'),   # BASELINE config 2 shape (small batch)
-    ((20, 20), 2, 128, 2, 'GRAND'),       # config 4 shape (hidden 128)
+    # mesh_dims, batch, hidden, layers, conv_type, extra opt
+    ((32,), 8, 8, 1, 'GRAND', {}),            # BASELINE config 1 (1-D plumbing)
+    ((11, 11), 2, 8, 4, 'GRAND_plus', {}),    # the reference's shipped default (params.py:37,130-134)
+    ((11, 11), 3, 4, 2, 'GRAND_plus', {}),
+    ((15, 15), 2, 16, 3, 'GRAND_plus', {}),
+    ((12, 12), 3, 32, 2, 'GRAND_plus', {}),
+    ((32, 32), 2, 64, 4, 'GRAND_plus', {}),   # BASELINE config 2 shape (small batch)
+    ((20, 20), 2, 128, 2, 'GRAND', {}),       # config 4 shape (hidden 128)
+    ((13, 13), 5, 64, 3, 'GRAND_plus', {'share_conv': False}),
+    ((13, 13), 2, 64, 2, 'GRAND_plus', {'softmax_temp_type': 'fixed', 'softmax_temp': 2.0}),
+    ((10, 10), 2, 64, 2, 'GRAND_plus', {'fix_boundary': False, 'self_loops': True}),   # in-degree 7 rows
+    ((21,), 3, 8, 3, 'GRAND', {'gnn_inc_feat_f': False}),                               # Burgers features (params.py:148,155)
 ]
+IDS = [f"{'x'.join(map(str, c[0]))}-b{c[1]}-C{c[2]}-L{c[3]}-{c[4]}" + ('-' + ','.join(c[5]) if c[5] else '') for c in CASES]
+
+
+def _run(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra):
+    opt, ds, data, oracle = make_case(mesh_dims, batch, hidden, layers, conv_type, **extra)
+    model = hip_model_like(oracle, ds, opt, gpu_device)
+    tgt = data.x_phys if data.x_phys.dim() == 2 else data.x_phys.unsqueeze(-1)
+    ref = oracle(data)
+    F.mse_loss(ref, tgt).backward()
+    o64, ref64 = oracle_fp64_twin(oracle, ds, opt, data, tgt)
+    out = model(data.clone().to(gpu_device))
+    F.mse_loss(out, tgt.to(gpu_device)).backward()
+    torch.cuda.synchronize()
+    return oracle, o64, model, ref, ref64, out
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mesh_dims,batch,hidden,layers,conv_type", CASES)
-def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, conv_type):
-    opt, ds, data, oracle = make_case(mesh_dims, batch, hidden, layers, conv_type)
-    model = hip_model_like(oracle, ds, opt, gpu_device)
-    tgt = data.x_phys if data.x_phys.dim() == 2 else data.x_phys.unsqueeze(-1)
-
-    ref = oracle(data)
-    loss_ref = F.mse_loss(ref, tgt)
-    loss_ref.backward()
-
-    out = model(data.clone().to(gpu_device))
-    loss = F.mse_loss(out, tgt.to(gpu_device))
-    loss.backward()
-    torch.cuda.synchronize()
-
+@pytest.mark.parametrize("mesh_dims,batch,hidden,layers,conv_type,extra", CASES, ids=IDS)
+def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra):
+    oracle, o64, model, ref, ref64, out = _run(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra)
     norm, elem = rel_err(out, ref)
-    assert norm <= COORD_TOL and elem <= COORD_TOL, f"x_phys rel err normwise {norm:.2e} elementwise {elem:.2e}"
-    lo, lh = oracle.conv_layers[0], model.conv_layers[0]
-    for name in ('lin_query.weight', 'lin_query.bias', 'lin_key.weight'):
-        g_ref = dict(lo.named_parameters())[name].grad
-        g_hip = dict(lh.named_parameters())[name].grad
-        n, _ = rel_err(g_hip, g_ref)
-        assert n <= GRAD_TOL, f"{name}.grad normwise rel err {n:.2e}"
-    # d/d lin_key.bias vanishes analytically (softmax shift invariance); the oracle's is rounding noise
-    gk_ref, gk_hip = lo.lin_key.bias.grad, lh.lin_key.bias.grad
-    assert gk_hip.abs().max().item() == 0.0
-    assert gk_ref.abs().max().item() <= 1e-4 * lo.lin_query.bias.grad.abs().max().item() + 1e-12
+    assert norm <= COORD_TOL and elem <= COORD_TOL, f"x_phys vs fp32 oracle: normwise {norm:.2e} elementwise {elem:.2e}"
+    assert rel_err(out, ref64)[0] <= COORD_TOL
+    n_layers = len({id(l) for l in model.conv_layers})
+    for li in range(n_layers):
+        lo, l64, lh = oracle.conv_layers[li], o64.conv_layers[li], model.conv_layers[li]
+        for name in ('lin_query.weight', 'lin_query.bias', 'lin_key.weight'):
+            g32 = dict(lo.named_parameters())[name].grad
+            g64 = dict(l64.named_parameters())[name].grad
+            gh = dict(lh.named_parameters())[name].grad
+            e64 = rel_err(gh, g64)[0]
+            assert e64 <= GRAD_TOL, f"layer {li} {name}.grad vs fp64 oracle: {e64:.2e}"
+            e32, noise = rel_err(gh, g32)[0], rel_err(g32, g64)[0]
+            assert e32 <= GRAD_TOL + 2 * noise, f"layer {li} {name}.grad vs fp32 oracle: {e32:.2e} (oracle rounding {noise:.2e})"
+        # d/d lin_key.bias vanishes analytically (softmax shift invariance); the oracle's is rounding noise
+        assert lh.lin_key.bias.grad.abs().max().item() == 0.0
+        assert l64.lin_key.bias.grad.abs().max().item() <= 1e-9 * max(l64.lin_query.bias.grad.abs().max().item(), 1e-30) + 1e-18

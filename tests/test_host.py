@@ -1,0 +1,130 @@
+"""Host-side logic and the C-ABI surface (no GPU): mesh graphs, collation, edge surgery, CSR build,
+exported symbols, module surface, loud failure without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from g_adaptivity_amd import (GNN, GRAND_conv, GRAND_plusConv, MeshDataset, MeshGraph, collate, get_conv, hot_path_opt,
+                              interval_mesh, prepare_edge_index, square_mesh)
+from g_adaptivity_amd import _native
+from oracle.pyg_restatement import masked_edge_index
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n,N,E0,E", [(11, 121, 640, 562), (15, 225, 1232, 1122), (32, 1024, 5890, 5644), (64, 4096, 24066, 23564)])
+def test_square_mesh_counts(n, N, E0, E):
+    """node/edge counts and the in-degree histogram {6: (n-2)^2, 2: 4(n-2), 1: 4}."""
+    m = square_mesh(n)
+    ds = collate([m])
+    ds.corner_nodes = [m.corner_nodes]
+    ei = prepare_edge_index(ds, 2, n, True, False, N)
+    assert m.x_comp.shape[0] == N and m.edge_index.shape[1] == E0 and ei.shape[1] == E
+    hist = torch.bincount(torch.bincount(ei[1], minlength=N))
+    assert hist[6] == (n - 2) ** 2 and hist[2] == 4 * (n - 2) and hist[1] == 4
+    assert sorted(m.corner_nodes.tolist()) == [0, n - 1, n * (n - 1), n * n - 1]
+
+
+def test_interval_mesh():
+    m = interval_mesh(32)
+    assert m.edge_index.shape[1] == 62 and len(m.corner_nodes) == 0
+    d = collate([m, m])
+    ei = prepare_edge_index(d, 1, 32, True, False, 64)
+    assert ei.shape[1] == 2 * 62
+    deg = torch.bincount(ei[1], minlength=64)
+    assert deg[[0, 31, 32, 63]].tolist() == [1, 1, 1, 1] and (deg[1:31] == 2).all()
+
+
+def test_collate_rules_and_edge_surgery_match_oracle():
+    ds = MeshDataset([9, 9], 3, seed=1)
+    d = collate(ds.samples)
+    assert d.x_comp.shape == (243, 2) and d.batch.tolist() == sum(([b] * 81 for b in range(3)), [])
+    assert d.edge_index.max().item() == 242 and isinstance(d.corner_nodes, list) and len(d.corner_nodes) == 3
+    ours = prepare_edge_index(d, 2, 9, True, False, 243)
+    ref = masked_edge_index(d, 2, 9)
+    assert torch.equal(ours, ref)
+    with_loops = prepare_edge_index(d, 2, 9, True, True, 243)
+    assert (with_loops[0] == with_loops[1]).sum().item() == 243
+
+
+def test_csr_build_host():
+    d = collate(MeshDataset([7, 7], 2, seed=0).samples)
+    ei = prepare_edge_index(d, 2, 7, True, False, 98)
+    g = MeshGraph(ei, 98, 'cpu')
+    src, dst = ei
+    rt, rs = g.rowptr_t.long(), g.rowptr_s.long()
+    assert rt[-1] == ei.shape[1] == rs[-1]
+    assert torch.equal(g.col_t.long(), src[g.eid_t.long()])
+    for i in range(98):
+        ids = g.eid_t[rt[i]:rt[i + 1]].long()
+        assert (dst[ids] == i).all() and (ids[1:] > ids[:-1]).all()          # grouped by target, input order kept
+        slots = g.perm_s[rs[i]:rs[i + 1]].long()
+        assert (src[g.eid_t[slots].long()] == i).all()
+        assert torch.equal(g.col_s[rs[i]:rs[i + 1]].long(), dst[g.eid_t[slots].long()])
+    assert torch.equal(g.tpos_s[g.perm_s.long()].long(), torch.arange(ei.shape[1]))
+    alpha_t = torch.arange(ei.shape[1], dtype=torch.float32)
+    assert torch.equal(g.alpha_to_edge_order(alpha_t)[g.eid_t.long()], alpha_t)
+
+
+def test_csr_build_rejects_out_of_range():
+    ei = torch.tensor([[0, 5], [1, 0]])
+    with pytest.raises(_native.NativeError):
+        MeshGraph(ei, 3, 'cpu')
+
+
+def test_every_declared_symbol_is_exported():
+    header = open(os.path.join(ROOT, 'include', 'gadapt_hip.h')).read()
+    declared = set(re.findall(r'\b(gadapt_[a-z0-9_]+)\s*\(', header))
+    lib = C.CDLL(_native.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/gadapt_hip.h but not exported"
+    assert declared == set(_native.PROTOTYPES), declared ^ set(_native.PROTOTYPES)
+    assert _native.lib().gadapt_abi_version() == 1
+    assert [c for c in (3, 4, 8, 16, 32, 64, 128, 256) if _native.lib().gadapt_supported_hidden_dim(c)] == [4, 8, 16, 32, 64, 128]
+
+
+def test_bad_arguments_return_codes_not_aborts():
+    lib = _native.lib()
+    assert lib.gadapt_backward_slab_rows(0, 64) < 0
+    assert lib.gadapt_backward_slab_rows(1000, 7) < 0 and b'hidden_dim' in lib.gadapt_last_error()
+    assert lib.gadapt_backward_slab_rows(131072, 64) == 512
+    assert lib.gadapt_coeffs_forward(None, None, None, None, None, 8, None) == -1
+
+
+def test_module_surface_and_state_dict_keys():
+    opt = hot_path_opt(mesh_dims=[7, 7], hidden_dim=8, num_layers=3, learn_step=True)
+    m = GNN(MeshDataset([7, 7], 1), opt)
+    keys = set(m.state_dict())
+    assert {'enc.weight', 'conv_layers.0.lin_key.weight', 'conv_layers.0.lin_key.bias', 'conv_layers.2.lin_query.weight',
+            'conv_layers.2.lin_query.bias', 'conv_layers.1.lin_skip.weight', 'steps.0', 'steps.2'} <= keys
+    assert m.conv_layers[0] is m.conv_layers[2]                       # share_conv (GNN.py:131-141)
+    assert not m.enc.weight.requires_grad and torch.equal(m.enc.weight[:4], torch.eye(4)) and m.enc.weight[4:].abs().sum() == 0
+    assert opt['hidden_dims_list'] == [2, 1, 1]
+    m.epoch = 3; m.plot_evol_flag = True                              # arbitrary attribute writes (run_GNN.py:97)
+    sep = GNN(MeshDataset([7, 7], 1), hot_path_opt(mesh_dims=[7, 7], share_conv=False, num_layers=2))
+    assert sep.conv_layers[0] is not sep.conv_layers[1]
+    assert isinstance(get_conv(opt, 'GRAND', 8, 8), GRAND_conv) and isinstance(get_conv(opt, 'GRAND_plus', 8, 8, 8), GRAND_plusConv)
+
+
+def test_reference_error_conventions():
+    opt = hot_path_opt()
+    for bad in ('nope', 'Laplacian'):
+        with pytest.raises(NotImplementedError):
+            get_conv(opt, bad, 8, 8)
+    with pytest.raises(NotImplementedError):
+        GNN(MeshDataset([7, 7], 1), hot_path_opt(mesh_dims=[7, 7], non_lin='swish'))
+    with pytest.raises(NotImplementedError):
+        GNN(MeshDataset([7, 7], 1), hot_path_opt(mesh_dims=[7, 7], enc='bogus'))
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without the GPU instead of computing on the CPU."""
+    opt = hot_path_opt(mesh_dims=[7, 7])
+    ds = MeshDataset([7, 7], 1)
+    m = GNN(ds, opt)
+    with pytest.raises(_native.NativeError):
+        m(collate(ds.samples))
