@@ -1308,13 +1308,21 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void coeffs_fwd_kernel(const float* wq, const float* bq, const float* wk, float* a, float* p0, int c) {
+__global__ void coeffs_fwd_kernel(const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wk,
+                                  float* __restrict__ a, float* __restrict__ p0, int c) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < c * c) {
+    if (e < c * c) {                    // A[o][cc] = sum_r wk[r][o] wq[r][cc]; 4 independent chains hide the load latency
         const int o = e / c, cc = e % c;
-        float v = 0.f;
-        for (int r = 0; r < c; ++r) v = fmaf(wk[r * c + o], wq[r * c + cc], v);
-        a[e] = v;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int r = 0;
+        for (; r + 3 < c; r += 4) {
+            v0 = fmaf(wk[(r + 0) * c + o], wq[(r + 0) * c + cc], v0);
+            v1 = fmaf(wk[(r + 1) * c + o], wq[(r + 1) * c + cc], v1);
+            v2 = fmaf(wk[(r + 2) * c + o], wq[(r + 2) * c + cc], v2);
+            v3 = fmaf(wk[(r + 3) * c + o], wq[(r + 3) * c + cc], v3);
+        }
+        for (; r < c; ++r) v0 = fmaf(wk[r * c + o], wq[r * c + cc], v0);
+        a[e] = (v0 + v1) + (v2 + v3);
     } else if (e < c * c + c) {
         const int o = e - c * c;
         float v = 0.f;
@@ -1323,20 +1331,35 @@ __global__ void coeffs_fwd_kernel(const float* wq, const float* bq, const float*
     }
 }
 
-__global__ void coeffs_bwd_kernel(const float* wq, const float* bq, const float* wk, const float* d_a, const float* d_p0,
-                                  float* d_wq, float* d_bq, float* d_wk, float* d_bk, int c) {
+__global__ void coeffs_bwd_kernel(const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wk,
+                                  const float* __restrict__ d_a, const float* __restrict__ d_p0,
+                                  float* __restrict__ d_wq, float* __restrict__ d_bq, float* __restrict__ d_wk, float* __restrict__ d_bk, int c) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int c2 = c * c;
     if (e < c2) {                       // d_wq[r][cc] = sum_o wk[r][o] dA[o][cc]
         const int r = e / c, cc = e % c;
-        float v = 0.f;
-        for (int o = 0; o < c; ++o) v = fmaf(wk[r * c + o], d_a[o * c + cc], v);
-        d_wq[e] = v;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int o = 0;
+        for (; o + 3 < c; o += 4) {
+            v0 = fmaf(wk[r * c + o + 0], d_a[(o + 0) * c + cc], v0);
+            v1 = fmaf(wk[r * c + o + 1], d_a[(o + 1) * c + cc], v1);
+            v2 = fmaf(wk[r * c + o + 2], d_a[(o + 2) * c + cc], v2);
+            v3 = fmaf(wk[r * c + o + 3], d_a[(o + 3) * c + cc], v3);
+        }
+        for (; o < c; ++o) v0 = fmaf(wk[r * c + o], d_a[o * c + cc], v0);
+        d_wq[e] = (v0 + v1) + (v2 + v3);
     } else if (e < 2 * c2) {            // d_wk[r][o] = sum_cc wq[r][cc] dA[o][cc] + bq[r] dp0[o]
         const int f = e - c2, r = f / c, o = f % c;
-        float v = bq[r] * d_p0[o];
-        for (int cc = 0; cc < c; ++cc) v = fmaf(wq[r * c + cc], d_a[o * c + cc], v);
-        d_wk[f] = v;
+        float v0 = bq[r] * d_p0[o], v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int cc = 0;
+        for (; cc + 3 < c; cc += 4) {
+            v0 = fmaf(wq[r * c + cc + 0], d_a[o * c + cc + 0], v0);
+            v1 = fmaf(wq[r * c + cc + 1], d_a[o * c + cc + 1], v1);
+            v2 = fmaf(wq[r * c + cc + 2], d_a[o * c + cc + 2], v2);
+            v3 = fmaf(wq[r * c + cc + 3], d_a[o * c + cc + 3], v3);
+        }
+        for (; cc < c; ++cc) v0 = fmaf(wq[r * c + cc], d_a[o * c + cc], v0);
+        d_wk[f] = (v0 + v1) + (v2 + v3);
     } else if (e < 2 * c2 + c) {        // d_bq[r] = sum_o wk[r][o] dp0[o]
         const int r = e - 2 * c2;
         float v = 0.f;
@@ -1347,15 +1370,21 @@ __global__ void coeffs_bwd_kernel(const float* wq, const float* bq, const float*
     }
 }
 
-__global__ void encode_linear_kernel(const float* feats, const float* w, const float* b, float* x0,
-                                     int64_t n_nodes, int f, int c) {
+// x0[i][4q..4q+3] = sum_k feats[i][k] w[4q+t][k] (+ b): one float4 store per thread, 16 lanes write one 256-B row
+__global__ void encode_linear_kernel(const float* __restrict__ feats, const float* __restrict__ w, const float* __restrict__ b,
+                                     float* __restrict__ x0, int64_t n_nodes, int f, int c) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_nodes * c) return;
-    const int64_t i = e / c;
-    const int o = (int)(e % c);
-    float v = b ? b[o] : 0.f;
-    for (int k = 0; k < f; ++k) v = fmaf(feats[i * f + k], w[o * f + k], v);
-    x0[e] = v;
+    const int c4 = c >> 2;
+    if (e >= n_nodes * c4) return;
+    const int64_t i = e / c4;
+    const int o = (int)(e % c4) * 4;
+    float4 v = b ? make_float4(b[o], b[o + 1], b[o + 2], b[o + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < f; ++k) {
+        const float xv = feats[i * f + k];
+        v.x = fmaf(xv, w[(o + 0) * f + k], v.x); v.y = fmaf(xv, w[(o + 1) * f + k], v.y);
+        v.z = fmaf(xv, w[(o + 2) * f + k], v.z); v.w = fmaf(xv, w[(o + 3) * f + k], v.w);
+    }
+    *reinterpret_cast<float4*>(x0 + i * c + o) = v;
 }
 
 // slab [n_rows][row_len] -> part [CHUNKS][row_len]
@@ -1569,7 +1598,8 @@ extern "C" int gadapt_coeffs_backward(const float* wq, const float* bq, const fl
 
 extern "C" int gadapt_encode_linear(const float* feats, const float* w, const float* b, float* x0, int64_t n_nodes, int f, int c, void* stream) {
     if (!feats || !w || !x0 || n_nodes <= 0 || f <= 0 || c <= 0) return fail(GADAPT_E_BADARG, "encode_linear: bad argument");
-    const int64_t n = n_nodes * c;
+    if (c % 4) return fail(GADAPT_E_BADARG, "encode_linear: hidden_dim must be a multiple of 4");
+    const int64_t n = n_nodes * (c / 4);
     hipLaunchKernelGGL(encode_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), feats, w, b, x0, n_nodes, f, c);
     return check_launch("encode_linear_kernel");
 }
