@@ -1370,21 +1370,48 @@ __global__ void coeffs_bwd_kernel(const float* __restrict__ wq, const float* __r
     }
 }
 
-// x0[i][4q..4q+3] = sum_k feats[i][k] w[4q+t][k] (+ b): one float4 store per thread, 16 lanes write one 256-B row
-__global__ void encode_linear_kernel(const float* __restrict__ feats, const float* __restrict__ w, const float* __restrict__ b,
-                                     float* __restrict__ x0, int64_t n_nodes, int f, int c) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// x0[i][4q..4q+3] = sum_k feats[i][k] w[4q+t][k] (+ b).  W^T sits in LDS as float4 per (k, q); C/4 consecutive
+// threads write one 4*C-byte row, and a thread keeps its q while it strides over nodes.
+#define GADAPT_ENC_MAX_WORDS 4096      /* C * F floats of LDS */
+__global__ __launch_bounds__(256) void encode_linear_kernel(const float* __restrict__ feats, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ x0,
+                                                            int64_t n_nodes, int f, int c) {
+    __shared__ float4 wl[GADAPT_ENC_MAX_WORDS / 4];
     const int c4 = c >> 2;
+    for (int idx = threadIdx.x; idx < f * c4; idx += blockDim.x) {
+        const int k = idx / c4, q = idx % c4;
+        wl[idx] = make_float4(w[(4 * q + 0) * f + k], w[(4 * q + 1) * f + k], w[(4 * q + 2) * f + k], w[(4 * q + 3) * f + k]);
+    }
+    __syncthreads();
+    const int q = threadIdx.x % c4;
+    const int rows_per_block = blockDim.x / c4;
+    const float4 bias = b ? *reinterpret_cast<const float4*>(b + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / c4; i < n_nodes; i += (int64_t)gridDim.x * rows_per_block) {
+        float4 v = bias;
+        for (int k = 0; k < f; ++k) {
+            const float xv = feats[i * f + k];
+            const float4 wv = wl[k * c4 + q];
+            v.x = fmaf(xv, wv.x, v.x); v.y = fmaf(xv, wv.y, v.y); v.z = fmaf(xv, wv.z, v.z); v.w = fmaf(xv, wv.w, v.w);
+        }
+        *reinterpret_cast<float4*>(x0 + i * c + 4 * q) = v;
+    }
+}
+
+// g_top[i][:] = {g_phys[i][0..d), 0, ...}: backward of the x[:, :dim] slice (GNN.py:299) in one pass
+__global__ void pad_columns_kernel(const float* __restrict__ g_phys, float* __restrict__ g_top, int64_t n_nodes, int d, int c) {
+    const int c4 = c >> 2;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_nodes * c4) return;
     const int64_t i = e / c4;
     const int o = (int)(e % c4) * 4;
-    float4 v = b ? make_float4(b[o], b[o + 1], b[o + 2], b[o + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < f; ++k) {
-        const float xv = feats[i * f + k];
-        v.x = fmaf(xv, w[(o + 0) * f + k], v.x); v.y = fmaf(xv, w[(o + 1) * f + k], v.y);
-        v.z = fmaf(xv, w[(o + 2) * f + k], v.z); v.w = fmaf(xv, w[(o + 3) * f + k], v.w);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o < d) {
+        v.x = g_phys[i * d + o];
+        if (o + 1 < d) v.y = g_phys[i * d + o + 1];
+        if (o + 2 < d) v.z = g_phys[i * d + o + 2];
+        if (o + 3 < d) v.w = g_phys[i * d + o + 3];
     }
-    *reinterpret_cast<float4*>(x0 + i * c + o) = v;
+    *reinterpret_cast<float4*>(g_top + i * c + o) = v;
 }
 
 // slab [n_rows][row_len] -> part [CHUNKS][row_len]
@@ -1598,10 +1625,20 @@ extern "C" int gadapt_coeffs_backward(const float* wq, const float* bq, const fl
 
 extern "C" int gadapt_encode_linear(const float* feats, const float* w, const float* b, float* x0, int64_t n_nodes, int f, int c, void* stream) {
     if (!feats || !w || !x0 || n_nodes <= 0 || f <= 0 || c <= 0) return fail(GADAPT_E_BADARG, "encode_linear: bad argument");
-    if (c % 4) return fail(GADAPT_E_BADARG, "encode_linear: hidden_dim must be a multiple of 4");
-    const int64_t n = n_nodes * (c / 4);
-    hipLaunchKernelGGL(encode_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), feats, w, b, x0, n_nodes, f, c);
+    if (c % 4 || c > 256 || 256 % (c / 4) || (int64_t)c * f > GADAPT_ENC_MAX_WORDS)
+        return fail(GADAPT_E_BADARG, "encode_linear: need hidden_dim in {4,8,...,256} dividing 1024 and hidden_dim*in_dim <= 4096");
+    const int rows_per_block = 256 / (c / 4);
+    int64_t blocks = (n_nodes + rows_per_block - 1) / rows_per_block;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(encode_linear_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), feats, w, b, x0, n_nodes, f, c);
     return check_launch("encode_linear_kernel");
+}
+
+extern "C" int gadapt_pad_columns(const float* g_phys, float* g_top, int64_t n_nodes, int d, int c, void* stream) {
+    if (!g_phys || !g_top || n_nodes <= 0 || d <= 0 || d > c || c % 4) return fail(GADAPT_E_BADARG, "pad_columns: bad argument");
+    const int64_t n = n_nodes * (c / 4);
+    hipLaunchKernelGGL(pad_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), g_phys, g_top, n_nodes, d, c);
+    return check_launch("pad_columns_kernel");
 }
 
 extern "C" int gadapt_mesh_loss_seed(const float* x_top, const float* target, float* x_phys, float* g_top, float* loss_out,

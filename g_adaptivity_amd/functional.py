@@ -41,7 +41,8 @@ class _GrandEulerBlock(torch.autograd.Function):
     S = 1 (share_conv) or L; layer_params [L,2] = (dt, score_scale)."""
 
     @staticmethod
-    def forward(ctx, x0, wq, bq, wk, bk, layer_params, graph: MeshGraph, num_layers: int, want_alpha: bool, x_all=None):
+    def forward(ctx, x0, wq, bq, wk, bk, layer_params, graph: MeshGraph, num_layers: int, want_alpha: bool, x_all=None,
+                out_cols=None):
         for t, n in ((x0, 'x'), (wq, 'lin_query.weight'), (bq, 'lin_query.bias'), (wk, 'lin_key.weight'),
                      (layer_params, 'layer_params')):
             _require_gpu(t, n)
@@ -73,8 +74,9 @@ class _GrandEulerBlock(torch.autograd.Function):
                                          ptr(p0), c if S > 1 else 0, ptr(layer_params), ptr(alpha), c, st),
               'gadapt_block_forward')
         ctx.graph, ctx.L, ctx.S, ctx.c = graph, L, S, c
+        ctx.out_cols = out_cols
         ctx.save_for_backward(x_all, alpha if need_grad else None, a, p0, wq, bq, wk, layer_params)
-        out = x_all[L]
+        out = x_all[L] if out_cols is None else x_all[L][:, :out_cols]    # x[:, :dim] (GNN.py:299)
         if want_alpha:
             ctx.mark_non_differentiable(alpha)
             return out, alpha
@@ -87,6 +89,9 @@ class _GrandEulerBlock(torch.autograd.Function):
         n = graph.num_nodes
         dev, st = g_top.device, current_stream(g_top.device)
         g_top = g_top.contiguous()
+        if ctx.out_cols is not None:            # one zero-padding pass instead of autograd's zeros + slice copy
+            g_phys, g_top = g_top, torch.empty(n, c, device=dev, dtype=torch.float32)
+            check(lib().gadapt_pad_columns(ptr(g_phys), ptr(g_top), n, ctx.out_cols, c, st), 'gadapt_pad_columns')
         need_x0 = ctx.needs_input_grad[0]
         slab_floats = lib().gadapt_backward_slab_floats(n, c)
         slab_rows = lib().gadapt_backward_slab_rows(n, c)
@@ -110,7 +115,7 @@ class _GrandEulerBlock(torch.autograd.Function):
             check(lib().gadapt_coeffs_backward(ptr(wq[s]), ptr(bq[s]), ptr(wk[s]), ptr(d_a), ptr(d_p0),
                                                ptr(d_wq[s]), ptr(d_bq[s]), ptr(d_wk[s]), ptr(d_bk[s]), c, st),
                   'gadapt_coeffs_backward')
-        return d_x0, d_wq, d_bq, d_wk, d_bk, d_lp, None, None, None, None
+        return d_x0, d_wq, d_bq, d_wk, d_bk, d_lp, None, None, None, None, None
 
 
 class _GrandResidual(torch.autograd.Function):
@@ -171,13 +176,15 @@ def grand_residual(x, wq, bq, wk, bk, scale: torch.Tensor, graph: MeshGraph, wan
 
 
 def grand_euler_block(x0: torch.Tensor, wq, bq, wk, bk, layer_params: torch.Tensor, graph: MeshGraph,
-                      num_layers: int, want_alpha: bool = False, x_all: Optional[torch.Tensor] = None):
+                      num_layers: int, want_alpha: bool = False, x_all: Optional[torch.Tensor] = None,
+                      out_cols: Optional[int] = None):
     """Returns (x_L [N,C], alpha [L,E] in target-CSR order or None).
 
     `x_all` (optional): a contiguous [(L+1),N,C] buffer whose slot 0 IS `x0` (same memory); the
-    layers then write straight into it and no copy of x0 is made."""
+    layers then write straight into it and no copy of x0 is made.  `out_cols`: return only the first
+    columns of x_L (the `x[:, :dim]` slice of `src/GNN.py:299`) with a single-pass backward."""
     return _GrandEulerBlock.apply(x0.contiguous(), wq, bq, wk, bk, layer_params, graph, num_layers, want_alpha,
-                                  None if x_all is None else [x_all])
+                                  None if x_all is None else [x_all], out_cols)
 
 
 def score_scale(hidden_dim: int, temperature=None):

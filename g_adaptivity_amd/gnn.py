@@ -178,7 +178,7 @@ class GNN(nn.Module):
         graph = self._graph(data, n, dev)
 
         fusable = self._fusable()
-        x_all = None
+        x_all, sliced = None, False
         if isinstance(self.enc, nn.Linear) and not self.enc.weight.requires_grad and self.enc.bias is None:
             if fusable and not (self.training and o.get('dropout', 0.0) > 0):
                 # encoder output lands in slot 0 of the block's activation buffer: no copy
@@ -203,7 +203,9 @@ class GNN(nn.Module):
                 bk = torch.stack([l.lin_key.bias for l in self.conv_layers])
             store = o['conv_type'] == 'GRAND' or isinstance(o.get('show_mesh_evol_plots'), bool)
             x, alpha = Fn.grand_euler_block(x, wq, bq, wk, bk, self._layer_params(dev), graph,
-                                            o['num_layers'], want_alpha=store, x_all=x_all)
+                                            o['num_layers'], want_alpha=store, x_all=x_all,
+                                            out_cols=self.dim if isinstance(self.dec, nn.Identity) else None)
+            sliced = isinstance(self.dec, nn.Identity)
             if store:                                                      # GRAND_plus.py:253-256, :381
                 for l, layer in enumerate(self.conv_layers):
                     layer.stored_ei, layer._stored = graph.edge_index, (graph, alpha[l])
@@ -219,8 +221,11 @@ class GNN(nn.Module):
                 else:
                     x = res
 
-        x = self.dec(x) if self.dec is not None else x                    # GNN.py:298
-        x_phys = x[:, :self.dim]                                          # GNN.py:299
+        if sliced:
+            x_phys = x                                                     # dec = Identity and x[:, :dim] done inside the block op
+        else:
+            x = self.dec(x) if self.dec is not None else x                 # GNN.py:298
+            x_phys = x[:, :self.dim]                                       # GNN.py:299
         if not self.training:
             torch.cuda.current_stream(dev).synchronize()                  # the stamp is read as a latency (utils_eval.py:201)
         self.end_MLmodel = time.time()                                    # GNN.py:301

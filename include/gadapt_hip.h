@@ -144,6 +144,9 @@ int gadapt_mesh_loss_seed(const float* x_top, const float* target, float* x_phys
                           float* loss_out, int64_t n_nodes, int d, int c, int l1, float grad_scale,
                           void* stream);
 
+/* Backward of the slice x_phys = x_top[:, :d] (GNN.py:299): g_top [N,C] = g_phys [N,d] zero-padded. */
+int gadapt_pad_columns(const float* g_phys, float* g_top, int64_t n_nodes, int d, int c, void* stream);
+
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.Adam(lr, weight_decay) step on a flat fp32 bucket (run_GNN.py:88,128-131):
  * L2 weight decay added to the gradient, bias-corrected moments, eps outside the sqrt.

@@ -143,8 +143,10 @@ def test_golden_fixtures(gpu_device, path):
     F.mse_loss(xL[:, :d], tgt).backward()
     assert rel_err(xL[:, :d], torch.from_numpy(g['x_phys_f64']))[0] <= 1e-5
     assert rel_err(graph.alpha_to_edge_order(alpha[-1]), torch.from_numpy(g['alpha_last_f64']))[0] <= 1e-5
-    for p, k in zip(params[:3], ('d_wq_f64', 'd_bq_f64', 'd_wk_f64')):
-        assert rel_err(p.grad[0], torch.from_numpy(g[k]))[0] <= 1e-4, k
+    for p, k in zip(params[:3], ('d_wq', 'd_bq', 'd_wk')):
+        want64, want32 = torch.from_numpy(g[k + '_f64']), torch.from_numpy(g[k + '_f32'])
+        noise = rel_err(want32, want64)[0]                                 # the fp32 oracle's own rounding error
+        assert rel_err(p.grad[0], want64)[0] <= max(1e-4, 1.5 * noise), (k, rel_err(p.grad[0], want64)[0], noise)
 
 
 @pytest.mark.gpu
