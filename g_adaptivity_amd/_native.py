@@ -16,7 +16,11 @@ SUPPORTED_HIDDEN = (4, 8, 16, 32, 64, 128)
 class GadaptGraph(C.Structure):
     _fields_ = [('n_nodes', C.c_int32), ('n_edges', C.c_int32),
                 ('rowptr_t', C.c_void_p), ('col_t', C.c_void_p),
-                ('rowptr_s', C.c_void_p), ('col_s', C.c_void_p), ('perm_s', C.c_void_p), ('tpos_s', C.c_void_p)]
+                ('rowptr_s', C.c_void_p), ('col_s', C.c_void_p), ('perm_s', C.c_void_p), ('tpos_s', C.c_void_p),
+                ('meta_t', C.c_void_p * 3), ('meta_s', C.c_void_p * 3)]
+
+
+TILE_HEIGHTS = (64, 128, 256)
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -28,6 +32,7 @@ PROTOTYPES = {
     'gadapt_last_error': (C.c_char_p, []),
     'gadapt_abi_version': (_I, []),
     'gadapt_csr_build_host': (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P]),
+    'gadapt_tile_meta_host': (_I, [_P, _L, _I, _P]),
     'gadapt_coeffs_forward': (_I, [_P, _P, _P, _P, _P, _I, _P]),
     'gadapt_coeffs_backward': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'gadapt_encode_linear': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),

@@ -40,3 +40,19 @@ extern "C" int gadapt_csr_build_host(const int64_t* src, const int64_t* dst, int
     }
     return GADAPT_OK;
 }
+
+// Per-tile staging metadata (see include/gadapt_hip.h): 4 ints per tile of `tile_rows` consecutive rows.
+extern "C" int gadapt_tile_meta_host(const int32_t* rowptr, int64_t n_nodes, int tile_rows, int32_t* meta_out) {
+    if (!rowptr || !meta_out || n_nodes <= 0 || tile_rows <= 0) return GADAPT_E_BADARG;
+    const int64_t n_tiles = (n_nodes + tile_rows - 1) / tile_rows;
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        const int64_t lo = t * tile_rows, hi = (lo + tile_rows < n_nodes) ? lo + tile_rows : n_nodes;
+        int32_t longest = 0;
+        for (int64_t i = lo; i < hi; ++i) { const int32_t d = rowptr[i + 1] - rowptr[i]; if (d > longest) longest = d; }
+        meta_out[4 * t + 0] = rowptr[lo];
+        meta_out[4 * t + 1] = rowptr[hi] - rowptr[lo];
+        meta_out[4 * t + 2] = longest;
+        meta_out[4 * t + 3] = 0;
+    }
+    return GADAPT_OK;
+}

@@ -246,52 +246,37 @@ template <int C> __device__ __forceinline__ void stage_tile(const float* __restr
     }
 }
 
-// The tile's slice of one CSR orientation in LDS: rowptr[TM+1], col[CAP] and AUXW per-edge words.
-// A tile whose slice does not fit (more than CAP entries) or that has a row longer than MAXD is flagged
-// "slow" for the whole workgroup and walks the HBM copy with plain loops instead.
+// The tile's slice of one CSR orientation in LDS: rowptr[TM+1], col[COLN] and AUXW per-edge words.  Where the slice
+// starts, how long it is and the tile's longest row come from per-tile metadata built with the graph
+// (gadapt_tile_meta_host), so every load of the stage is issued at once: one memory round trip per tile.
+// A tile whose slice does not fit (more than CAP entries) or that has a row longer than MAXD is "slow":
+// the whole workgroup walks the HBM copy with plain loops instead.
 template <int C, int AUXW> struct TileCsr {
     using K = Cfg<C>;
     int* rp; int* col; float* aux;
-    const int32_t* rowptr_g; const int32_t* col_g; const float* aux_g;
-    int ebase, parity;
+    const int32_t* rowptr_g; const int32_t* col_g; const float* aux_g; const int4* meta_g;
+    int ebase;
 
-    __device__ __forceinline__ void bind(float* lds_after_tiles, const int32_t* rowptr_g_, const int32_t* col_g_, const float* aux_g_) {
+    __device__ __forceinline__ void bind(float* lds_after_tiles, const int32_t* rowptr_g_, const int32_t* col_g_, const float* aux_g_,
+                                         const int32_t* meta_g_) {
         rp = reinterpret_cast<int*>(lds_after_tiles);
         col = rp + (K::TM + 4);
         aux = reinterpret_cast<float*>(col + K::COLN);
-        rowptr_g = rowptr_g_; col_g = col_g_; aux_g = aux_g_;
+        rowptr_g = rowptr_g_; col_g = col_g_; aux_g = aux_g_; meta_g = reinterpret_cast<const int4*>(meta_g_);
     }
-    // Returns the tile's largest row length (block-uniform), or -1 for a slow tile (a row longer than
-    // MAXD, or more than CAP entries).  Acts as the workgroup barrier after staging.
-    // (block-wide bitwise OR through two alternating LDS words: __syncthreads_or is only a logical OR)
-    __device__ __forceinline__ void init(int tid) {
-        if (tid == 0) { rp[K::TM + 1] = 0; rp[K::TM + 2] = 0; }
-        parity = 0;
-        __syncthreads();
-    }
-    __device__ __forceinline__ int stage(int node0, int n_nodes, int tid) {
-        int bits = 0;
-        for (int idx = tid; idx <= K::TM; idx += 256) {
-            const int lo = rowptr_g[min(node0 + idx, n_nodes)];
-            rp[idx] = lo;
-            if (idx < K::TM) bits |= 1 << min(rowptr_g[min(node0 + idx + 1, n_nodes)] - lo, GADAPT_MAXD + 1);
-        }
-        ebase = rowptr_g[node0];
-        const int total = rowptr_g[min(node0 + K::TM, n_nodes)] - ebase;
+    // Returns the tile's largest row length (block-uniform), or -1 for a slow tile.  Ends with the workgroup barrier.
+    __device__ __forceinline__ int stage(int t, int node0, int n_nodes, int tid) {
+        const int4 m = meta_g[t];
+        ebase = m.x;
+        const int total = m.y;
         const int cnt = min(total, K::CAP);
+        for (int idx = tid; idx <= K::TM; idx += 256) rp[idx] = rowptr_g[min(node0 + idx, n_nodes)];
         for (int idx = tid; idx < cnt + GADAPT_MAXD; idx += 256) col[idx] = (idx < cnt) ? col_g[ebase + idx] : node0;
         if constexpr (AUXW > 0)
             for (int idx = tid; idx < AUXW * (cnt + GADAPT_MAXD); idx += 256)
                 aux[idx] = (idx < AUXW * cnt) ? aux_g[(size_t)AUXW * ebase + idx] : 0.f;
-        if (total > K::CAP) bits |= 1 << (GADAPT_MAXD + 1);
-        int* flag = rp + K::TM + 1 + parity;
-        if (bits) atomicOr(flag, bits);
         __syncthreads();
-        bits = *flag;
-        parity ^= 1;
-        if (tid == 0) rp[K::TM + 1 + parity] = 0;               // next tile's word; its last readers passed a barrier already
-        if (bits >> (GADAPT_MAXD + 1)) return -1;
-        return 31 - __builtin_clz(bits | 1);
+        return (total > K::CAP || m.z > GADAPT_MAXD) ? -1 : m.z;
     }
 };
 
@@ -424,7 +409,7 @@ extern "C" int gadapt_debug_set_stamp_buffer(void* p) { g_stamp_buf = static_cas
 struct FwdArgs {
     const float* x_in; float* x_out;
     const float* A; const float* p0; const float* lp;
-    const int32_t* rowptr; const int32_t* col;
+    const int32_t* rowptr; const int32_t* col; const int32_t* meta;
     float* alpha_out;
     int n_nodes, n_tiles, residual_only;
     unsigned long long* stamps;
@@ -437,8 +422,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     float* xs = reinterpret_cast<float*>(smem4);
     float* ps = xs + K::TILE_FLOATS;
     TileCsr<C, 0> csr;
-    csr.bind(ps + K::TILE_FLOATS, p.rowptr, p.col, nullptr);
-    csr.init(threadIdx.x);
+    csr.bind(ps + K::TILE_FLOATS, p.rowptr, p.col, nullptr, p.meta);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
     const float dt = p.lp[0], sc = p.lp[1];
@@ -566,7 +550,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
         GADAPT_STAMP(p.stamps, tslot + 0);
         if constexpr (K::MFMA) gemm.load(p.A, p.p0);
         stage_tile<C>(p.x_in, xs, node0, p.n_nodes, tid);
-        const int dmax = csr.stage(node0, p.n_nodes, tid);      // barrier inside
+        const int dmax = csr.stage(t, node0, p.n_nodes, tid);      // barrier inside
         GADAPT_STAMP(p.stamps, tslot + 1);
         if (dmax >= 0) {
             dispatch_dmax(dmax, [&](auto tag) {
@@ -633,13 +617,14 @@ template <int NROWS> struct FBuf {
     int deg, el0;
 };
 
-// Loader wave: global -> registers -> LDS for one tile.  Rows past N are zero.  64 lanes.  The first
-// chunk of loads is issued BEFORE the compute waves' mid-tile barriers (the loader just arrives at them
-// with the loads in flight); the rest follows in chunks of at most 8 float4 per lane.
+// Loader wave: global -> registers -> LDS for one tile.  Rows past N are zero.  64 lanes.  Every load of the
+// first chunk is issued BEFORE the compute waves' mid-tile barriers (the loader just arrives at them with the
+// loads in flight); the rest of the x rows follows in chunks of at most 8 float4 per lane.
 template <int C, int AUXW>
 __device__ __forceinline__ void loader_fetch_tile(const float* __restrict__ xsrc, const int32_t* __restrict__ rowptr_g,
                                                   const int32_t* __restrict__ col_g, const float* __restrict__ aux_g,
-                                                  int node0, int n_nodes, int lane, const TileSlot<C, AUXW>& dst, int n_mid_barriers) {
+                                                  const int32_t* __restrict__ meta_g, int t, int n_nodes, int lane,
+                                                  const TileSlot<C, AUXW>& dst, int n_mid_barriers) {
     using K = Cfg<C>;
     using S = Swz<C>;
     constexpr int V = C / 4;
@@ -647,6 +632,10 @@ __device__ __forceinline__ void loader_fetch_tile(const float* __restrict__ xsrc
     constexpr int XCH = XN < 8 ? XN : 8;
     constexpr int RN = (K::TM + 1 + 63) / 64;
     constexpr int CN = K::COLN / 64;
+    const int node0 = t * K::TM;
+    const int4 m = reinterpret_cast<const int4*>(meta_g)[t];
+    const int ebase = m.x, total = m.y;
+    const int cnt = min(total, K::CAP);
     float4 xv[XCH];
     int rpv[RN], cv[CN];
     auto x_load = [&](int c0) {
@@ -666,25 +655,14 @@ __device__ __forceinline__ void loader_fetch_tile(const float* __restrict__ xsrc
     x_load(0);
 #pragma unroll
     for (int q = 0; q < RN; ++q) rpv[q] = rowptr_g[min(node0 + min(q * 64 + lane, K::TM), n_nodes)];
-    const int ebase = rowptr_g[node0];
-    const int total = rowptr_g[min(node0 + K::TM, n_nodes)] - ebase;
-    const int cnt = min(total, K::CAP);
 #pragma unroll
     for (int q = 0; q < CN; ++q) cv[q] = (q * 64 + lane < cnt) ? col_g[ebase + q * 64 + lane] : node0;   // padding: a valid node
     for (int b = 0; b < n_mid_barriers; ++b) __builtin_amdgcn_s_barrier();
     x_store(0);
 #pragma unroll 1
     for (int c0 = XCH; c0 < XN; c0 += XCH) { x_load(c0); x_store(c0); }
-    int bits = 0;
 #pragma unroll
-    for (int q = 0; q < RN; ++q) {
-        const int idx = q * 64 + lane;
-        if (idx <= K::TM) dst.rp[idx] = rpv[q];
-        // row length of node idx = rowptr[idx+1]-rowptr[idx]; the neighbour lane holds rowptr[idx+1]
-        int nxt = __shfl_down(rpv[q], 1, 64);
-        if (q + 1 < RN) { const int wrap = __shfl(rpv[q + 1 < RN ? q + 1 : q], 0, 64); if (lane == 63) nxt = wrap; }
-        if (idx < K::TM) bits |= 1 << min(max(nxt - rpv[q], 0), GADAPT_MAXD + 1);
-    }
+    for (int q = 0; q < RN; ++q) if (q * 64 + lane <= K::TM) dst.rp[q * 64 + lane] = rpv[q];
 #pragma unroll
     for (int q = 0; q < CN; ++q) dst.col[q * 64 + lane] = cv[q];
     if constexpr (AUXW > 0) {
@@ -694,10 +672,7 @@ __device__ __forceinline__ void loader_fetch_tile(const float* __restrict__ xsrc
             dst.aux[idx] = (idx < AUXW * cnt) ? aux_g[(size_t)AUXW * ebase + idx] : 0.f;
         }
     }
-    if (total > K::CAP) bits |= 1 << (GADAPT_MAXD + 1);
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) bits |= __shfl_xor(bits, m, 64);
-    if (lane == 0) dst.rp[K::TM + 1] = (bits >> (GADAPT_MAXD + 1)) ? -1 : 31 - __builtin_clz(bits | 1);
+    if (lane == 0) dst.rp[K::TM + 1] = (total > K::CAP || m.z > GADAPT_MAXD) ? -1 : m.z;
 }
 
 template <int C>
@@ -713,14 +688,14 @@ __global__ __launch_bounds__(320, GADAPT_WAVES_FWD_MFMA) void grand_fwd_mfma_ker
 
     if (wave == 4) {
         // ------------------------------------------------------------------ loader wave
-        if (tr.t < tr.t_end) loader_fetch_tile<C, 0>(p.x_in, p.rowptr, p.col, nullptr, tr.t * K::TM, p.n_nodes, lane, slot_of(0), 0);
+        if (tr.t < tr.t_end) loader_fetch_tile<C, 0>(p.x_in, p.rowptr, p.col, nullptr, p.meta, tr.t, p.n_nodes, lane, slot_of(0), 0);
         wg_barrier();                                            // first tile staged
         int cur = 0;
         for (int t = tr.t; t < tr.t_end; t += tr.step, cur ^= 1) {
             const int lslot = 16 + ((t - tr.t) / tr.step) * 4;
             GADAPT_STAMP_L(p.stamps, lslot + 0);
             if (t + tr.step < tr.t_end)
-                loader_fetch_tile<C, 0>(p.x_in, p.rowptr, p.col, nullptr, (t + tr.step) * K::TM, p.n_nodes, lane, slot_of(cur ^ 1), 2);
+                loader_fetch_tile<C, 0>(p.x_in, p.rowptr, p.col, nullptr, p.meta, t + tr.step, p.n_nodes, lane, slot_of(cur ^ 1), 2);
             else { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
             GADAPT_STAMP_L(p.stamps, lslot + 1);
             wg_barrier();                                        // end of tile: next slot is staged
@@ -894,20 +869,21 @@ __global__ __launch_bounds__(320, GADAPT_WAVES_FWD_MFMA) void grand_fwd_mfma_ker
 struct BwdTArgs {
     const float* x_in; const float* g_in; const float* alpha;
     const float* A; const float* lp;
-    const int32_t* rowptr; const int32_t* col; const int32_t* tpos;
+    const int32_t* rowptr; const int32_t* col; const int32_t* tpos; const int32_t* meta;
     float2* edge_ws; float* dxd; float* slab; float* sums_out;
     int n_nodes, n_tiles, accumulate, residual_only;
 };
 
-template <int C>
+// SUMS: also reduce d/d(dt) and d/d(score_scale) (learn_step / learnable temperature).  A separate instantiation:
+// hipcc otherwise sinks the per-edge log terms behind the pipeline and keeps 48 extra registers alive for them.
+template <int C, bool SUMS>
 __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kernel(BwdTArgs p) {
     using K = Cfg<C>;
     extern __shared__ float4 smem4[];
     float* xs = reinterpret_cast<float*>(smem4);
     float* ds = xs + K::TILE_FLOATS;                            // dP tile
     TileCsr<C, 1> csr;                                          // aux = forward alpha (target order)
-    csr.bind(ds + K::TILE_FLOATS, p.rowptr, p.col, p.alpha);
-    csr.init(threadIdx.x);
+    csr.bind(ds + K::TILE_FLOATS, p.rowptr, p.col, p.alpha, p.meta);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
     // out = base*x + dt*(m - x): Euler step (base 1) or bare residual (base 0, dt 1)
@@ -945,7 +921,8 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         if (i < p.n_nodes) {
             // d dt = sum_i <g_i, m_i - x_i>   (GNN.py:288-289 learn_step); every lane adds its 4 channels
             const float4 xi = *reinterpret_cast<const float4*>(xs + li * K::LD + 4 * sub);
-            sum_ddt += gi.x * (m.x - xi.x) + gi.y * (m.y - xi.y) + gi.z * (m.z - xi.z) + gi.w * (m.w - xi.w);
+            if constexpr (SUMS)
+                sum_ddt += gi.x * (m.x - xi.x) + gi.y * (m.y - xi.y) + gi.z * (m.z - xi.z) + gi.w * (m.w - xi.w);
             dp0acc.x += dP.x; dp0acc.y += dP.y; dp0acc.z += dP.z; dp0acc.w += dP.w;
         }
         *reinterpret_cast<float4*>(ds + li * K::LD + 4 * sub) = dP;
@@ -988,8 +965,10 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             const float dsp = a[k] * (da[k] - D);                   // d(score'), score' = sc * <P_i,x_j>
             da[k] = dsp * sc;                                       // reuse: d<P_i,x_j>
             axpy4(dP, da[k], b.r[k]);
-            axpy4(m, a[k], b.r[k]);
-            if (p.sums_out) { if (a[k] > 0.f) sum_dsc = fmaf(dsp, __logf(a[k]), sum_dsc); }
+            if constexpr (SUMS) {
+                axpy4(m, a[k], b.r[k]);
+                if (a[k] > 0.f) sum_dsc = fmaf(dsp, __logf(a[k]), sum_dsc);
+            }
         }
         if constexpr (K::LPN >= DM) {
             const float am = pick(a, sub), dm_ = pick(da, sub);
@@ -1019,8 +998,10 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
                 const float dsp = ak * (group_sum<K::LPN>(dot4(dm, v)) - D);
                 const float dss = dsp * sc;
                 axpy4(dP, dss, v);
-                axpy4(m, ak, v);
-                if (ak > 0.f) sum_dsc = fmaf(dsp, __logf(ak), sum_dsc);
+                if constexpr (SUMS) {
+                    axpy4(m, ak, v);
+                    if (ak > 0.f) sum_dsc = fmaf(dsp, __logf(ak), sum_dsc);
+                }
                 if ((k % K::LPN) == sub) p.edge_ws[p.tpos[e0 + k]] = make_float2(ak * dt, dss);
             }
         }
@@ -1031,7 +1012,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
     for (int t = tr.t; t < tr.t_end; t += tr.step) {
         const int node0 = t * K::TM;
         stage_tile<C>(p.x_in, xs, node0, p.n_nodes, tid);
-        const int dmax = csr.stage(node0, p.n_nodes, tid);      // barrier inside
+        const int dmax = csr.stage(t, node0, p.n_nodes, tid);      // barrier inside
         // ---- edge phase: dP_i per node -> LDS
         if (dmax >= 0) {
             dispatch_dmax(dmax, [&](auto tag) {
@@ -1165,7 +1146,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             if (p.accumulate) v += row[C * C + tid];
             row[C * C + tid] = v;
         }
-        if (p.sums_out && tid < 2) {
+        if (SUMS && p.sums_out && tid < 2) {
             float v = 0.f;
             for (int s = 0; s < 256; ++s) v += red[s * 6 + 4 + tid];
             if (tid == 1) v = v / sc;                           // d/d(score_scale) = sum d(score') * <P,x>
@@ -1180,7 +1161,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
 struct BwdSArgs {
     const float* x_in; const float* g_in; const float* edge_ws; const float* dxd;
     const float* A; const float* p0;
-    const int32_t* rowptr; const int32_t* col;
+    const int32_t* rowptr; const int32_t* col; const int32_t* meta;
     float* g_out;
     int n_nodes, n_tiles;
 };
@@ -1192,8 +1173,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
     float* ys = reinterpret_cast<float*>(smem4);
     float* os = ys + K::TILE_FLOATS;
     TileCsr<C, 2> csr;                                          // aux = {alpha*dt, d<P,x>} per out-edge (source order)
-    csr.bind(os + K::TILE_FLOATS, p.rowptr, p.col, p.edge_ws);
-    csr.init(threadIdx.x);
+    csr.bind(os + K::TILE_FLOATS, p.rowptr, p.col, p.edge_ws, p.meta);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
 
@@ -1257,7 +1237,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
     const TileRange tr = tile_range(p.n_tiles);
     for (int t = tr.t; t < tr.t_end; t += tr.step) {
         const int node0 = t * K::TM;
-        const int dmax = csr.stage(node0, p.n_nodes, tid);      // barrier inside
+        const int dmax = csr.stage(t, node0, p.n_nodes, tid);      // barrier inside
         float4 zr[K::ITERS];
         float sg[K::ITERS];
         if (dmax >= 0) {
@@ -1487,6 +1467,11 @@ static inline int grid_for(int n_tiles, int max_blocks) {
 #endif
 #define GADAPT_BWD_T_MAX_BLOCKS 512      /* target pass grid = slab row count */
 
+// per-tile metadata pointer for this kernel's tile height (the graph carries one array per supported height)
+template <int TM> static const int32_t* meta_for(const int32_t* const (&m)[3]) {
+    static_assert(TM == 64 || TM == 128 || TM == 256, "tile heights with metadata");
+    return m[TM == 64 ? 0 : (TM == 128 ? 1 : 2)];
+}
 template <typename KernelT> static void allow_lds(KernelT k, int bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
@@ -1494,7 +1479,8 @@ template <typename KernelT> static void allow_lds(KernelT k, int bytes) {
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                                        const float* lp, float* alpha_out, int residual_only, hipStream_t st) {
     using K = Cfg<C>;
-    FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, alpha_out, g->n_nodes, (g->n_nodes + K::TM - 1) / K::TM, residual_only, nullptr};
+    FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t), alpha_out, g->n_nodes,
+              (g->n_nodes + K::TM - 1) / K::TM, residual_only, nullptr};
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
 #endif
@@ -1515,18 +1501,23 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
                                        int accumulate, float* sums_out, float* g_out, int residual_only, hipStream_t st) {
     using K = Cfg<C>;
     const int n_tiles = (g->n_nodes + K::TM - 1) / K::TM;
-    BwdTArgs pt{x_in, g_in, alpha, a, lp, g->rowptr_t, g->col_t, g->tpos_s, reinterpret_cast<float2*>(edge_ws), dxd, slab, sums_out,
+    BwdTArgs pt{x_in, g_in, alpha, a, lp, g->rowptr_t, g->col_t, g->tpos_s, meta_for<K::TM>(g->meta_t), reinterpret_cast<float2*>(edge_ws), dxd, slab, sums_out,
                 g->n_nodes, n_tiles, accumulate, residual_only};
     constexpr int lds_t = K::lds_bytes(1), lds_s = K::lds_bytes(2);
-    allow_lds(grand_bwd_target_kernel<C>, lds_t);
     int rc;
     {
         ProfScope prof(1, st);
-        hipLaunchKernelGGL(grand_bwd_target_kernel<C>, dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
+        if (sums_out) {
+            allow_lds(grand_bwd_target_kernel<C, true>, lds_t);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, true>), dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
+        } else {
+            allow_lds(grand_bwd_target_kernel<C, false>, lds_t);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false>), dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
+        }
         rc = check_launch("grand_bwd_target_kernel");
     }
     if (rc || !g_out) return rc;
-    BwdSArgs ps{x_in, g_in, edge_ws, dxd, a, p0, g->rowptr_s, g->col_s, g_out, g->n_nodes, n_tiles};
+    BwdSArgs ps{x_in, g_in, edge_ws, dxd, a, p0, g->rowptr_s, g->col_s, meta_for<K::TM>(g->meta_s), g_out, g->n_nodes, n_tiles};
     allow_lds(grand_bwd_source_kernel<C>, lds_s);
     ProfScope prof(2, st);
     hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds_s, st, ps);
@@ -1546,6 +1537,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
 
 static int check_graph(const gadapt_graph* g, int c) {
     if (!g || g->n_nodes <= 0 || g->n_edges < 0 || !g->rowptr_t || !g->col_t) return fail(GADAPT_E_BADARG, "bad graph");
+    for (int k = 0; k < 3; ++k) if (!g->meta_t[k] || !g->meta_s[k]) return fail(GADAPT_E_BADARG, "graph without tile metadata (gadapt_tile_meta_host)");
     if ((int64_t)g->n_nodes * c * 4 >= ((int64_t)1 << 32)) return fail(GADAPT_E_BADARG, "n_nodes*C*4 must stay below 4 GiB (32-bit row offsets)");
     return GADAPT_OK;
 }
@@ -1559,7 +1551,7 @@ extern "C" int gadapt_debug_occupancy(int c, int* out3) {
         using K = Cfg<CC>;                                                                                              \
         if constexpr (K::MFMA) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_mfma_kernel<CC>, 320, 2 * TileSlot<CC, 0>::WORDS * 4); \
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_kernel<CC>, 256, K::lds_bytes(0)); \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC>, 256, K::lds_bytes(1)); \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC, false>, 256, K::lds_bytes(1)); \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], grand_bwd_source_kernel<CC>, 256, K::lds_bytes(2)); \
         return GADAPT_OK;                                                                                               \
     }

@@ -99,7 +99,7 @@ class _GrandEulerBlock(torch.autograd.Function):
         dxd_ws = torch.empty(n, c, device=dev, dtype=torch.float32)
         edge_ws = torch.empty(max(graph.num_edges, 1), 2, device=dev, dtype=torch.float32)
         slab = torch.empty(S, slab_floats, device=dev, dtype=torch.float32)
-        d_lp = torch.zeros(L, 2, device=dev, dtype=torch.float32)
+        d_lp = torch.zeros(L, 2, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
         d_x0 = torch.empty(n, c, device=dev, dtype=torch.float32) if need_x0 else None
         check(lib().gadapt_block_backward(graph.c_ref, ptr(x_all), ptr(alpha), ptr(g_top), L,
                                           ptr(a), c * c if S > 1 else 0, ptr(p0), c if S > 1 else 0, ptr(layer_params),

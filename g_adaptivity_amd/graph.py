@@ -62,13 +62,23 @@ class MeshGraph:
                                                  rowptr_s.data_ptr(), col_s.data_ptr(), perm_s.data_ptr(), tpos_s.data_ptr())
         if rc != 0:
             raise _native.NativeError(f"gadapt_csr_build_host failed (code {rc}): edge endpoint outside [0,{n})?")
+        metas = {}
+        for tag, rp in (('t', rowptr_t), ('s', rowptr_s)):
+            for tm in _native.TILE_HEIGHTS:
+                m = torch.empty(4 * ((n + tm - 1) // tm), dtype=torch.int32)
+                if _native.lib().gadapt_tile_meta_host(rp.data_ptr(), n, tm, m.data_ptr()) != 0:
+                    raise _native.NativeError("gadapt_tile_meta_host failed")
+                metas[(tag, tm)] = m.to(self.device)
+        self._metas = metas
         self.edge_index = edge_index                        # as given (original order/device)
         self.rowptr_t, self.col_t, self.eid_t = (t.to(self.device) for t in (rowptr_t, col_t, eid_t))
         self.rowptr_s, self.col_s, self.perm_s, self.tpos_s = (t.to(self.device) for t in (rowptr_s, col_s, perm_s, tpos_s))
         self.max_in_degree = int((rowptr_t[1:] - rowptr_t[:-1]).max())
         self.c_struct = GadaptGraph(n, e, self.rowptr_t.data_ptr(), self.col_t.data_ptr(),
                                     self.rowptr_s.data_ptr(), self.col_s.data_ptr(), self.perm_s.data_ptr(),
-                                    self.tpos_s.data_ptr())
+                                    self.tpos_s.data_ptr(),
+                                    (C.c_void_p * 3)(*[metas[('t', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]),
+                                    (C.c_void_p * 3)(*[metas[('s', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]))
         self.c_ref = C.byref(self.c_struct)
 
     def alpha_to_edge_order(self, alpha_t: torch.Tensor) -> torch.Tensor:

@@ -55,6 +55,11 @@ int gadapt_csr_build_host(const int64_t* src, const int64_t* dst, int64_t n_edge
                           int32_t* rowptr_t, int32_t* col_t, int32_t* eid_t,
                           int32_t* rowptr_s, int32_t* col_s, int32_t* perm_s, int32_t* tpos_s);
 
+/* Per-tile staging metadata for the kernels: for tiles of `tile_rows` consecutive rows of one CSR orientation,
+ * meta[4t+0] = first entry of the tile's slice, [4t+1] = its length, [4t+2] = the longest row, [4t+3] = 0.
+ * The kernels use tile heights 64, 128 and 256 (by hidden size): build all three for both orientations. */
+int gadapt_tile_meta_host(const int32_t* rowptr, int64_t n_nodes, int tile_rows, int32_t* meta_out);
+
 typedef struct gadapt_graph {
     int32_t n_nodes;
     int32_t n_edges;
@@ -64,6 +69,8 @@ typedef struct gadapt_graph {
     const int32_t* col_s;
     const int32_t* perm_s;
     const int32_t* tpos_s;
+    const int32_t* meta_t[3];  /* device: tile metadata of the target CSR for tile heights 64, 128, 256 */
+    const int32_t* meta_s[3];  /* device: same for the source CSR */
 } gadapt_graph;
 
 /* ------------------------------------------------------------------ weights

@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Diagnostic: phase timeline of the two backward kernels from in-kernel s_memtime stamps (-DGADAPT_STAMPS build)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from g_adaptivity_amd import _native, MeshDataset, collate, hot_path_opt, GNN
+handle = C.CDLL(_native.LIB_PATH)
+dev = torch.device('cuda:0')
+n, B, Cc, L = 64, 32, 64, 4
+opt = hot_path_opt(mesh_dims=[n, n], hidden_dim=Cc, num_layers=L, device='cuda:0', show_mesh_evol_plots='False')
+ds = MeshDataset([n, n], B, seed=0); data = collate(ds.samples).to(dev)
+model = GNN(ds, opt).to(dev).train()
+buf = torch.zeros(3 * 1024 * 32, dtype=torch.int64, device=dev)
+for _ in range(2):
+    model.zero_grad(); F.mse_loss(model(data), data.x_phys).backward()
+torch.cuda.synchronize()
+handle.gadapt_debug_set_stamp_buffer(C.c_void_p(buf.data_ptr()))
+model.zero_grad(); F.mse_loss(model(data), data.x_phys).backward()
+torch.cuda.synchronize()
+handle.gadapt_debug_set_stamp_buffer(None)
+allb = buf.cpu().numpy().reshape(3, 1024, 32).astype(np.float64)
+for name, s, names in (('backward_target (last launch = layer 0)', allb[1], ['start', 'staged(b)', 'edge done', 'barrier', 'dA done(b)', 'gemm(b)', 'epilogue', 'end(b)']),
+                       ('backward_source (last launch = layer 1)', allb[2], ['start', 'staged(b)', 'edge done', 'barrier', 'gemm(b)', 'epilogue', 'end(b)', '-'])):
+    print(name)
+    for tile in range(4):
+        seg = s[:, tile * 8:(tile + 1) * 8]
+        ok = seg[:, 1] > 0
+        if not ok.any():
+            continue
+        nst = 8 if 'target' in name else 7
+        line = f"  tile {tile} (n={ok.sum()}):"
+        for k in range(1, nst):
+            d = seg[ok, k] - seg[ok, k - 1]
+            line += f"  {names[k]} {np.median(d):.0f}"
+        line += f"  | total {np.median(seg[ok, nst - 1] - seg[ok, 0]):.0f}"
+        print(line)
