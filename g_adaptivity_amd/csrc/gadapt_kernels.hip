@@ -264,19 +264,78 @@ template <int C, int AUXW> struct TileCsr {
         aux = reinterpret_cast<float*>(col + K::COLN);
         rowptr_g = rowptr_g_; col_g = col_g_; aux_g = aux_g_; meta_g = reinterpret_cast<const int4*>(meta_g_);
     }
-    // Returns the tile's largest row length (block-uniform), or -1 for a slow tile.  Ends with the workgroup barrier.
-    __device__ __forceinline__ int stage(int t, int node0, int n_nodes, int tid) {
-        const int4 m = meta_g[t];
-        ebase = m.x;
-        const int total = m.y;
-        const int cnt = min(total, K::CAP);
-        for (int idx = tid; idx <= K::TM; idx += 256) rp[idx] = rowptr_g[min(node0 + idx, n_nodes)];
-        for (int idx = tid; idx < cnt + GADAPT_MAXD; idx += 256) col[idx] = (idx < cnt) ? col_g[ebase + idx] : node0;
-        if constexpr (AUXW > 0)
-            for (int idx = tid; idx < AUXW * (cnt + GADAPT_MAXD); idx += 256)
-                aux[idx] = (idx < AUXW * cnt) ? aux_g[(size_t)AUXW * ebase + idx] : 0.f;
-        __syncthreads();
-        return (total > K::CAP || m.z > GADAPT_MAXD) ? -1 : m.z;
+    // Staging is split so a kernel can request tile k+1 while it computes tile k: issue() only starts the
+    // loads (results stay in registers), commit() writes them to LDS.  Nothing depends on an earlier load
+    // except the slice position, which comes from the metadata word read one tile ahead.
+    static constexpr int CQ = (K::CAP + GADAPT_MAXD + 255) / 256;
+    struct Regs {
+        int4 meta, meta_next;
+        int rpv, rpv2;
+        int colv[CQ];
+        float auxv[AUXW > 0 ? AUXW * CQ : 1];
+    };
+    __device__ __forceinline__ int4 meta_of(int t, int n_tiles) const { return meta_g[min(t, n_tiles - 1)]; }
+    // `meta` of tile t must already be in r.meta (first tile: load it with meta_of)
+    __device__ __forceinline__ void issue(Regs& r, int t, int t_next, int n_tiles, int node0, int n_nodes, int tid) const {
+        const int eb = r.meta.x;
+        const int cnt = min(r.meta.y, K::CAP);
+        r.meta_next = meta_of(t_next, n_tiles);
+        r.rpv = (tid <= K::TM) ? rowptr_g[min(node0 + tid, n_nodes)] : 0;
+        r.rpv2 = (K::TM >= 256 && 256 + tid <= K::TM) ? rowptr_g[min(node0 + 256 + tid, n_nodes)] : 0;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+            const int idx = q * 256 + tid;
+            r.colv[q] = (idx < cnt) ? col_g[eb + idx] : node0;
+            if constexpr (AUXW > 0) {
+#pragma unroll
+                for (int w = 0; w < AUXW; ++w) {
+                    const int ia = (q * AUXW + w) * 256 + tid;
+                    r.auxv[q * AUXW + w] = (ia < AUXW * cnt) ? aux_g[(size_t)AUXW * eb + ia] : 0.f;
+                }
+            }
+        }
+    }
+    // LDS writes of a previously issued tile; returns its row-length bound (-1: slow tile).  Caller barriers.
+    __device__ __forceinline__ int commit(const Regs& r, int tid) {
+        static_assert(K::TM + 1 <= 512, "rowptr slice: at most 2 entries per thread");
+        ebase = r.meta.x;
+        if (tid <= K::TM) rp[tid] = r.rpv;
+        if (K::TM >= 256 && 256 + tid <= K::TM) rp[256 + tid] = r.rpv2;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+            const int idx = q * 256 + tid;
+            if (idx < K::CAP + GADAPT_MAXD) col[idx] = r.colv[q];
+            if constexpr (AUXW > 0) {
+#pragma unroll
+                for (int w = 0; w < AUXW; ++w) {
+                    const int ia = (q * AUXW + w) * 256 + tid;
+                    if (ia < AUXW * (K::CAP + GADAPT_MAXD)) aux[ia] = r.auxv[q * AUXW + w];
+                }
+            }
+        }
+        return (r.meta.y > K::CAP || r.meta.z > GADAPT_MAXD) ? -1 : r.meta.z;
+    }
+};
+
+// x-tile rows of a tile held in registers between issue and commit (same split as TileCsr)
+template <int C> struct TileRows {
+    using K = Cfg<C>;
+    static constexpr int V = C / 4;
+    static constexpr int XQ = (K::TM * V + 255) / 256;
+    float4 v[XQ];
+    __device__ __forceinline__ void issue(const float* __restrict__ src, int node0, int n_nodes, int tid) {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = q * 256 + tid, r = idx / V, c4 = idx % V;
+            v[q] = (idx < K::TM * V && node0 + r < n_nodes) ? ld_row4<C>(src, node0 + r, c4) : f4zero();
+        }
+    }
+    __device__ __forceinline__ void commit(float* tile, int tid) const {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = q * 256 + tid, r = idx / V, c4 = idx % V;
+            if (idx < K::TM * V) *reinterpret_cast<float4*>(tile + r * K::LD + 4 * c4) = v[q];
+        }
     }
 };
 
@@ -544,13 +603,26 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     };
 
     const TileRange tr = tile_range(p.n_tiles);
+    typename TileCsr<C, 0>::Regs sr;
+    TileRows<C> xr;
+    if (tr.t < tr.t_end) {
+        sr.meta = csr.meta_of(tr.t, p.n_tiles);
+        csr.issue(sr, tr.t, tr.t + tr.step, p.n_tiles, tr.t * K::TM, p.n_nodes, tid);
+        xr.issue(p.x_in, tr.t * K::TM, p.n_nodes, tid);
+    }
     for (int t = tr.t; t < tr.t_end; t += tr.step) {
         const int node0 = t * K::TM;
         const int tslot = ((t - tr.t) / tr.step) * 8;           // stamps of the first 4 tiles of this workgroup
         GADAPT_STAMP(p.stamps, tslot + 0);
         if constexpr (K::MFMA) gemm.load(p.A, p.p0);
-        stage_tile<C>(p.x_in, xs, node0, p.n_nodes, tid);
-        const int dmax = csr.stage(t, node0, p.n_nodes, tid);      // barrier inside
+        xr.commit(xs, tid);
+        const int dmax = csr.commit(sr, tid);
+        __syncthreads();
+        if (t + tr.step < tr.t_end) {                           // request the next tile now: it lands during this one
+            sr.meta = sr.meta_next;
+            csr.issue(sr, t + tr.step, t + 2 * tr.step, p.n_tiles, (t + tr.step) * K::TM, p.n_nodes, tid);
+            xr.issue(p.x_in, (t + tr.step) * K::TM, p.n_nodes, tid);
+        }
         GADAPT_STAMP(p.stamps, tslot + 1);
         if (dmax >= 0) {
             dispatch_dmax(dmax, [&](auto tag) {
@@ -872,6 +944,7 @@ struct BwdTArgs {
     const int32_t* rowptr; const int32_t* col; const int32_t* tpos; const int32_t* meta;
     float2* edge_ws; float* dxd; float* slab; float* sums_out;
     int n_nodes, n_tiles, accumulate, residual_only;
+    unsigned long long* stamps;
 };
 
 // SUMS: also reduce d/d(dt) and d/d(score_scale) (learn_step / learnable temperature).  A separate instantiation:
@@ -1009,10 +1082,26 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
     };
 
     const TileRange tr = tile_range(p.n_tiles);
+    typename TileCsr<C, 1>::Regs sr;
+    TileRows<C> xr;
+    if (tr.t < tr.t_end) {
+        sr.meta = csr.meta_of(tr.t, p.n_tiles);
+        csr.issue(sr, tr.t, tr.t + tr.step, p.n_tiles, tr.t * K::TM, p.n_nodes, tid);
+        xr.issue(p.x_in, tr.t * K::TM, p.n_nodes, tid);
+    }
     for (int t = tr.t; t < tr.t_end; t += tr.step) {
         const int node0 = t * K::TM;
-        stage_tile<C>(p.x_in, xs, node0, p.n_nodes, tid);
-        const int dmax = csr.stage(t, node0, p.n_nodes, tid);      // barrier inside
+        const int tslot = ((t - tr.t) / tr.step) * 8;
+        GADAPT_STAMP(p.stamps, tslot + 0);
+        xr.commit(xs, tid);
+        const int dmax = csr.commit(sr, tid);
+        __syncthreads();
+        if (t + tr.step < tr.t_end) {                           // request the next tile now: it lands during this one
+            sr.meta = sr.meta_next;
+            csr.issue(sr, t + tr.step, t + 2 * tr.step, p.n_tiles, (t + tr.step) * K::TM, p.n_nodes, tid);
+            xr.issue(p.x_in, (t + tr.step) * K::TM, p.n_nodes, tid);
+        }
+        GADAPT_STAMP(p.stamps, tslot + 1);
         // ---- edge phase: dP_i per node -> LDS
         if (dmax >= 0) {
             dispatch_dmax(dmax, [&](auto tag) {
@@ -1025,8 +1114,10 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
 #pragma unroll 1
             for (int it = 0; it < K::ITERS; ++it) slow_node(node0, it);
         }
+        GADAPT_STAMP(p.stamps, tslot + 2);
         if constexpr (K::MFMA) gemm.load(p.A, nullptr);         // in flight under the barrier and the dA pass
         __syncthreads();
+        GADAPT_STAMP(p.stamps, tslot + 3);
         // ---- dA partial:  dA[o][c] += sum_node dP[node][o] x[node][c]
         if constexpr (K::MFMA) {
             const int h = lane >> 5, r31 = lane & 31;
@@ -1063,11 +1154,13 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             }
         }
         __syncthreads();
+        GADAPT_STAMP(p.stamps, tslot + 4);
         // ---- dxd = (base-dt) g + dP A
         if constexpr (K::MFMA) {
             gemm.run(ds, xs);                                   // xs is dead after the dA pass
             __syncthreads();
         }
+        GADAPT_STAMP(p.stamps, tslot + 5);
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) {
             const int li = it * K::SLOTS + slot;
@@ -1089,7 +1182,9 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             r.x = fmaf(w1, gi.x, r.x); r.y = fmaf(w1, gi.y, r.y); r.z = fmaf(w1, gi.z, r.z); r.w = fmaf(w1, gi.w, r.w);
             st_row4<C>(p.dxd, i, sub, r);
         }
+        GADAPT_STAMP(p.stamps, tslot + 6);
         __syncthreads();
+        GADAPT_STAMP(p.stamps, tslot + 7);
     }
 
     // ---- flush partials into this workgroup's slab row (deterministic: one owner per element)
@@ -1164,6 +1259,7 @@ struct BwdSArgs {
     const int32_t* rowptr; const int32_t* col; const int32_t* meta;
     float* g_out;
     int n_nodes, n_tiles;
+    unsigned long long* stamps;
 };
 
 template <int C>
@@ -1235,9 +1331,22 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
     };
 
     const TileRange tr = tile_range(p.n_tiles);
+    typename TileCsr<C, 2>::Regs sr;
+    if (tr.t < tr.t_end) {
+        sr.meta = csr.meta_of(tr.t, p.n_tiles);
+        csr.issue(sr, tr.t, tr.t + tr.step, p.n_tiles, tr.t * K::TM, p.n_nodes, tid);
+    }
     for (int t = tr.t; t < tr.t_end; t += tr.step) {
         const int node0 = t * K::TM;
-        const int dmax = csr.stage(t, node0, p.n_nodes, tid);      // barrier inside
+        const int tslot = ((t - tr.t) / tr.step) * 8;
+        GADAPT_STAMP(p.stamps, tslot + 0);
+        const int dmax = csr.commit(sr, tid);
+        __syncthreads();
+        if (t + tr.step < tr.t_end) {                           // request the next tile now: it lands during this one
+            sr.meta = sr.meta_next;
+            csr.issue(sr, t + tr.step, t + 2 * tr.step, p.n_tiles, (t + tr.step) * K::TM, p.n_nodes, tid);
+        }
+        GADAPT_STAMP(p.stamps, tslot + 1);
         float4 zr[K::ITERS];
         float sg[K::ITERS];
         if (dmax >= 0) {
@@ -1251,12 +1360,15 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
 #pragma unroll
             for (int it = 0; it < K::ITERS; ++it) slow_node(node0, it, zr[it], sg[it]);
         }
+        GADAPT_STAMP(p.stamps, tslot + 2);
         if constexpr (K::MFMA) gemm.load(p.A, nullptr);         // in flight under the barrier
         __syncthreads();
+        GADAPT_STAMP(p.stamps, tslot + 3);
         if constexpr (K::MFMA) {
             gemm.run(ys, os);
             __syncthreads();
         }
+        GADAPT_STAMP(p.stamps, tslot + 4);
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) {
             const int li = it * K::SLOTS + slot;
@@ -1281,7 +1393,9 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
             r.z = (r.z + fmaf(s, p0v.z, z.z)) + d.z; r.w = (r.w + fmaf(s, p0v.w, z.w)) + d.w;
             st_row4<C>(p.g_out, j, sub, r);
         }
+        GADAPT_STAMP(p.stamps, tslot + 5);
         __syncthreads();
+        GADAPT_STAMP(p.stamps, tslot + 6);
     }
 }
 
@@ -1502,7 +1616,10 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     using K = Cfg<C>;
     const int n_tiles = (g->n_nodes + K::TM - 1) / K::TM;
     BwdTArgs pt{x_in, g_in, alpha, a, lp, g->rowptr_t, g->col_t, g->tpos_s, meta_for<K::TM>(g->meta_t), reinterpret_cast<float2*>(edge_ws), dxd, slab, sums_out,
-                g->n_nodes, n_tiles, accumulate, residual_only};
+                g->n_nodes, n_tiles, accumulate, residual_only, nullptr};
+#ifdef GADAPT_STAMPS
+    pt.stamps = g_stamp_buf ? g_stamp_buf + 1024 * 32 : nullptr;
+#endif
     constexpr int lds_t = K::lds_bytes(1), lds_s = K::lds_bytes(2);
     int rc;
     {
@@ -1517,7 +1634,10 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
         rc = check_launch("grand_bwd_target_kernel");
     }
     if (rc || !g_out) return rc;
-    BwdSArgs ps{x_in, g_in, edge_ws, dxd, a, p0, g->rowptr_s, g->col_s, meta_for<K::TM>(g->meta_s), g_out, g->n_nodes, n_tiles};
+    BwdSArgs ps{x_in, g_in, edge_ws, dxd, a, p0, g->rowptr_s, g->col_s, meta_for<K::TM>(g->meta_s), g_out, g->n_nodes, n_tiles, nullptr};
+#ifdef GADAPT_STAMPS
+    ps.stamps = g_stamp_buf ? g_stamp_buf + 2 * 1024 * 32 : nullptr;
+#endif
     allow_lds(grand_bwd_source_kernel<C>, lds_s);
     ProfScope prof(2, st);
     hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds_s, st, ps);
