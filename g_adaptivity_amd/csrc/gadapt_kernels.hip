@@ -25,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GADAPT_MAXD 8           // in/out degree handled from registers; larger rows take the loop path
 // minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
 #ifndef GADAPT_WAVES_FWD
-#define GADAPT_WAVES_FWD 4
+#define GADAPT_WAVES_FWD 3
 #endif
 #ifndef GADAPT_WAVES_BWD_T
 #define GADAPT_WAVES_BWD_T 2
@@ -104,9 +104,11 @@ extern "C" int gadapt_profile_reset(void) {
 // compile-time geometry
 // ------------------------------------------------------------------------------------------------
 template <int C> struct Cfg {
-    static constexpr int LPN = C / 4;                  // lanes per node (float4 each)
-    static constexpr int SLOTS = 256 / LPN;            // nodes in flight per workgroup
     static constexpr bool MFMA = (C >= 32);
+    static constexpr int FPL = MFMA ? 8 : 4;           // floats per lane
+    static constexpr int NV = FPL / 4;                 // float4 chunks per lane
+    static constexpr int LPN = C / FPL;                // lanes per node
+    static constexpr int SLOTS = 256 / LPN;            // nodes in flight per workgroup
     static constexpr int TM = MFMA ? (C == 32 ? 128 : 64) : (SLOTS < 64 ? 64 : SLOTS);
     static constexpr int ITERS = TM / SLOTS;
     static constexpr int LD = C + 4;                   // padded LDS row (floats): conflict-free b128 rows
@@ -377,7 +379,7 @@ template <int V> struct IntTag { static constexpr int value = V; };
 // bound keeps a single buffer: two would cost a wave of occupancy for every tile shape.
 template <int ITERS, typename BufT, typename Fetch, typename Consume, typename Mid>
 __device__ __forceinline__ void run_pipeline(Fetch&& fetch, Consume&& consume, Mid&& before_first) {
-    if constexpr (BufT::N <= 6) {
+    if constexpr (sizeof(BufT) <= 128) {                        // two buffers only while one stays within 32 VGPRs
         BufT b0, b1;
         fetch(b0, 0);
         before_first();
@@ -414,24 +416,6 @@ template <typename F> __device__ __forceinline__ void dispatch_dmax(int dmax, F&
     else f(IntTag<GADAPT_MAXD>{});
 }
 
-// One node's in-edge rows (+ its own gradient row) for the target pass.
-template <int NROWS> struct TBuf {
-    static constexpr int N = NROWS;
-    float4 r[NROWS]; float4 g;
-    int deg, el0;
-};
-// One node's out-edge rows for the source pass: g_i and x_i of every target i.
-template <int NROWS> struct SBuf {
-    static constexpr int N = NROWS;
-    float4 g[NROWS], x[NROWS];
-    int deg, el0;
-};
-// One node's in-edge rows, fetched ahead of use.
-template <int NROWS> struct RowBuf {
-    static constexpr int N = NROWS;
-    float4 r[NROWS];
-    int deg, el0;          // degree (0 for nodes past N; > MAXD flags the slow path), first entry (tile-local)
-};
 
 // In-kernel phase stamps: diagnostic builds only (-DGADAPT_STAMPS); never compiled into the shipped library.
 #ifdef GADAPT_STAMPS
@@ -463,6 +447,51 @@ extern "C" int gadapt_debug_set_stamp_buffer(void* p) { g_stamp_buf = static_cas
 #endif
 
 // ------------------------------------------------------------------------------------------------
+// Per-lane channel vector.  A node's C channels are spread over LPN = C/FPL lanes; a lane owns NV = FPL/4
+// float4 chunks: chunk indices sub, sub+LPN, ... so that the LPN lanes of one load instruction read 16*LPN
+// contiguous bytes of the row.  FPL = 8 for C >= 32: fewer lanes per node means the per-node scalar work
+// (softmax, masks, address arithmetic) and the DPP reduction steps are shared by twice as many nodes per wave.
+// ------------------------------------------------------------------------------------------------
+template <int NV> struct Vec {
+    float4 v[NV];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = f4zero();
+    }
+};
+template <int NV> __device__ __forceinline__ float vdot(const Vec<NV>& a, const Vec<NV>& b) {
+    float s = dot4(a.v[0], b.v[0]);
+#pragma unroll
+    for (int i = 1; i < NV; ++i) s += dot4(a.v[i], b.v[i]);
+    return s;
+}
+template <int NV> __device__ __forceinline__ void vaxpy(Vec<NV>& y, float a, const Vec<NV>& x) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) axpy4(y.v[i], a, x.v[i]);
+}
+template <int C> __device__ __forceinline__ Vec<Cfg<C>::NV> ld_vec(const float* __restrict__ base, int row, int sub) {
+    Vec<Cfg<C>::NV> r;
+#pragma unroll
+    for (int i = 0; i < Cfg<C>::NV; ++i) r.v[i] = ld_row4<C>(base, row, sub + i * Cfg<C>::LPN);
+    return r;
+}
+template <int C> __device__ __forceinline__ void st_vec(float* __restrict__ base, int row, int sub, const Vec<Cfg<C>::NV>& x) {
+#pragma unroll
+    for (int i = 0; i < Cfg<C>::NV; ++i) st_row4<C>(base, row, sub + i * Cfg<C>::LPN, x.v[i]);
+}
+// padded LDS tile [TM][LD]
+template <int C> __device__ __forceinline__ Vec<Cfg<C>::NV> lds_vec(const float* tile, int li, int sub) {
+    Vec<Cfg<C>::NV> r;
+#pragma unroll
+    for (int i = 0; i < Cfg<C>::NV; ++i) r.v[i] = *reinterpret_cast<const float4*>(tile + li * Cfg<C>::LD + 4 * (sub + i * Cfg<C>::LPN));
+    return r;
+}
+template <int C> __device__ __forceinline__ void lds_put(float* tile, int li, int sub, const Vec<Cfg<C>::NV>& x) {
+#pragma unroll
+    for (int i = 0; i < Cfg<C>::NV; ++i) *reinterpret_cast<float4*>(tile + li * Cfg<C>::LD + 4 * (sub + i * Cfg<C>::LPN)) = x.v[i];
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 struct FwdArgs {
@@ -474,9 +503,16 @@ struct FwdArgs {
     unsigned long long* stamps;
 };
 
+template <int NROWS, int NV> struct RowBuf {
+    static constexpr int N = NROWS;
+    Vec<NV> r[NROWS];
+    int deg, el0;
+};
+
 template <int C>
 __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArgs p) {
     using K = Cfg<C>;
+    using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
     float* xs = reinterpret_cast<float*>(smem4);
     float* ps = xs + K::TILE_FLOATS;
@@ -492,6 +528,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     if constexpr (K::MFMA) {
         gemm.init(lane, wave);
     } else {
+        static_assert(K::MFMA || K::NV == 1, "VALU projection assumes one float4 per lane");
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -499,52 +536,56 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
         p0v = *reinterpret_cast<const float4*>(p.p0 + 4 * sub);
     }
 
-    auto projected = [&](int li) {                               // P_i = A x_i + p0 for this lane's 4 channels
-        float4 Pi;
+    auto projected = [&](int li) {                               // P_i = A x_i + p0 for this lane's channels
+        V Pi;
         if constexpr (K::MFMA) {
-            Pi = *reinterpret_cast<const float4*>(ps + li * K::LD + 4 * sub);
+            Pi = lds_vec<C>(ps, li, sub);
         } else {
-            Pi = p0v;
+            Pi.v[0] = p0v;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const float xc = xs[li * K::LD + c];
-                Pi.x = fmaf(arow[0][c], xc, Pi.x); Pi.y = fmaf(arow[1][c], xc, Pi.y);
-                Pi.z = fmaf(arow[2][c], xc, Pi.z); Pi.w = fmaf(arow[3][c], xc, Pi.w);
+                Pi.v[0].x = fmaf(arow[0][c], xc, Pi.v[0].x); Pi.v[0].y = fmaf(arow[1][c], xc, Pi.v[0].y);
+                Pi.v[0].z = fmaf(arow[2][c], xc, Pi.v[0].z); Pi.v[0].w = fmaf(arow[3][c], xc, Pi.v[0].w);
             }
         }
         return Pi;
     };
-    auto finish = [&](int li, int i, const float4& m) {          // res = m - x (GRAND_plus.py:267); x + dt*res (GNN.py:291)
-        const float4 xi = *reinterpret_cast<const float4*>(xs + li * K::LD + 4 * sub);
-        float4 o;
-        o.x = m.x - xi.x; o.y = m.y - xi.y; o.z = m.z - xi.z; o.w = m.w - xi.w;
-        if (!p.residual_only) {
-            o.x = fmaf(dt, o.x, xi.x); o.y = fmaf(dt, o.y, xi.y); o.z = fmaf(dt, o.z, xi.z); o.w = fmaf(dt, o.w, xi.w);
+    auto finish = [&](int li, int i, const V& m) {               // res = m - x (GRAND_plus.py:267); x + dt*res (GNN.py:291)
+        const V xi = lds_vec<C>(xs, li, sub);
+        V o;
+#pragma unroll
+        for (int q = 0; q < K::NV; ++q) {
+            float4 r;
+            r.x = m.v[q].x - xi.v[q].x; r.y = m.v[q].y - xi.v[q].y; r.z = m.v[q].z - xi.v[q].z; r.w = m.v[q].w - xi.v[q].w;
+            if (!p.residual_only) {
+                r.x = fmaf(dt, r.x, xi.v[q].x); r.y = fmaf(dt, r.y, xi.v[q].y); r.z = fmaf(dt, r.z, xi.v[q].z); r.w = fmaf(dt, r.w, xi.v[q].w);
+            }
+            o.v[q] = r;
         }
-        st_row4<C>(p.x_out, i, sub, o);
+        st_vec<C>(p.x_out, i, sub, o);
     };
 
     // Fast path, row length bounded by the compile-time DM: every lane issues exactly DM gathers (slots past
-    // its own row length re-read the row's last neighbour and get weight 0), so there is no divergence.
+    // its own row length read some valid row and get weight 0), so there is no divergence.
     auto fetch = [&](auto& b, int node0, int it) {
         constexpr int DM = std::remove_reference_t<decltype(b)>::N;
         const int li = it * K::SLOTS + slot;
-        const int i = node0 + li;
         b.el0 = csr.rp[li] - csr.ebase;
-        b.deg = (i < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
+        b.deg = (node0 + li < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
 #pragma unroll
-        for (int k = 0; k < DM; ++k) b.r[k] = ld_row4<C>(p.x_in, csr.col[b.el0 + k], sub);   // k >= deg: some valid row, weight 0
+        for (int k = 0; k < DM; ++k) b.r[k] = ld_vec<C>(p.x_in, csr.col[b.el0 + k], sub);
     };
 
     auto consume = [&](const auto& b, int node0, int it) {
         constexpr int DM = std::remove_reference_t<decltype(b)>::N;
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
-        const float4 Pi = projected(li);
+        const V Pi = projected(li);
         const int deg = b.deg;
         float s[DM];
 #pragma unroll
-        for (int k = 0; k < DM; ++k) s[k] = dot4(Pi, b.r[k]);
+        for (int k = 0; k < DM; ++k) s[k] = vdot(Pi, b.r[k]);
         group_sum_n<K::LPN>(s);
         float mx = -INFINITY;
 #pragma unroll
@@ -552,18 +593,19 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
             s[k] = (k < deg) ? s[k] * sc : -INFINITY;
             mx = fmaxf(mx, s[k]);
         }
+        if (deg == 0) mx = 0.f;                                  // keeps exp(-inf - mx) = 0 instead of NaN
         float den = 0.f;
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
-            s[k] = (k < deg) ? __expf(s[k] - mx) : 0.f;         // deg == 0: mx = -inf, nothing is summed
+            s[k] = __expf(s[k] - mx);                            // masked slots: exp(-inf) = 0
             den += s[k];
         }
         const float inv = __builtin_amdgcn_rcpf(den + 1e-16f);  // PyG softmax epsilon
-        float4 m = f4zero();
+        V m; m.zero();
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
             s[k] *= inv;
-            axpy4(m, s[k], b.r[k]);
+            vaxpy(m, s[k], b.r[k]);
         }
         if (p.alpha_out) {
             if constexpr (K::LPN >= DM) {
@@ -583,20 +625,20 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
         if (i >= p.n_nodes) return;
-        const float4 Pi = projected(li);
+        const V Pi = projected(li);
         const int e0 = p.rowptr[i], deg = p.rowptr[i + 1] - e0;
         float mx = -INFINITY;
         for (int k = 0; k < deg; ++k)
-            mx = fmaxf(mx, group_sum<K::LPN>(dot4(Pi, ld_row4<C>(p.x_in, p.col[e0 + k], sub))) * sc);
+            mx = fmaxf(mx, group_sum<K::LPN>(vdot(Pi, ld_vec<C>(p.x_in, p.col[e0 + k], sub))) * sc);
         float den = 0.f;
         for (int k = 0; k < deg; ++k)
-            den += __expf(group_sum<K::LPN>(dot4(Pi, ld_row4<C>(p.x_in, p.col[e0 + k], sub))) * sc - mx);
+            den += __expf(group_sum<K::LPN>(vdot(Pi, ld_vec<C>(p.x_in, p.col[e0 + k], sub))) * sc - mx);
         const float inv = 1.0f / (den + 1e-16f);
-        float4 m = f4zero();
+        V m; m.zero();
         for (int k = 0; k < deg; ++k) {
-            const float4 v = ld_row4<C>(p.x_in, p.col[e0 + k], sub);
-            const float a = __expf(group_sum<K::LPN>(dot4(Pi, v)) * sc - mx) * inv;
-            axpy4(m, a, v);
+            const V v = ld_vec<C>(p.x_in, p.col[e0 + k], sub);
+            const float a = __expf(group_sum<K::LPN>(vdot(Pi, v)) * sc - mx) * inv;
+            vaxpy(m, a, v);
             if (p.alpha_out && (k % K::LPN) == sub) p.alpha_out[e0 + k] = a;
         }
         finish(li, i, m);
@@ -626,9 +668,9 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
         GADAPT_STAMP(p.stamps, tslot + 1);
         if (dmax >= 0) {
             dispatch_dmax(dmax, [&](auto tag) {
-                run_pipeline<K::ITERS, RowBuf<decltype(tag)::value>>(
+                run_pipeline<K::ITERS, RowBuf<decltype(tag)::value, K::NV>>(
                     [&](auto& b, int it) { fetch(b, node0, it); },
-                    [&](const auto& b, int it) { consume(b, node0, it); GADAPT_STAMP(p.stamps, tslot + 3 + it); },
+                    [&](const auto& b, int it) { consume(b, node0, it); GADAPT_STAMP(p.stamps, tslot + 3 + (it & 3)); },
                     [&]() {                                      // neighbour rows are in flight under the MFMA phase
                         if constexpr (K::MFMA) { gemm.run(xs, ps); __syncthreads(); }
                         GADAPT_STAMP(p.stamps, tslot + 2);
@@ -647,294 +689,6 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// forward, matrix-core path (C >= 32): loader wave + compute waves
-//
-// A workgroup is 5 waves.  Waves 0-3 compute: P = x A^T + p0 on the matrix cores (B fragments from L2 in
-// two halves), written IN PLACE over the x tile, then the edge walk.  Wave 4 only moves data: while the
-// compute waves work on tile k it fetches tile k+1 (x rows + the CSR slice) into the other LDS buffer and
-// derives the tile's row-length bound, so HBM latency is hidden behind MFMA/VALU work instead of being
-// serialised with it (measured: staging alone was 18 of 40 us when every wave staged, then computed).
-// LDS tiles are unpadded with 16-byte chunks XOR-swizzled by row (conflict-free for every access below).
-// Raw s_barrier + lgkmcnt(0): the loader's global loads stay in flight across the barriers.
-// ------------------------------------------------------------------------------------------------
-#ifndef GADAPT_WAVES_FWD_MFMA
-#define GADAPT_WAVES_FWD_MFMA 4
-#endif
-template <int C> struct Swz {
-    static constexpr int V = C / 4;
-    static __device__ __forceinline__ int off4(int row, int c4) { return row * C + ((c4 ^ (row & (V - 1))) << 2); }
-    static __device__ __forceinline__ int off(int row, int col) { return off4(row, col >> 2) | (col & 3); }
-};
-__device__ __forceinline__ void wg_barrier() {                 // LDS traffic of this wave done, then rendezvous
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-// LDS image of one tile: x rows (later P rows), rowptr, col, and the row-length bound
-template <int C, int AUXW> struct TileSlot {
-    using K = Cfg<C>;
-    static constexpr int X_FLOATS = K::TM * C;
-    static constexpr int WORDS = X_FLOATS + (K::TM + 4) + K::COLN + AUXW * K::COLN;
-    float* x; int* rp; int* col; float* aux;
-    __device__ __forceinline__ void bind(float* base) {
-        x = base; rp = reinterpret_cast<int*>(base + X_FLOATS); col = rp + (K::TM + 4);
-        aux = reinterpret_cast<float*>(col + K::COLN);
-    }
-    __device__ __forceinline__ int ebase() const { return rp[0]; }
-    __device__ __forceinline__ int dmax() const { return rp[K::TM + 1]; }     // -1: slow tile
-};
-template <int NROWS> struct FBuf {
-    static constexpr int N = NROWS;
-    float4 r[NROWS]; float4 self;
-    int deg, el0;
-};
-
-// Loader wave: global -> registers -> LDS for one tile.  Rows past N are zero.  64 lanes.  Every load of the
-// first chunk is issued BEFORE the compute waves' mid-tile barriers (the loader just arrives at them with the
-// loads in flight); the rest of the x rows follows in chunks of at most 8 float4 per lane.
-template <int C, int AUXW>
-__device__ __forceinline__ void loader_fetch_tile(const float* __restrict__ xsrc, const int32_t* __restrict__ rowptr_g,
-                                                  const int32_t* __restrict__ col_g, const float* __restrict__ aux_g,
-                                                  const int32_t* __restrict__ meta_g, int t, int n_nodes, int lane,
-                                                  const TileSlot<C, AUXW>& dst, int n_mid_barriers) {
-    using K = Cfg<C>;
-    using S = Swz<C>;
-    constexpr int V = C / 4;
-    constexpr int XN = K::TM * V / 64;                          // float4 per lane for the x tile
-    constexpr int XCH = XN < 8 ? XN : 8;
-    constexpr int RN = (K::TM + 1 + 63) / 64;
-    constexpr int CN = K::COLN / 64;
-    const int node0 = t * K::TM;
-    const int4 m = reinterpret_cast<const int4*>(meta_g)[t];
-    const int ebase = m.x, total = m.y;
-    const int cnt = min(total, K::CAP);
-    float4 xv[XCH];
-    int rpv[RN], cv[CN];
-    auto x_load = [&](int c0) {
-#pragma unroll
-        for (int q = 0; q < XCH; ++q) {
-            const int idx = (c0 + q) * 64 + lane, r = idx / V, c4 = idx % V;
-            xv[q] = (node0 + r < n_nodes) ? ld_row4<C>(xsrc, node0 + r, c4) : f4zero();
-        }
-    };
-    auto x_store = [&](int c0) {
-#pragma unroll
-        for (int q = 0; q < XCH; ++q) {
-            const int idx = (c0 + q) * 64 + lane, r = idx / V, c4 = idx % V;
-            *reinterpret_cast<float4*>(dst.x + S::off4(r, c4)) = xv[q];
-        }
-    };
-    x_load(0);
-#pragma unroll
-    for (int q = 0; q < RN; ++q) rpv[q] = rowptr_g[min(node0 + min(q * 64 + lane, K::TM), n_nodes)];
-#pragma unroll
-    for (int q = 0; q < CN; ++q) cv[q] = (q * 64 + lane < cnt) ? col_g[ebase + q * 64 + lane] : node0;   // padding: a valid node
-    for (int b = 0; b < n_mid_barriers; ++b) __builtin_amdgcn_s_barrier();
-    x_store(0);
-#pragma unroll 1
-    for (int c0 = XCH; c0 < XN; c0 += XCH) { x_load(c0); x_store(c0); }
-#pragma unroll
-    for (int q = 0; q < RN; ++q) if (q * 64 + lane <= K::TM) dst.rp[q * 64 + lane] = rpv[q];
-#pragma unroll
-    for (int q = 0; q < CN; ++q) dst.col[q * 64 + lane] = cv[q];
-    if constexpr (AUXW > 0) {
-#pragma unroll 1
-        for (int q = 0; q < AUXW * CN; ++q) {
-            const int idx = q * 64 + lane;
-            dst.aux[idx] = (idx < AUXW * cnt) ? aux_g[(size_t)AUXW * ebase + idx] : 0.f;
-        }
-    }
-    if (lane == 0) dst.rp[K::TM + 1] = (total > K::CAP || m.z > GADAPT_MAXD) ? -1 : m.z;
-}
-
-template <int C>
-__global__ __launch_bounds__(320, GADAPT_WAVES_FWD_MFMA) void grand_fwd_mfma_kernel(FwdArgs p) {
-    using K = Cfg<C>;
-    using S = Swz<C>;
-    static_assert(K::MFMA, "matrix-core path");
-    extern __shared__ float4 smem4[];
-    float* lds = reinterpret_cast<float*>(smem4);
-    auto slot_of = [&](int which) { TileSlot<C, 0> s_; s_.bind(lds + which * TileSlot<C, 0>::WORDS); return s_; };
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const TileRange tr = tile_range(p.n_tiles);
-
-    if (wave == 4) {
-        // ------------------------------------------------------------------ loader wave
-        if (tr.t < tr.t_end) loader_fetch_tile<C, 0>(p.x_in, p.rowptr, p.col, nullptr, p.meta, tr.t, p.n_nodes, lane, slot_of(0), 0);
-        wg_barrier();                                            // first tile staged
-        int cur = 0;
-        for (int t = tr.t; t < tr.t_end; t += tr.step, cur ^= 1) {
-            const int lslot = 16 + ((t - tr.t) / tr.step) * 4;
-            GADAPT_STAMP_L(p.stamps, lslot + 0);
-            if (t + tr.step < tr.t_end)
-                loader_fetch_tile<C, 0>(p.x_in, p.rowptr, p.col, nullptr, p.meta, t + tr.step, p.n_nodes, lane, slot_of(cur ^ 1), 2);
-            else { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
-            GADAPT_STAMP_L(p.stamps, lslot + 1);
-            wg_barrier();                                        // end of tile: next slot is staged
-            GADAPT_STAMP_L(p.stamps, lslot + 2);
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- compute waves
-    const int slot = tid / K::LPN, sub = tid % K::LPN;
-    const int h = lane >> 5, r31 = lane & 31;
-    const float dt = p.lp[0], sc = p.lp[1];
-    constexpr int BPW = (K::CB * K::RB) / 4;                    // 32x32 output blocks per wave
-    const int cb = wave % K::CB, rb0 = wave / K::CB;
-    const int j = cb * 32 + r31;
-
-    auto finish = [&](int i, const float4& xi, const float4& m) {
-        float4 o;                                                // res = m - x (GRAND_plus.py:267); x + dt*res (GNN.py:291)
-        o.x = m.x - xi.x; o.y = m.y - xi.y; o.z = m.z - xi.z; o.w = m.w - xi.w;
-        if (!p.residual_only) {
-            o.x = fmaf(dt, o.x, xi.x); o.y = fmaf(dt, o.y, xi.y); o.z = fmaf(dt, o.z, xi.z); o.w = fmaf(dt, o.w, xi.w);
-        }
-        st_row4<C>(p.x_out, i, sub, o);
-    };
-
-    GADAPT_STAMP(p.stamps, 31);
-#ifdef GADAPT_STAMPS
-    if (p.stamps && threadIdx.x == 0) {
-        unsigned xcc, hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        p.stamps[(size_t)blockIdx.x * 32 + 30] = ((unsigned long long)hwid << 32) | xcc;
-    }
-#endif
-    wg_barrier();                                                // first tile staged
-    int cur = 0;
-    for (int t = tr.t; t < tr.t_end; t += tr.step, cur ^= 1) {
-        const int node0 = t * K::TM;
-        const TileSlot<C, 0> ts = slot_of(cur);
-        float* xs = ts.x;
-        const int tslot = ((t - tr.t) / tr.step) * 8;
-        GADAPT_STAMP(p.stamps, tslot + 0);
-        // ---- P = x A^T + p0 on the matrix cores, B fragments in two halves
-        f32x16 acc[BPW];
-#pragma unroll
-        for (int b = 0; b < BPW; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float bf[C / 4];
-#pragma unroll
-            for (int q = 0; q < C / 16; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(p.A + (size_t)j * C + 8 * (half * (C / 16) + q) + 4 * h);
-                bf[4 * q + 0] = v.x; bf[4 * q + 1] = v.y; bf[4 * q + 2] = v.z; bf[4 * q + 3] = v.w;
-            }
-#pragma unroll
-            for (int b = 0; b < BPW; ++b) {
-                const int row = (rb0 + b * (4 / K::CB)) * 32 + r31;
-#pragma unroll
-                for (int q = 0; q < C / 16; ++q) {
-                    const int qq = half * (C / 16) + q;
-                    const float4 a = *reinterpret_cast<const float4*>(xs + S::off4(row, 2 * qq + h));
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bf[4 * q + 0], acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bf[4 * q + 1], acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bf[4 * q + 2], acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bf[4 * q + 3], acc[b], 0, 0, 0);
-                }
-            }
-        }
-        const float bias = p.p0[j];
-        GADAPT_STAMP(p.stamps, tslot + 1);
-        wg_barrier();                                           // (mid 1) every wave has read its x rows
-#pragma unroll
-        for (int b = 0; b < BPW; ++b) {
-            const int rbase = (rb0 + b * (4 / K::CB)) * 32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-                xs[S::off(row, j)] = acc[b][r] + bias;
-            }
-        }
-        wg_barrier();                                           // (mid 2) P tile complete
-        GADAPT_STAMP(p.stamps, tslot + 2);
-        // ---- edge walk
-        const int ebase = ts.ebase();
-        const int dmax = ts.dmax();
-        if (dmax >= 0) {
-            dispatch_dmax(dmax, [&](auto tag) {
-                constexpr int DM = decltype(tag)::value;
-                auto fetch = [&](FBuf<DM>& b, int it) {
-                    const int li = it * K::SLOTS + slot;
-                    const int i = node0 + li;
-                    const int self = min(i, p.n_nodes - 1);
-                    b.el0 = ts.rp[li] - ebase;
-                    b.deg = (i < p.n_nodes) ? ts.rp[li + 1] - ts.rp[li] : 0;
-                    b.self = ld_row4<C>(p.x_in, self, sub);
-#pragma unroll
-                    for (int k = 0; k < DM; ++k) b.r[k] = ld_row4<C>(p.x_in, ts.col[b.el0 + k], sub);   // k >= deg: valid row, weight 0
-                };
-                auto consume = [&](const FBuf<DM>& b, int it) {
-                    const int li = it * K::SLOTS + slot;
-                    const int i = node0 + li;
-                    const int deg = b.deg;
-                    const float4 Pi = *reinterpret_cast<const float4*>(xs + S::off4(li, sub));
-                    float s[DM];
-#pragma unroll
-                    for (int k = 0; k < DM; ++k) s[k] = dot4(Pi, b.r[k]);
-                    group_sum_n<K::LPN>(s);
-                    float mx = -INFINITY;
-#pragma unroll
-                    for (int k = 0; k < DM; ++k) {
-                        s[k] = (k < deg) ? s[k] * sc : -INFINITY;
-                        mx = fmaxf(mx, s[k]);
-                    }
-                    float den = 0.f;
-#pragma unroll
-                    for (int k = 0; k < DM; ++k) {
-                        s[k] = (k < deg) ? __expf(s[k] - mx) : 0.f;
-                        den += s[k];
-                    }
-                    const float inv = __builtin_amdgcn_rcpf(den + 1e-16f);  // PyG softmax epsilon
-                    float4 m = f4zero();
-#pragma unroll
-                    for (int k = 0; k < DM; ++k) {
-                        s[k] *= inv;
-                        axpy4(m, s[k], b.r[k]);
-                    }
-                    if (p.alpha_out) {
-                        const float mine = pick(s, sub);         // LPN >= 8 >= DM on this path
-                        if (sub < deg) p.alpha_out[ebase + b.el0 + sub] = mine;
-                    }
-                    if (i < p.n_nodes) finish(i, b.self, m);
-                    GADAPT_STAMP(p.stamps, tslot + 3 + (it & 3));
-                };
-                run_pipeline<K::ITERS, FBuf<DM>>(fetch, consume, [&]() {});
-            });
-        } else {
-#pragma unroll 1
-            for (int it = 0; it < K::ITERS; ++it) {              // any row length, CSR straight from HBM
-                const int li = it * K::SLOTS + slot;
-                const int i = node0 + li;
-                if (i >= p.n_nodes) continue;
-                const float4 Pi = *reinterpret_cast<const float4*>(xs + S::off4(li, sub));
-                const int e0 = p.rowptr[i], deg = p.rowptr[i + 1] - e0;
-                float mx = -INFINITY;
-                for (int k = 0; k < deg; ++k)
-                    mx = fmaxf(mx, group_sum<K::LPN>(dot4(Pi, ld_row4<C>(p.x_in, p.col[e0 + k], sub))) * sc);
-                float den = 0.f;
-                for (int k = 0; k < deg; ++k)
-                    den += __expf(group_sum<K::LPN>(dot4(Pi, ld_row4<C>(p.x_in, p.col[e0 + k], sub))) * sc - mx);
-                const float inv = 1.0f / (den + 1e-16f);
-                float4 m = f4zero();
-                for (int k = 0; k < deg; ++k) {
-                    const float4 v = ld_row4<C>(p.x_in, p.col[e0 + k], sub);
-                    const float a = __expf(group_sum<K::LPN>(dot4(Pi, v)) * sc - mx) * inv;
-                    axpy4(m, a, v);
-                    if (p.alpha_out && (k % K::LPN) == sub) p.alpha_out[e0 + k] = a;
-                }
-                finish(i, ld_row4<C>(p.x_in, i, sub), m);
-            }
-        }
-        wg_barrier();                                           // end of tile: this slot may be refilled
-        GADAPT_STAMP(p.stamps, tslot + 7);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // backward, target pass
 // ------------------------------------------------------------------------------------------------
@@ -947,11 +701,18 @@ struct BwdTArgs {
     unsigned long long* stamps;
 };
 
+template <int NROWS, int NV> struct TBuf {
+    static constexpr int N = NROWS;
+    Vec<NV> r[NROWS]; Vec<NV> g;
+    int deg, el0;
+};
+
 // SUMS: also reduce d/d(dt) and d/d(score_scale) (learn_step / learnable temperature).  A separate instantiation:
-// hipcc otherwise sinks the per-edge log terms behind the pipeline and keeps 48 extra registers alive for them.
+// hipcc otherwise sinks the per-edge log terms behind the pipeline and keeps dozens of registers alive for them.
 template <int C, bool SUMS>
 __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kernel(BwdTArgs p) {
     using K = Cfg<C>;
+    using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
     float* xs = reinterpret_cast<float*>(smem4);
     float* ds = xs + K::TILE_FLOATS;                            // dP tile
@@ -987,30 +748,36 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
 #pragma unroll
             for (int r = 0; r < 16; ++r) dacc[b][r] = 0.f;
     }
-    float4 dp0acc = f4zero();
+    V dp0acc; dp0acc.zero();
     float sum_ddt = 0.f, sum_dsc = 0.f;
 
-    auto finish = [&](int li, int i, const float4& gi, const float4& m, const float4& dP) {
+    auto finish = [&](int li, int i, const V& gi, const V& m, const V& dP) {
         if (i < p.n_nodes) {
-            // d dt = sum_i <g_i, m_i - x_i>   (GNN.py:288-289 learn_step); every lane adds its 4 channels
-            const float4 xi = *reinterpret_cast<const float4*>(xs + li * K::LD + 4 * sub);
-            if constexpr (SUMS)
-                sum_ddt += gi.x * (m.x - xi.x) + gi.y * (m.y - xi.y) + gi.z * (m.z - xi.z) + gi.w * (m.w - xi.w);
-            dp0acc.x += dP.x; dp0acc.y += dP.y; dp0acc.z += dP.z; dp0acc.w += dP.w;
+            if constexpr (SUMS) {
+                // d dt = sum_i <g_i, m_i - x_i>   (GNN.py:288-289 learn_step); every lane adds its channels
+                const V xi = lds_vec<C>(xs, li, sub);
+#pragma unroll
+                for (int q = 0; q < K::NV; ++q)
+                    sum_ddt += gi.v[q].x * (m.v[q].x - xi.v[q].x) + gi.v[q].y * (m.v[q].y - xi.v[q].y) +
+                               gi.v[q].z * (m.v[q].z - xi.v[q].z) + gi.v[q].w * (m.v[q].w - xi.v[q].w);
+            }
+#pragma unroll
+            for (int q = 0; q < K::NV; ++q) {
+                dp0acc.v[q].x += dP.v[q].x; dp0acc.v[q].y += dP.v[q].y; dp0acc.v[q].z += dP.v[q].z; dp0acc.v[q].w += dP.v[q].w;
+            }
         }
-        *reinterpret_cast<float4*>(ds + li * K::LD + 4 * sub) = dP;
+        lds_put<C>(ds, li, sub, dP);
     };
 
     auto fetch = [&](auto& b, int node0, int it) {
         constexpr int DM = std::remove_reference_t<decltype(b)>::N;
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
-        const int self = min(i, p.n_nodes - 1);
         b.el0 = csr.rp[li] - csr.ebase;
         b.deg = (i < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
-        b.g = ld_row4<C>(p.g_in, self, sub);
+        b.g = ld_vec<C>(p.g_in, min(i, p.n_nodes - 1), sub);
 #pragma unroll
-        for (int k = 0; k < DM; ++k) b.r[k] = ld_row4<C>(p.x_in, csr.col[b.el0 + k], sub);   // k >= deg: some valid row, weight 0
+        for (int k = 0; k < DM; ++k) b.r[k] = ld_vec<C>(p.x_in, csr.col[b.el0 + k], sub);   // k >= deg: some valid row, weight 0
     };
 
     auto consume = [&](const auto& b, int node0, int it) {
@@ -1018,28 +785,32 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
         const int deg = b.deg, e0 = b.el0;
-        float4 gi = b.g;
-        if (i >= p.n_nodes) gi = f4zero();
-        float4 dm; dm.x = dt * gi.x; dm.y = dt * gi.y; dm.z = dt * gi.z; dm.w = dt * gi.w;
+        V gi = b.g;
+        if (i >= p.n_nodes) gi.zero();
+        V dm;
+#pragma unroll
+        for (int q = 0; q < K::NV; ++q) {
+            dm.v[q].x = dt * gi.v[q].x; dm.v[q].y = dt * gi.v[q].y; dm.v[q].z = dt * gi.v[q].z; dm.v[q].w = dt * gi.v[q].w;
+        }
         float a[DM], da[DM];
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
             const float av = csr.aux[e0 + k];
             a[k] = (k < deg) ? av : 0.f;
-            da[k] = dot4(dm, b.r[k]);
+            da[k] = vdot(dm, b.r[k]);
         }
         group_sum_n<K::LPN>(da);
         float D = 0.f;
 #pragma unroll
         for (int k = 0; k < DM; ++k) D = fmaf(a[k], da[k], D);
-        float4 dP = f4zero(), m = f4zero();
+        V dP, m; dP.zero(); m.zero();
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
             const float dsp = a[k] * (da[k] - D);                   // d(score'), score' = sc * <P_i,x_j>
             da[k] = dsp * sc;                                       // reuse: d<P_i,x_j>
-            axpy4(dP, da[k], b.r[k]);
+            vaxpy(dP, da[k], b.r[k]);
             if constexpr (SUMS) {
-                axpy4(m, a[k], b.r[k]);
+                vaxpy(m, a[k], b.r[k]);
                 if (a[k] > 0.f) sum_dsc = fmaf(dsp, __logf(a[k]), sum_dsc);
             }
         }
@@ -1057,22 +828,26 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
     auto slow_node = [&](int node0, int it) {
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
-        float4 dP = f4zero(), m = f4zero(), gi = f4zero();
+        V dP, m, gi; dP.zero(); m.zero(); gi.zero();
         if (i < p.n_nodes) {
-            gi = ld_row4<C>(p.g_in, i, sub);
-            float4 dm; dm.x = dt * gi.x; dm.y = dt * gi.y; dm.z = dt * gi.z; dm.w = dt * gi.w;
+            gi = ld_vec<C>(p.g_in, i, sub);
+            V dm;
+#pragma unroll
+            for (int q = 0; q < K::NV; ++q) {
+                dm.v[q].x = dt * gi.v[q].x; dm.v[q].y = dt * gi.v[q].y; dm.v[q].z = dt * gi.v[q].z; dm.v[q].w = dt * gi.v[q].w;
+            }
             const int e0 = p.rowptr[i], deg = p.rowptr[i + 1] - e0;
             float D = 0.f;
             for (int k = 0; k < deg; ++k)
-                D = fmaf(p.alpha[e0 + k], group_sum<K::LPN>(dot4(dm, ld_row4<C>(p.x_in, p.col[e0 + k], sub))), D);
+                D = fmaf(p.alpha[e0 + k], group_sum<K::LPN>(vdot(dm, ld_vec<C>(p.x_in, p.col[e0 + k], sub))), D);
             for (int k = 0; k < deg; ++k) {
-                const float4 v = ld_row4<C>(p.x_in, p.col[e0 + k], sub);
+                const V v = ld_vec<C>(p.x_in, p.col[e0 + k], sub);
                 const float ak = p.alpha[e0 + k];
-                const float dsp = ak * (group_sum<K::LPN>(dot4(dm, v)) - D);
+                const float dsp = ak * (group_sum<K::LPN>(vdot(dm, v)) - D);
                 const float dss = dsp * sc;
-                axpy4(dP, dss, v);
+                vaxpy(dP, dss, v);
                 if constexpr (SUMS) {
-                    axpy4(m, ak, v);
+                    vaxpy(m, ak, v);
                     if (ak > 0.f) sum_dsc = fmaf(dsp, __logf(ak), sum_dsc);
                 }
                 if ((k % K::LPN) == sub) p.edge_ws[p.tpos[e0 + k]] = make_float2(ak * dt, dss);
@@ -1105,7 +880,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         // ---- edge phase: dP_i per node -> LDS
         if (dmax >= 0) {
             dispatch_dmax(dmax, [&](auto tag) {
-                run_pipeline<K::ITERS, TBuf<decltype(tag)::value>>(
+                run_pipeline<K::ITERS, TBuf<decltype(tag)::value, K::NV>>(
                     [&](auto& b, int it) { fetch(b, node0, it); },
                     [&](const auto& b, int it) { consume(b, node0, it); },
                     [&]() {});
@@ -1166,21 +941,25 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             const int li = it * K::SLOTS + slot;
             const int i = node0 + li;
             if (i >= p.n_nodes) continue;
-            float4 r;
+            V r;
             if constexpr (K::MFMA) {
-                r = *reinterpret_cast<const float4*>(xs + li * K::LD + 4 * sub);
+                r = lds_vec<C>(xs, li, sub);
             } else {
-                r = f4zero();
+                r.zero();
 #pragma unroll
                 for (int o = 0; o < C; ++o) {
                     const float d = ds[li * K::LD + o];
-                    r.x = fmaf(d, acol[0][o], r.x); r.y = fmaf(d, acol[1][o], r.y);
-                    r.z = fmaf(d, acol[2][o], r.z); r.w = fmaf(d, acol[3][o], r.w);
+                    r.v[0].x = fmaf(d, acol[0][o], r.v[0].x); r.v[0].y = fmaf(d, acol[1][o], r.v[0].y);
+                    r.v[0].z = fmaf(d, acol[2][o], r.v[0].z); r.v[0].w = fmaf(d, acol[3][o], r.v[0].w);
                 }
             }
-            const float4 gi = ld_row4<C>(p.g_in, i, sub);
-            r.x = fmaf(w1, gi.x, r.x); r.y = fmaf(w1, gi.y, r.y); r.z = fmaf(w1, gi.z, r.z); r.w = fmaf(w1, gi.w, r.w);
-            st_row4<C>(p.dxd, i, sub, r);
+            const V gi = ld_vec<C>(p.g_in, i, sub);
+#pragma unroll
+            for (int q = 0; q < K::NV; ++q) {
+                r.v[q].x = fmaf(w1, gi.v[q].x, r.v[q].x); r.v[q].y = fmaf(w1, gi.v[q].y, r.v[q].y);
+                r.v[q].z = fmaf(w1, gi.v[q].z, r.v[q].z); r.v[q].w = fmaf(w1, gi.v[q].w, r.v[q].w);
+            }
+            st_vec<C>(p.dxd, i, sub, r);
         }
         GADAPT_STAMP(p.stamps, tslot + 6);
         __syncthreads();
@@ -1228,22 +1007,28 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         }
         __syncthreads();
     }
-    {   // dp0 and the two scalars: tree over the node slots
-        float* red = xs;                                        // [256][6], spans into the dP tile for small C
-        red[tid * 6 + 0] = dp0acc.x; red[tid * 6 + 1] = dp0acc.y; red[tid * 6 + 2] = dp0acc.z; red[tid * 6 + 3] = dp0acc.w;
-        red[tid * 6 + 4] = sum_ddt;
-        red[tid * 6 + 5] = (sub == 0) ? sum_dsc : 0.f;          // d(score) sums are group-uniform: count once
+    {   // dp0 and the two scalars: tree over the node slots.  Thread (slot, sub) holds channels 4*(sub+q*LPN)+comp.
+        constexpr int W = 4 * K::NV + 2;
+        float* red = xs;                                        // [256][W], spans into the dP tile for small C
+#pragma unroll
+        for (int q = 0; q < K::NV; ++q) {
+            red[tid * W + 4 * q + 0] = dp0acc.v[q].x; red[tid * W + 4 * q + 1] = dp0acc.v[q].y;
+            red[tid * W + 4 * q + 2] = dp0acc.v[q].z; red[tid * W + 4 * q + 3] = dp0acc.v[q].w;
+        }
+        red[tid * W + 4 * K::NV] = sum_ddt;
+        red[tid * W + 4 * K::NV + 1] = (sub == 0) ? sum_dsc : 0.f;   // d(score) sums are group-uniform: count once
         __syncthreads();
         if (tid < C) {
-            const int sb = tid / 4, comp = tid % 4;
+            const int c4 = tid / 4, comp = tid % 4;
+            const int sb = c4 % K::LPN, q = c4 / K::LPN;
             float v = 0.f;
-            for (int s = 0; s < K::SLOTS; ++s) v += red[(s * K::LPN + sb) * 6 + comp];
+            for (int s = 0; s < K::SLOTS; ++s) v += red[(s * K::LPN + sb) * W + 4 * q + comp];
             if (p.accumulate) v += row[C * C + tid];
             row[C * C + tid] = v;
         }
         if (SUMS && p.sums_out && tid < 2) {
             float v = 0.f;
-            for (int s = 0; s < 256; ++s) v += red[s * 6 + 4 + tid];
+            for (int s = 0; s < 256; ++s) v += red[s * W + 4 * K::NV + tid];
             if (tid == 1) v = v / sc;                           // d/d(score_scale) = sum d(score') * <P,x>
             atomicAdd(p.sums_out + tid, v);
         }
@@ -1262,9 +1047,17 @@ struct BwdSArgs {
     unsigned long long* stamps;
 };
 
+// Half of one node's out-edge rows: g_i and x_i of HN targets (two halves cover DM edges)
+template <int HN_, int NV> struct SBuf {
+    static constexpr int N = HN_;
+    Vec<NV> g[HN_], x[HN_];
+    float2 ev[HN_];
+};
+
 template <int C>
 __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kernel(BwdSArgs p) {
     using K = Cfg<C>;
+    using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
     float* ys = reinterpret_cast<float*>(smem4);
     float* os = ys + K::TILE_FLOATS;
@@ -1283,52 +1076,9 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
 #pragma unroll
             for (int c = 0; c < C; ++c) arow[t][c] = p.A[(4 * sub + t) * C + c];
     }
-    const float4 p0v = *reinterpret_cast<const float4*>(p.p0 + 4 * sub);
-
-    auto fetch = [&](auto& b, int node0, int it) {
-        constexpr int DM = std::remove_reference_t<decltype(b)>::N;
-        const int li = it * K::SLOTS + slot;
-        const int j = node0 + li;
-        const int self = min(j, p.n_nodes - 1);
-        b.el0 = csr.rp[li] - csr.ebase;
-        b.deg = (j < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
+    V p0v;
 #pragma unroll
-        for (int k = 0; k < DM; ++k) {
-            const int i = csr.col[b.el0 + k];                    // k >= deg: some valid row, weight 0
-            b.g[k] = ld_row4<C>(p.g_in, i, sub);
-            b.x[k] = ld_row4<C>(p.x_in, i, sub);
-        }
-    };
-    auto consume = [&](const auto& b, int it, float4& z, float& sig) {
-        constexpr int DM = std::remove_reference_t<decltype(b)>::N;
-        const int li = it * K::SLOTS + slot;
-        float4 y = f4zero();
-        z = f4zero(); sig = 0.f;
-#pragma unroll
-        for (int k = 0; k < DM; ++k) {
-            float2 ev = *reinterpret_cast<const float2*>(csr.aux + 2 * (b.el0 + k));
-            if (k >= b.deg) ev = make_float2(0.f, 0.f);
-            axpy4(z, ev.x, b.g[k]); axpy4(y, ev.y, b.x[k]); sig += ev.y;
-        }
-        *reinterpret_cast<float4*>(ys + li * K::LD + 4 * sub) = y;
-    };
-    auto slow_node = [&](int node0, int it, float4& z, float& sig) {
-        const int li = it * K::SLOTS + slot;
-        const int j = node0 + li;
-        float4 y = f4zero();
-        z = f4zero(); sig = 0.f;
-        if (j < p.n_nodes) {
-            const int e0 = p.rowptr[j], deg = p.rowptr[j + 1] - e0;
-            for (int k = 0; k < deg; ++k) {
-                const int i = p.col[e0 + k];
-                const float2 ev = *reinterpret_cast<const float2*>(p.edge_ws + 2 * (size_t)(e0 + k));
-                axpy4(z, ev.x, ld_row4<C>(p.g_in, i, sub));
-                axpy4(y, ev.y, ld_row4<C>(p.x_in, i, sub));
-                sig += ev.y;
-            }
-        }
-        *reinterpret_cast<float4*>(ys + li * K::LD + 4 * sub) = y;
-    };
+    for (int q = 0; q < K::NV; ++q) p0v.v[q] = *reinterpret_cast<const float4*>(p.p0 + 4 * (sub + q * K::LPN));
 
     const TileRange tr = tile_range(p.n_tiles);
     typename TileCsr<C, 2>::Regs sr;
@@ -1347,18 +1097,62 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
             csr.issue(sr, t + tr.step, t + 2 * tr.step, p.n_tiles, (t + tr.step) * K::TM, p.n_nodes, tid);
         }
         GADAPT_STAMP(p.stamps, tslot + 1);
-        float4 zr[K::ITERS];
-        float sg[K::ITERS];
+        V zr[K::ITERS];                                         // sum(alpha dt g_i) + sigma p0, kept across the GEMM
         if (dmax >= 0) {
             dispatch_dmax(dmax, [&](auto tag) {
-                run_pipeline<K::ITERS, SBuf<decltype(tag)::value>>(
-                    [&](auto& b, int it) { fetch(b, node0, it); },
-                    [&](const auto& b, int it) { consume(b, it, zr[it], sg[it]); },
-                    [&]() {});
+                constexpr int DM = decltype(tag)::value;
+                constexpr int HN = (DM + 1) / 2;
+                // pipeline steps = (node slot, half): rows of the next half are requested before this one is summed
+                auto fetch = [&](SBuf<HN, K::NV>& b, int step) {
+                    const int it = step >> 1, half = step & 1;
+                    const int li = it * K::SLOTS + slot;
+                    const int e0 = csr.rp[li] - csr.ebase + half * HN;
+                    const int deg = (node0 + li < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
+#pragma unroll
+                    for (int k = 0; k < HN; ++k) {
+                        const int i = csr.col[e0 + k];               // past the row end: some valid row, weight 0
+                        b.ev[k] = *reinterpret_cast<const float2*>(csr.aux + 2 * (e0 + k));
+                        if (half * HN + k >= deg) b.ev[k] = make_float2(0.f, 0.f);
+                        b.g[k] = ld_vec<C>(p.g_in, i, sub);
+                        b.x[k] = ld_vec<C>(p.x_in, i, sub);
+                    }
+                };
+                V z, y; float sig = 0.f;
+                auto consume = [&](const SBuf<HN, K::NV>& b, int step) {
+                    const int it = step >> 1, half = step & 1;
+                    if (half == 0) { z.zero(); y.zero(); sig = 0.f; }
+#pragma unroll
+                    for (int k = 0; k < HN; ++k) { vaxpy(z, b.ev[k].x, b.g[k]); vaxpy(y, b.ev[k].y, b.x[k]); sig += b.ev[k].y; }
+                    if (half == 1) {
+                        const int li = it * K::SLOTS + slot;
+                        lds_put<C>(ys, li, sub, y);
+                        vaxpy(z, sig, p0v);
+                        zr[it] = z;
+                    }
+                };
+                run_pipeline<2 * K::ITERS, SBuf<HN, K::NV>>(fetch, consume, [&]() {});
             });
         } else {
 #pragma unroll
-            for (int it = 0; it < K::ITERS; ++it) slow_node(node0, it, zr[it], sg[it]);
+            for (int it = 0; it < K::ITERS; ++it) {              // any row length, CSR straight from HBM
+                const int li = it * K::SLOTS + slot;
+                const int j = node0 + li;
+                V z, y; z.zero(); y.zero();
+                float sig = 0.f;
+                if (j < p.n_nodes) {
+                    const int e0 = p.rowptr[j], deg = p.rowptr[j + 1] - e0;
+                    for (int k = 0; k < deg; ++k) {
+                        const int i = p.col[e0 + k];
+                        const float2 ev = *reinterpret_cast<const float2*>(p.edge_ws + 2 * (size_t)(e0 + k));
+                        vaxpy(z, ev.x, ld_vec<C>(p.g_in, i, sub));
+                        vaxpy(y, ev.y, ld_vec<C>(p.x_in, i, sub));
+                        sig += ev.y;
+                    }
+                }
+                lds_put<C>(ys, li, sub, y);
+                vaxpy(z, sig, p0v);
+                zr[it] = z;
+            }
         }
         GADAPT_STAMP(p.stamps, tslot + 2);
         if constexpr (K::MFMA) gemm.load(p.A, nullptr);         // in flight under the barrier
@@ -1374,24 +1168,25 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
             const int li = it * K::SLOTS + slot;
             const int j = node0 + li;
             if (j >= p.n_nodes) continue;
-            float4 r;
+            V r;
             if constexpr (K::MFMA) {
-                r = *reinterpret_cast<const float4*>(os + li * K::LD + 4 * sub);
+                r = lds_vec<C>(os, li, sub);
             } else {
-                r = f4zero();
+                r.zero();
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const float yc = ys[li * K::LD + c];
-                    r.x = fmaf(arow[0][c], yc, r.x); r.y = fmaf(arow[1][c], yc, r.y);
-                    r.z = fmaf(arow[2][c], yc, r.z); r.w = fmaf(arow[3][c], yc, r.w);
+                    r.v[0].x = fmaf(arow[0][c], yc, r.v[0].x); r.v[0].y = fmaf(arow[1][c], yc, r.v[0].y);
+                    r.v[0].z = fmaf(arow[2][c], yc, r.v[0].z); r.v[0].w = fmaf(arow[3][c], yc, r.v[0].w);
                 }
             }
-            const float4 d = ld_row4<C>(p.dxd, j, sub);
-            const float4 z = zr[it];
-            const float s = sg[it];
-            r.x = (r.x + fmaf(s, p0v.x, z.x)) + d.x; r.y = (r.y + fmaf(s, p0v.y, z.y)) + d.y;
-            r.z = (r.z + fmaf(s, p0v.z, z.z)) + d.z; r.w = (r.w + fmaf(s, p0v.w, z.w)) + d.w;
-            st_row4<C>(p.g_out, j, sub, r);
+            const V d = ld_vec<C>(p.dxd, j, sub);
+#pragma unroll
+            for (int q = 0; q < K::NV; ++q) {
+                r.v[q].x = (r.v[q].x + zr[it].v[q].x) + d.v[q].x; r.v[q].y = (r.v[q].y + zr[it].v[q].y) + d.v[q].y;
+                r.v[q].z = (r.v[q].z + zr[it].v[q].z) + d.v[q].z; r.v[q].w = (r.v[q].w + zr[it].v[q].w) + d.v[q].w;
+            }
+            st_vec<C>(p.g_out, j, sub, r);
         }
         GADAPT_STAMP(p.stamps, tslot + 5);
         __syncthreads();
@@ -1575,9 +1370,11 @@ static inline int grid_for(int n_tiles, int max_blocks) {
     if (g < 8) g = 8;
     return g;
 }
-#define GADAPT_FWD_MAX_BLOCKS 1024
-#ifndef GADAPT_FWD_MFMA_MAX_BLOCKS
-#define GADAPT_FWD_MFMA_MAX_BLOCKS 512   /* measured residency of the 5-wave workgroups: 2 per CU x 256 CUs */
+#ifndef GADAPT_FWD_MAX_BLOCKS
+#define GADAPT_FWD_MAX_BLOCKS 768        /* 3 resident workgroups per CU x 256 CUs (A/B on MI355X: 768 > 512 > 1024) */
+#endif
+#ifndef GADAPT_BWD_S_MAX_BLOCKS
+#define GADAPT_BWD_S_MAX_BLOCKS 1024
 #endif
 #define GADAPT_BWD_T_MAX_BLOCKS 512      /* target pass grid = slab row count */
 
@@ -1599,15 +1396,9 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
     p.stamps = g_stamp_buf;
 #endif
     ProfScope prof(0, st);
-    if constexpr (K::MFMA) {
-        constexpr int lds = 2 * TileSlot<C, 0>::WORDS * 4;
-        allow_lds(grand_fwd_mfma_kernel<C>, lds);
-        hipLaunchKernelGGL(grand_fwd_mfma_kernel<C>, dim3(grid_for(p.n_tiles, GADAPT_FWD_MFMA_MAX_BLOCKS)), dim3(320), lds, st, p);
-    } else {
-        constexpr int lds = K::lds_bytes(0);
-        allow_lds(grand_fwd_kernel<C>, lds);
-        hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds, st, p);
-    }
+    constexpr int lds = K::lds_bytes(0);
+    allow_lds(grand_fwd_kernel<C>, lds);
+    hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds, st, p);
     return check_launch("grand_fwd_kernel");
 }
 template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha,
@@ -1640,7 +1431,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
 #endif
     allow_lds(grand_bwd_source_kernel<C>, lds_s);
     ProfScope prof(2, st);
-    hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds_s, st, ps);
+    hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, GADAPT_BWD_S_MAX_BLOCKS)), dim3(256), lds_s, st, ps);
     return check_launch("grand_bwd_source_kernel");
 }
 
@@ -1669,8 +1460,7 @@ extern "C" int gadapt_debug_occupancy(int c, int* out3) {
 #define GADAPT_OCC(CC)                                                                                                  \
     case CC: {                                                                                                          \
         using K = Cfg<CC>;                                                                                              \
-        if constexpr (K::MFMA) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_mfma_kernel<CC>, 320, 2 * TileSlot<CC, 0>::WORDS * 4); \
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_kernel<CC>, 256, K::lds_bytes(0)); \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_kernel<CC>, 256, K::lds_bytes(0)); \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC, false>, 256, K::lds_bytes(1)); \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], grand_bwd_source_kernel<CC>, 256, K::lds_bytes(2)); \
         return GADAPT_OK;                                                                                               \
