@@ -1,0 +1,47 @@
+"""End-to-end: a reference-style training loop on the HIP model tracks the CPU oracle trained with torch.optim.Adam."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from g_adaptivity_amd import GNN, MeshDataset, MeshLoader, collate, hot_path_opt
+from g_adaptivity_amd.optim import FlatAdam
+from helpers import rel_err
+from oracle.pyg_restatement import OracleGNN
+
+
+@pytest.mark.gpu
+def test_training_steps_track_the_oracle(gpu_device):
+    opt = hot_path_opt(mesh_dims=[12, 12], hidden_dim=64, num_layers=3, lr=1e-3, decay=1e-4, batch_size=4)
+    ds = MeshDataset([12, 12], 16, seed=0)
+    torch.manual_seed(0)
+    oracle = OracleGNN(ds, dict(opt)).train()
+    o = dict(opt); o['device'] = str(gpu_device)
+    model = GNN(ds, o).to(gpu_device).train()
+    model.load_state_dict(copy.deepcopy(oracle.state_dict()))
+    opt_ref = torch.optim.Adam(oracle.parameters(), lr=opt['lr'], weight_decay=opt['decay'])
+    opt_hip = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'])
+    losses_ref, losses_hip = [], []
+    for epoch in range(2):
+        for data in MeshLoader(ds, batch_size=4, shuffle=False):
+            opt_ref.zero_grad()
+            l = F.mse_loss(oracle(data), data.x_phys); l.backward(); opt_ref.step(); losses_ref.append(l.item())
+            opt_hip.zero_grad()
+            d = data.clone().to(gpu_device)
+            l2 = F.mse_loss(model(d), d.x_phys); l2.backward(); opt_hip.step(); losses_hip.append(l2.item())
+    assert losses_ref[-1] < losses_ref[0]                              # it trains
+    for a, b in zip(losses_hip, losses_ref):
+        assert abs(a - b) <= 1e-4 * abs(b)
+    lo, lh = oracle.conv_layers[0], model.conv_layers[0]
+    # Adam turns gradient rounding into O(lr) parameter differences only where a gradient is ~0; compare the update
+    for name in ('lin_query.weight', 'lin_key.weight', 'lin_query.bias'):
+        w_ref, w_hip = dict(lo.named_parameters())[name], dict(lh.named_parameters())[name]
+        assert (w_hip.detach().cpu() - w_ref.detach()).abs().max().item() <= 2e-3 * 8 * opt['lr'] + 1e-6
+    assert torch.equal(lh.lin_skip.weight.cpu(), lo.lin_skip.weight)   # never receives a gradient: untouched (also by weight decay)
+    # eval-mode forward: same result, end_MLmodel stamped after a stream sync
+    model.eval()
+    data = collate(ds.samples[:2])
+    with torch.no_grad():
+        out = model(data.clone().to(gpu_device))
+    assert model.end_MLmodel is not None and rel_err(out, oracle.eval()(data))[0] <= 1e-4
