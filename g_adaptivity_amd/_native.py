@@ -32,7 +32,7 @@ PROTOTYPES = {
     'gadapt_last_error': (C.c_char_p, []),
     'gadapt_abi_version': (_I, []),
     'gadapt_csr_build_host': (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P]),
-    'gadapt_tile_meta_host': (_I, [_P, _L, _I, _P]),
+    'gadapt_tile_meta_host': (_I, [_P, _P, _L, _I, _P]),
     'gadapt_coeffs_forward': (_I, [_P, _P, _P, _P, _P, _I, _P]),
     'gadapt_coeffs_backward': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'gadapt_encode_linear': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),

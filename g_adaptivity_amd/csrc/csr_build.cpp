@@ -42,17 +42,22 @@ extern "C" int gadapt_csr_build_host(const int64_t* src, const int64_t* dst, int
 }
 
 // Per-tile staging metadata (see include/gadapt_hip.h): 4 ints per tile of `tile_rows` consecutive rows.
-extern "C" int gadapt_tile_meta_host(const int32_t* rowptr, int64_t n_nodes, int tile_rows, int32_t* meta_out) {
-    if (!rowptr || !meta_out || n_nodes <= 0 || tile_rows <= 0) return GADAPT_E_BADARG;
+extern "C" int gadapt_tile_meta_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int tile_rows, int32_t* meta_out) {
+    if (!rowptr || !col || !meta_out || n_nodes <= 0 || tile_rows <= 0) return GADAPT_E_BADARG;
     const int64_t n_tiles = (n_nodes + tile_rows - 1) / tile_rows;
     for (int64_t t = 0; t < n_tiles; ++t) {
         const int64_t lo = t * tile_rows, hi = (lo + tile_rows < n_nodes) ? lo + tile_rows : n_nodes;
         int32_t longest = 0;
         for (int64_t i = lo; i < hi; ++i) { const int32_t d = rowptr[i + 1] - rowptr[i]; if (d > longest) longest = d; }
+        // windowed: every neighbour of the tile's rows lies in the slabs t-1, t, t+1
+        const int64_t wlo = (t - 1) * tile_rows, whi = (t + 2) * tile_rows;
+        int32_t windowed = 1;
+        for (int32_t e = rowptr[lo]; e < rowptr[hi]; ++e)
+            if (col[e] < wlo || col[e] >= whi) { windowed = 0; break; }
         meta_out[4 * t + 0] = rowptr[lo];
         meta_out[4 * t + 1] = rowptr[hi] - rowptr[lo];
         meta_out[4 * t + 2] = longest;
-        meta_out[4 * t + 3] = 0;
+        meta_out[4 * t + 3] = windowed;
     }
     return GADAPT_OK;
 }

@@ -25,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GADAPT_MAXD 8           // in/out degree handled from registers; larger rows take the loop path
 // minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
 #ifndef GADAPT_WAVES_FWD
-#define GADAPT_WAVES_FWD 3
+#define GADAPT_WAVES_FWD 2
 #endif
 #ifndef GADAPT_WAVES_BWD_T
 #define GADAPT_WAVES_BWD_T 2
@@ -118,8 +118,10 @@ template <int C> struct Cfg {
     static constexpr int CAP = 7 * TM;                 // CSR entries of one tile staged in LDS (rest read from HBM)
     static constexpr int COLN = CAP + 64;              // + padding: reads up to MAXD past a row's end stay in
                                                        //   bounds and return a valid node id (weight 0)
-    // LDS: two [TM][LD] tiles, rowptr[TM+1] (padded to TM+4), col[COLN], aux[AUXW*COLN]
-    static constexpr int lds_bytes(int auxw) { return (2 * TILE_FLOATS + (TM + 4) + COLN + auxw * COLN) * 4; }
+    // LDS: `tiles` [TM][LD] tiles, rowptr[TM+1] (padded to TM+4), col[COLN], aux[AUXW*COLN]
+    static constexpr int MAXM = 64;                    // tile-metadata words of this workgroup's tiles kept in LDS
+    static constexpr int lds_bytes(int auxw, int tiles = 2) { return (tiles * TILE_FLOATS + (TM + 4) + COLN + auxw * COLN + 4 * MAXM) * 4; }
+    static constexpr int RING = 3;                     // LDS slabs of x rows kept by the rolling-window kernels
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -166,6 +168,19 @@ __device__ __forceinline__ TileRange tile_range(int n_tiles) {
     const int t0 = xcd * per;
     const int t1 = min(n_tiles, t0 + per);
     return {t0 + bi, t1, gx};
+}
+
+// Contiguous tiles [t0, t1) for this workgroup (rolling-window kernels): XCD group x walks the x-th eighth of the
+// tiles, split evenly between that group's workgroups.
+struct TileChunk { int t0, t1; };
+__device__ __forceinline__ TileChunk tile_chunk(int n_tiles) {
+    const int gx = gridDim.x >> 3, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int per = (n_tiles + 7) >> 3;
+    const int x0 = xcd * per, x1 = min(n_tiles, x0 + per);
+    if (x1 <= x0) return {0, 0};
+    const int pw = (x1 - x0 + gx - 1) / gx;
+    const int t0 = x0 + bi * pw;
+    return {min(t0, x1), min(x1, t0 + pw)};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -255,50 +270,73 @@ template <int C> __device__ __forceinline__ void stage_tile(const float* __restr
 // the whole workgroup walks the HBM copy with plain loops instead.
 template <int C, int AUXW> struct TileCsr {
     using K = Cfg<C>;
-    int* rp; int* col; float* aux;
+    int* rp; int* col; float* aux; int4* metas;
     const int32_t* rowptr_g; const int32_t* col_g; const float* aux_g; const int4* meta_g;
-    int ebase;
+    int ebase, n_edges_m1, m_first, m_step, m_ntiles;
 
     __device__ __forceinline__ void bind(float* lds_after_tiles, const int32_t* rowptr_g_, const int32_t* col_g_, const float* aux_g_,
-                                         const int32_t* meta_g_) {
+                                         const int32_t* meta_g_, int n_edges) {
+        n_edges_m1 = max(n_edges - 1, 0);
         rp = reinterpret_cast<int*>(lds_after_tiles);
         col = rp + (K::TM + 4);
         aux = reinterpret_cast<float*>(col + K::COLN);
+        metas = reinterpret_cast<int4*>(aux + AUXW * K::COLN);
         rowptr_g = rowptr_g_; col_g = col_g_; aux_g = aux_g_; meta_g = reinterpret_cast<const int4*>(meta_g_);
     }
+    // Metadata of this workgroup's tiles first, first+step, ... -> LDS, once per launch.  Read per tile with
+    // meta_at(k): a per-tile global load would be moved to SGPRs by hipcc (v_readfirstlane) and its s_waitcnt,
+    // vmcnt being in-order, would also wait for every older load - the GEMM's B fragments.  Caller barriers.
+    __device__ __forceinline__ void load_metas(int first, int step, int n_tiles, int tid) {
+        m_first = first; m_step = step; m_ntiles = n_tiles;
+        if (tid < K::MAXM) metas[tid] = meta_g[min(first + tid * step, n_tiles - 1)];
+    }
+    // pure LDS read (the launch grid guarantees at most MAXM tiles per workgroup): a global-load fallback here,
+    // even on a never-taken branch, makes hipcc wait vmcnt(0) at the join in every tile
+    __device__ __forceinline__ int4 meta_at(int k) const { return metas[min(k, K::MAXM - 1)]; }
     // Staging is split so a kernel can request tile k+1 while it computes tile k: issue() only starts the
     // loads (results stay in registers), commit() writes them to LDS.  Nothing depends on an earlier load
     // except the slice position, which comes from the metadata word read one tile ahead.
     static constexpr int CQ = (K::CAP + GADAPT_MAXD + 255) / 256;
     struct Regs {
-        int4 meta, meta_next;
+        int4 meta;
         int rpv, rpv2;
         int colv[CQ];
         float auxv[AUXW > 0 ? AUXW * CQ : 1];
     };
-    __device__ __forceinline__ int4 meta_of(int t, int n_tiles) const { return meta_g[min(t, n_tiles - 1)]; }
-    // `meta` of tile t must already be in r.meta (first tile: load it with meta_of)
-    __device__ __forceinline__ void issue(Regs& r, int t, int t_next, int n_tiles, int node0, int n_nodes, int tid) const {
+    // Every load here is
+    // UNCONDITIONAL with a clamped address (validity is applied in commit): a load under a branch or an exec mask
+    // makes hipcc assume the worst at the join and emit s_waitcnt vmcnt(small) later, which drains the whole
+    // prefetch right where the B fragments of the GEMM are waited for (vmcnt is in-order).
+    // k = index of the tile within this workgroup's sequence (see load_metas)
+    __device__ __forceinline__ void issue(Regs& r, int k, int node0, int n_nodes, int tid) const {
+        r.meta = meta_at(k);
         const int eb = r.meta.x;
-        const int cnt = min(r.meta.y, K::CAP);
-        r.meta_next = meta_of(t_next, n_tiles);
-        r.rpv = (tid <= K::TM) ? rowptr_g[min(node0 + tid, n_nodes)] : 0;
-        r.rpv2 = (K::TM >= 256 && 256 + tid <= K::TM) ? rowptr_g[min(node0 + 256 + tid, n_nodes)] : 0;
+        r.rpv = rowptr_g[min(min(node0, n_nodes) + min(tid, K::TM), n_nodes)];
+        r.rpv2 = (K::TM >= 256) ? rowptr_g[min(min(node0, n_nodes) + min(256 + tid, K::TM), n_nodes)] : 0;
 #pragma unroll
         for (int q = 0; q < CQ; ++q) {
             const int idx = q * 256 + tid;
-            r.colv[q] = (idx < cnt) ? col_g[eb + idx] : node0;
+            r.colv[q] = col_g[min(eb + idx, n_edges_m1)];
             if constexpr (AUXW > 0) {
 #pragma unroll
                 for (int w = 0; w < AUXW; ++w) {
                     const int ia = (q * AUXW + w) * 256 + tid;
-                    r.auxv[q * AUXW + w] = (ia < AUXW * cnt) ? aux_g[(size_t)AUXW * eb + ia] : 0.f;
+                    r.auxv[q * AUXW + w] = aux_g[min((size_t)AUXW * eb + ia, (size_t)AUXW * n_edges_m1 + (AUXW - 1))];
                 }
             }
         }
     }
+    // Float offset, inside a RING-slab LDS ring, of the row of node j when slabs t-1, t, t+1 are resident
+    // (slab s lives in slot s % RING).
+    static __device__ __forceinline__ int ring_off(int j, int t) {
+        int slot = (t + K::RING - 1) % K::RING + (j / K::TM - (t - 1));
+        if (slot >= K::RING) slot -= K::RING;
+        return slot * K::TILE_FLOATS + (j % K::TM) * K::LD;
+    }
     // LDS writes of a previously issued tile; returns its row-length bound (-1: slow tile).  Caller barriers.
-    __device__ __forceinline__ int commit(const Regs& r, int tid) {
+    // windowed_tile >= 0: the tile's neighbours all live in slabs t-1..t+1 (metadata word 3): store ring offsets
+    // instead of node ids so the gathers read LDS directly.
+    __device__ __forceinline__ int commit(const Regs& r, int tid, int node0_pad, int windowed_tile = -1) {
         static_assert(K::TM + 1 <= 512, "rowptr slice: at most 2 entries per thread");
         ebase = r.meta.x;
         if (tid <= K::TM) rp[tid] = r.rpv;
@@ -306,12 +344,14 @@ template <int C, int AUXW> struct TileCsr {
 #pragma unroll
         for (int q = 0; q < CQ; ++q) {
             const int idx = q * 256 + tid;
-            if (idx < K::CAP + GADAPT_MAXD) col[idx] = r.colv[q];
+            const int cnt = min(r.meta.y, K::CAP);
+            const int jv = (idx < cnt) ? r.colv[q] : node0_pad;       // padding entries: a valid node of this tile
+            if (idx < K::CAP + GADAPT_MAXD) col[idx] = (windowed_tile >= 0) ? ring_off(jv, windowed_tile) : jv;
             if constexpr (AUXW > 0) {
 #pragma unroll
                 for (int w = 0; w < AUXW; ++w) {
                     const int ia = (q * AUXW + w) * 256 + tid;
-                    if (ia < AUXW * (K::CAP + GADAPT_MAXD)) aux[ia] = r.auxv[q * AUXW + w];
+                    if (ia < AUXW * (K::CAP + GADAPT_MAXD)) aux[ia] = (ia < AUXW * cnt) ? r.auxv[q * AUXW + w] : 0.f;
                 }
             }
         }
@@ -325,18 +365,22 @@ template <int C> struct TileRows {
     static constexpr int V = C / 4;
     static constexpr int XQ = (K::TM * V + 255) / 256;
     float4 v[XQ];
+    int node0_;
+    // unconditional clamped loads (see TileCsr::issue); rows past N are zeroed at commit
     __device__ __forceinline__ void issue(const float* __restrict__ src, int node0, int n_nodes, int tid) {
+        node0_ = node0;
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
-            const int idx = q * 256 + tid, r = idx / V, c4 = idx % V;
-            v[q] = (idx < K::TM * V && node0 + r < n_nodes) ? ld_row4<C>(src, node0 + r, c4) : f4zero();
+            const int idx = min(q * 256 + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
+            v[q] = ld_row4<C>(src, min(max(node0 + r, 0), n_nodes - 1), c4);
         }
     }
-    __device__ __forceinline__ void commit(float* tile, int tid) const {
+    __device__ __forceinline__ void commit(float* tile, int n_nodes, int tid) const {
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
             const int idx = q * 256 + tid, r = idx / V, c4 = idx % V;
-            if (idx < K::TM * V) *reinterpret_cast<float4*>(tile + r * K::LD + 4 * c4) = v[q];
+            if (idx < K::TM * V)
+                *reinterpret_cast<float4*>(tile + r * K::LD + 4 * c4) = (node0_ + r < n_nodes && node0_ + r >= 0) ? v[q] : f4zero();
         }
     }
 };
@@ -499,7 +543,7 @@ struct FwdArgs {
     const float* A; const float* p0; const float* lp;
     const int32_t* rowptr; const int32_t* col; const int32_t* meta;
     float* alpha_out;
-    int n_nodes, n_tiles, residual_only;
+    int n_nodes, n_tiles, residual_only, n_edges;
     unsigned long long* stamps;
 };
 
@@ -514,13 +558,15 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     using K = Cfg<C>;
     using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
-    float* xs = reinterpret_cast<float*>(smem4);
-    float* ps = xs + K::TILE_FLOATS;
+    float* ring = reinterpret_cast<float*>(smem4);               // RING slabs of x rows: slab s in slot s % RING
+    float* ps = ring + K::RING * K::TILE_FLOATS;
     TileCsr<C, 0> csr;
-    csr.bind(ps + K::TILE_FLOATS, p.rowptr, p.col, nullptr, p.meta);
+    csr.bind(ps + K::TILE_FLOATS, p.rowptr, p.col, nullptr, p.meta, p.n_edges);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
     const float dt = p.lp[0], sc = p.lp[1];
+    float* xs = ring;                                            // slab of the current tile (set per tile)
+    bool win = false;                                            // current tile gathers from the LDS ring
 
     TileGemm<C, false> gemm;
     float arow[K::MFMA ? 1 : 4][K::MFMA ? 1 : C];
@@ -568,13 +614,26 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
 
     // Fast path, row length bounded by the compile-time DM: every lane issues exactly DM gathers (slots past
     // its own row length read some valid row and get weight 0), so there is no divergence.
-    auto fetch = [&](auto& b, int node0, int it) {
+    // WIN (compile time): the tile gathers from the LDS ring (col holds ring offsets) or from HBM/L2.  The two
+    // variants must not share a join point: a pending-global-load possibility on one side makes hipcc put
+    // s_waitcnt vmcnt(0) in front of every use of the rows on the other side too.
+    auto fetch = [&](auto& b, int node0, int it, auto win_tag) {
         constexpr int DM = std::remove_reference_t<decltype(b)>::N;
+        constexpr bool WIN = decltype(win_tag)::value != 0;
         const int li = it * K::SLOTS + slot;
         b.el0 = csr.rp[li] - csr.ebase;
         b.deg = (node0 + li < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
+        if constexpr (WIN) {
 #pragma unroll
-        for (int k = 0; k < DM; ++k) b.r[k] = ld_vec<C>(p.x_in, csr.col[b.el0 + k], sub);
+            for (int k = 0; k < DM; ++k) {
+                const float* row = ring + csr.col[b.el0 + k];
+#pragma unroll
+                for (int q = 0; q < K::NV; ++q) b.r[k].v[q] = *reinterpret_cast<const float4*>(row + 4 * (sub + q * K::LPN));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < DM; ++k) b.r[k] = ld_vec<C>(p.x_in, csr.col[b.el0 + k], sub);
+        }
     };
 
     auto consume = [&](const auto& b, int node0, int it) {
@@ -644,48 +703,65 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
         finish(li, i, m);
     };
 
-    const TileRange tr = tile_range(p.n_tiles);
-    typename TileCsr<C, 0>::Regs sr;
-    TileRows<C> xr;
-    if (tr.t < tr.t_end) {
-        sr.meta = csr.meta_of(tr.t, p.n_tiles);
-        csr.issue(sr, tr.t, tr.t + tr.step, p.n_tiles, tr.t * K::TM, p.n_nodes, tid);
-        xr.issue(p.x_in, tr.t * K::TM, p.n_nodes, tid);
-    }
-    for (int t = tr.t; t < tr.t_end; t += tr.step) {
+    // ---- rolling window: this workgroup walks the consecutive tiles [t0, t1); when it works on tile t the slabs
+    //      t-1, t, t+1 of x are resident in the ring (one new slab per tile, requested one tile ahead)
+    const TileChunk ch = tile_chunk(p.n_tiles);
+    if (ch.t0 >= ch.t1) return;
+    auto slab_ptr = [&](int s_) { return ring + ((s_ + K::RING) % K::RING) * K::TILE_FLOATS; };
+    // Staging runs TWO tiles ahead (two register sets, used alternately): every workgroup of the launch requests
+    // its next slab at the same moment, so one tile of compute does not cover that burst.
+    typename TileCsr<C, 0>::Regs srA, srB;
+    TileRows<C> xrA, xrB;
+    if constexpr (K::MFMA) gemm.load(p.A, p.p0);                 // B fragments stay in registers for the whole launch
+    csr.load_metas(ch.t0, 1, p.n_tiles, tid);
+    xrA.issue(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
+    xrA.issue(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0), p.n_nodes, tid);
+    __syncthreads();                                             // tile metadata visible
+    xrA.issue(p.x_in, (ch.t0 + 1) * K::TM, p.n_nodes, tid);      // rows past N come back as zeros
+    csr.issue(srA, 0, ch.t0 * K::TM, p.n_nodes, tid);
+    xrB.issue(p.x_in, (ch.t0 + 2) * K::TM, p.n_nodes, tid);
+    csr.issue(srB, 1, (ch.t0 + 1) * K::TM, p.n_nodes, tid);
+
+    // Order inside a tile: GEMM first (its A operand, slab t, was committed during tile t-1; B fragments are
+    // resident), THEN commit the prefetched slab t+1 / CSR slice of tile t.  vmcnt is in-order and hipcc waits
+    // conservatively (vmcnt(0)) before the commit reads the prefetch registers, so anything still in flight -
+    // the previous tile's output stores included - is paid for there: behind the MFMA phase it is (mostly) free.
+    auto do_tile = [&](int t, TileRows<C>& xr, typename TileCsr<C, 0>::Regs& sr) {
         const int node0 = t * K::TM;
-        const int tslot = ((t - tr.t) / tr.step) * 8;           // stamps of the first 4 tiles of this workgroup
+        const int tslot = (t - ch.t0) * 8;                      // stamps of the first 4 tiles of this workgroup
         GADAPT_STAMP(p.stamps, tslot + 0);
-        if constexpr (K::MFMA) gemm.load(p.A, p.p0);
-        xr.commit(xs, tid);
-        const int dmax = csr.commit(sr, tid);
-        __syncthreads();
-        if (t + tr.step < tr.t_end) {                           // request the next tile now: it lands during this one
-            sr.meta = sr.meta_next;
-            csr.issue(sr, t + tr.step, t + 2 * tr.step, p.n_tiles, (t + tr.step) * K::TM, p.n_nodes, tid);
-            xr.issue(p.x_in, (t + tr.step) * K::TM, p.n_nodes, tid);
-        }
+        xs = slab_ptr(t);
+        if constexpr (K::MFMA) gemm.run(xs, ps);
         GADAPT_STAMP(p.stamps, tslot + 1);
+        win = sr.meta.w != 0;
+        xr.commit(slab_ptr(t + 1), p.n_nodes, tid);
+        const int dmax = csr.commit(sr, tid, node0, win ? t : -1);
+        __syncthreads();                                        // P tile, slab t+1 and the CSR slice are complete
+        {   // this register set's next job: tile t+2 (slab t+3).  Unconditional (clamped past the chunk end): see issue()
+            csr.issue(sr, t + 2 - ch.t0, (t + 2) * K::TM, p.n_nodes, tid);
+            xr.issue(p.x_in, (t + 3) * K::TM, p.n_nodes, tid);
+        }
+        GADAPT_STAMP(p.stamps, tslot + 2);
         if (dmax >= 0) {
             dispatch_dmax(dmax, [&](auto tag) {
-                run_pipeline<K::ITERS, RowBuf<decltype(tag)::value, K::NV>>(
-                    [&](auto& b, int it) { fetch(b, node0, it); },
-                    [&](const auto& b, int it) { consume(b, node0, it); GADAPT_STAMP(p.stamps, tslot + 3 + (it & 3)); },
-                    [&]() {                                      // neighbour rows are in flight under the MFMA phase
-                        if constexpr (K::MFMA) { gemm.run(xs, ps); __syncthreads(); }
-                        GADAPT_STAMP(p.stamps, tslot + 2);
-                    });
+                auto walk = [&](auto win_tag) {
+                    run_pipeline<K::ITERS, RowBuf<decltype(tag)::value, K::NV>>(
+                        [&](auto& b, int it) { fetch(b, node0, it, win_tag); },
+                        [&](const auto& b, int it) { consume(b, node0, it); GADAPT_STAMP(p.stamps, tslot + 3 + (it & 3)); },
+                        [&]() {});
+                };
+                if (win) walk(IntTag<1>{}); else walk(IntTag<0>{});
             });
         } else {
-            if constexpr (K::MFMA) {
-                gemm.run(xs, ps);
-                __syncthreads();
-            }
 #pragma unroll 1
             for (int it = 0; it < K::ITERS; ++it) slow_node(node0, it);
         }
-        __syncthreads();
+        __syncthreads();                                        // edge walk done: P tile and ring slot t-1 may be rewritten
         GADAPT_STAMP(p.stamps, tslot + 7);
+    };
+    for (int t = ch.t0; t < ch.t1; t += 2) {
+        do_tile(t, xrA, srA);
+        if (t + 1 < ch.t1) do_tile(t + 1, xrB, srB);
     }
 }
 
@@ -697,7 +773,7 @@ struct BwdTArgs {
     const float* A; const float* lp;
     const int32_t* rowptr; const int32_t* col; const int32_t* tpos; const int32_t* meta;
     float2* edge_ws; float* dxd; float* slab; float* sums_out;
-    int n_nodes, n_tiles, accumulate, residual_only;
+    int n_nodes, n_tiles, accumulate, residual_only, n_edges;
     unsigned long long* stamps;
 };
 
@@ -717,7 +793,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
     float* xs = reinterpret_cast<float*>(smem4);
     float* ds = xs + K::TILE_FLOATS;                            // dP tile
     TileCsr<C, 1> csr;                                          // aux = forward alpha (target order)
-    csr.bind(ds + K::TILE_FLOATS, p.rowptr, p.col, p.alpha, p.meta);
+    csr.bind(ds + K::TILE_FLOATS, p.rowptr, p.col, p.alpha, p.meta, p.n_edges);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
     // out = base*x + dt*(m - x): Euler step (base 1) or bare residual (base 0, dt 1)
@@ -859,21 +935,22 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
     const TileRange tr = tile_range(p.n_tiles);
     typename TileCsr<C, 1>::Regs sr;
     TileRows<C> xr;
+    csr.load_metas(tr.t, tr.step, p.n_tiles, tid);
+    __syncthreads();
+    int kt = 0;                                                 // index of the tile in this workgroup's sequence
     if (tr.t < tr.t_end) {
-        sr.meta = csr.meta_of(tr.t, p.n_tiles);
-        csr.issue(sr, tr.t, tr.t + tr.step, p.n_tiles, tr.t * K::TM, p.n_nodes, tid);
+        csr.issue(sr, 0, tr.t * K::TM, p.n_nodes, tid);
         xr.issue(p.x_in, tr.t * K::TM, p.n_nodes, tid);
     }
     for (int t = tr.t; t < tr.t_end; t += tr.step) {
         const int node0 = t * K::TM;
         const int tslot = ((t - tr.t) / tr.step) * 8;
         GADAPT_STAMP(p.stamps, tslot + 0);
-        xr.commit(xs, tid);
-        const int dmax = csr.commit(sr, tid);
+        xr.commit(xs, p.n_nodes, tid);
+        const int dmax = csr.commit(sr, tid, node0);
         __syncthreads();
-        if (t + tr.step < tr.t_end) {                           // request the next tile now: it lands during this one
-            sr.meta = sr.meta_next;
-            csr.issue(sr, t + tr.step, t + 2 * tr.step, p.n_tiles, (t + tr.step) * K::TM, p.n_nodes, tid);
+        {   // request the next tile now (unconditional, clamped past the end: see issue()): it lands during this one
+            csr.issue(sr, ++kt, (t + tr.step) * K::TM, p.n_nodes, tid);
             xr.issue(p.x_in, (t + tr.step) * K::TM, p.n_nodes, tid);
         }
         GADAPT_STAMP(p.stamps, tslot + 1);
@@ -1043,7 +1120,7 @@ struct BwdSArgs {
     const float* A; const float* p0;
     const int32_t* rowptr; const int32_t* col; const int32_t* meta;
     float* g_out;
-    int n_nodes, n_tiles;
+    int n_nodes, n_tiles, n_edges;
     unsigned long long* stamps;
 };
 
@@ -1062,7 +1139,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
     float* ys = reinterpret_cast<float*>(smem4);
     float* os = ys + K::TILE_FLOATS;
     TileCsr<C, 2> csr;                                          // aux = {alpha*dt, d<P,x>} per out-edge (source order)
-    csr.bind(os + K::TILE_FLOATS, p.rowptr, p.col, p.edge_ws, p.meta);
+    csr.bind(os + K::TILE_FLOATS, p.rowptr, p.col, p.edge_ws, p.meta, p.n_edges);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
 
@@ -1082,19 +1159,18 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
 
     const TileRange tr = tile_range(p.n_tiles);
     typename TileCsr<C, 2>::Regs sr;
-    if (tr.t < tr.t_end) {
-        sr.meta = csr.meta_of(tr.t, p.n_tiles);
-        csr.issue(sr, tr.t, tr.t + tr.step, p.n_tiles, tr.t * K::TM, p.n_nodes, tid);
-    }
+    csr.load_metas(tr.t, tr.step, p.n_tiles, tid);
+    __syncthreads();
+    int kt = 0;                                                 // index of the tile in this workgroup's sequence
+    if (tr.t < tr.t_end) csr.issue(sr, 0, tr.t * K::TM, p.n_nodes, tid);
     for (int t = tr.t; t < tr.t_end; t += tr.step) {
         const int node0 = t * K::TM;
         const int tslot = ((t - tr.t) / tr.step) * 8;
         GADAPT_STAMP(p.stamps, tslot + 0);
-        const int dmax = csr.commit(sr, tid);
+        const int dmax = csr.commit(sr, tid, node0);
         __syncthreads();
-        if (t + tr.step < tr.t_end) {                           // request the next tile now: it lands during this one
-            sr.meta = sr.meta_next;
-            csr.issue(sr, t + tr.step, t + 2 * tr.step, p.n_tiles, (t + tr.step) * K::TM, p.n_nodes, tid);
+        {   // request the next tile now (unconditional, clamped past the end: see issue()): it lands during this one
+            csr.issue(sr, ++kt, (t + tr.step) * K::TM, p.n_nodes, tid);
         }
         GADAPT_STAMP(p.stamps, tslot + 1);
         V zr[K::ITERS];                                         // sum(alpha dt g_i) + sigma p0, kept across the GEMM
@@ -1364,14 +1440,18 @@ __global__ void adam_step_kernel(float* param, const float* grad, float* m, floa
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// Workgroups of a launch: a multiple of 8 (XCD groups), at most max_blocks (the resident set) unless that would
+// give a workgroup more than 64 tiles (Cfg::MAXM: its tile metadata must fit the LDS table).
 static inline int grid_for(int n_tiles, int max_blocks) {
     int g = (n_tiles + 7) & ~7;
     if (g > max_blocks) g = max_blocks;
+    const int need = (((n_tiles + 63) / 64) + 7) & ~7;
+    if (g < need) g = need;
     if (g < 8) g = 8;
     return g;
 }
 #ifndef GADAPT_FWD_MAX_BLOCKS
-#define GADAPT_FWD_MAX_BLOCKS 768        /* 3 resident workgroups per CU x 256 CUs (A/B on MI355X: 768 > 512 > 1024) */
+#define GADAPT_FWD_MAX_BLOCKS 512        /* 2 resident workgroups per CU (LDS ring: 4 tiles each) x 256 CUs */
 #endif
 #ifndef GADAPT_BWD_S_MAX_BLOCKS
 #define GADAPT_BWD_S_MAX_BLOCKS 1024
@@ -1391,12 +1471,12 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
                                        const float* lp, float* alpha_out, int residual_only, hipStream_t st) {
     using K = Cfg<C>;
     FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t), alpha_out, g->n_nodes,
-              (g->n_nodes + K::TM - 1) / K::TM, residual_only, nullptr};
+              (g->n_nodes + K::TM - 1) / K::TM, residual_only, g->n_edges, nullptr};
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
 #endif
     ProfScope prof(0, st);
-    constexpr int lds = K::lds_bytes(0);
+    constexpr int lds = K::lds_bytes(0, K::RING + 1);
     allow_lds(grand_fwd_kernel<C>, lds);
     hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds, st, p);
     return check_launch("grand_fwd_kernel");
@@ -1407,7 +1487,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     using K = Cfg<C>;
     const int n_tiles = (g->n_nodes + K::TM - 1) / K::TM;
     BwdTArgs pt{x_in, g_in, alpha, a, lp, g->rowptr_t, g->col_t, g->tpos_s, meta_for<K::TM>(g->meta_t), reinterpret_cast<float2*>(edge_ws), dxd, slab, sums_out,
-                g->n_nodes, n_tiles, accumulate, residual_only, nullptr};
+                g->n_nodes, n_tiles, accumulate, residual_only, g->n_edges, nullptr};
 #ifdef GADAPT_STAMPS
     pt.stamps = g_stamp_buf ? g_stamp_buf + 1024 * 32 : nullptr;
 #endif
@@ -1425,7 +1505,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
         rc = check_launch("grand_bwd_target_kernel");
     }
     if (rc || !g_out) return rc;
-    BwdSArgs ps{x_in, g_in, edge_ws, dxd, a, p0, g->rowptr_s, g->col_s, meta_for<K::TM>(g->meta_s), g_out, g->n_nodes, n_tiles, nullptr};
+    BwdSArgs ps{x_in, g_in, edge_ws, dxd, a, p0, g->rowptr_s, g->col_s, meta_for<K::TM>(g->meta_s), g_out, g->n_nodes, n_tiles, g->n_edges, nullptr};
 #ifdef GADAPT_STAMPS
     ps.stamps = g_stamp_buf ? g_stamp_buf + 2 * 1024 * 32 : nullptr;
 #endif
@@ -1460,7 +1540,7 @@ extern "C" int gadapt_debug_occupancy(int c, int* out3) {
 #define GADAPT_OCC(CC)                                                                                                  \
     case CC: {                                                                                                          \
         using K = Cfg<CC>;                                                                                              \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_kernel<CC>, 256, K::lds_bytes(0)); \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_kernel<CC>, 256, K::lds_bytes(0, K::RING + 1)); \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC, false>, 256, K::lds_bytes(1)); \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], grand_bwd_source_kernel<CC>, 256, K::lds_bytes(2)); \
         return GADAPT_OK;                                                                                               \

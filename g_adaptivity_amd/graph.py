@@ -63,10 +63,10 @@ class MeshGraph:
         if rc != 0:
             raise _native.NativeError(f"gadapt_csr_build_host failed (code {rc}): edge endpoint outside [0,{n})?")
         metas = {}
-        for tag, rp in (('t', rowptr_t), ('s', rowptr_s)):
+        for tag, rp, cl in (('t', rowptr_t, col_t), ('s', rowptr_s, col_s)):
             for tm in _native.TILE_HEIGHTS:
                 m = torch.empty(4 * ((n + tm - 1) // tm), dtype=torch.int32)
-                if _native.lib().gadapt_tile_meta_host(rp.data_ptr(), n, tm, m.data_ptr()) != 0:
+                if _native.lib().gadapt_tile_meta_host(rp.data_ptr(), cl.data_ptr(), n, tm, m.data_ptr()) != 0:
                     raise _native.NativeError("gadapt_tile_meta_host failed")
                 metas[(tag, tm)] = m.to(self.device)
         self._metas = metas

@@ -56,9 +56,11 @@ int gadapt_csr_build_host(const int64_t* src, const int64_t* dst, int64_t n_edge
                           int32_t* rowptr_s, int32_t* col_s, int32_t* perm_s, int32_t* tpos_s);
 
 /* Per-tile staging metadata for the kernels: for tiles of `tile_rows` consecutive rows of one CSR orientation,
- * meta[4t+0] = first entry of the tile's slice, [4t+1] = its length, [4t+2] = the longest row, [4t+3] = 0.
- * The kernels use tile heights 64, 128 and 256 (by hidden size): build all three for both orientations. */
-int gadapt_tile_meta_host(const int32_t* rowptr, int64_t n_nodes, int tile_rows, int32_t* meta_out);
+ * meta[4t+0] = first entry of the tile's slice, [4t+1] = its length, [4t+2] = the longest row,
+ * [4t+3] = 1 if every neighbour of the tile's rows lies in tiles t-1..t+1 (the kernels then gather from an LDS
+ * window instead of L2), else 0.  The kernels use tile heights 64, 128 and 256 (by hidden size): build all three
+ * for both orientations (host pointers). */
+int gadapt_tile_meta_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int tile_rows, int32_t* meta_out);
 
 typedef struct gadapt_graph {
     int32_t n_nodes;
