@@ -33,6 +33,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_WAVES_BWD_S
 #define GADAPT_WAVES_BWD_S 2
 #endif
+#ifndef GADAPT_STAGGER_FWD
+#define GADAPT_STAGGER_FWD 0
+#endif
+#ifndef GADAPT_STAGGER_T
+#define GADAPT_STAGGER_T 0
+#endif
+#ifndef GADAPT_STAGGER_S
+#define GADAPT_STAGGER_S 0
+#endif
 #define GADAPT_SLAB_CHUNKS 32   // second-level partials of the slab reduction
 
 // ------------------------------------------------------------------------------------------------
@@ -120,7 +129,7 @@ template <int C> struct Cfg {
                                                        //   bounds and return a valid node id (weight 0)
     // LDS: `tiles` [TM][LD] tiles, rowptr[TM+1] (padded to TM+4), col[COLN], aux[AUXW*COLN]
     static constexpr int MAXM = 64;                    // tile-metadata words of this workgroup's tiles kept in LDS
-    static constexpr int lds_bytes(int auxw, int tiles = 2) { return (tiles * TILE_FLOATS + (TM + 4) + COLN + auxw * COLN + 4 * MAXM) * 4; }
+    static constexpr int lds_bytes(int auxw, int tiles = 2, int ext = 0) { return (tiles * TILE_FLOATS + (TM + 4) + COLN + (auxw + ext) * COLN + 4 * MAXM) * 4; }
     static constexpr int RING = 3;                     // LDS slabs of x rows kept by the rolling-window kernels
 };
 
@@ -168,6 +177,18 @@ __device__ __forceinline__ TileRange tile_range(int n_tiles) {
     const int t0 = xcd * per;
     const int t1 = min(n_tiles, t0 + per);
     return {t0 + bi, t1, gx};
+}
+
+// Phase stagger: the second half of the launch (the second workgroup of every CU when two are resident) starts
+// `units` x 64 cycles late, so that co-resident workgroups are in different phases (edge walk: VALU/LDS, GEMM
+// phases: MFMA) and the launch does not request its tiles from HBM in lockstep bursts.
+template <int UNITS> __device__ __forceinline__ void stagger_start() {
+    if constexpr (UNITS > 0) {
+        if (blockIdx.x >= (gridDim.x >> 1)) {
+#pragma unroll 1
+            for (int k = 0; k < UNITS; k += 64) __builtin_amdgcn_s_sleep(64);
+        }
+    }
 }
 
 // Contiguous tiles [t0, t1) for this workgroup (rolling-window kernels): XCD group x walks the x-th eighth of the
@@ -221,30 +242,48 @@ template <int C, bool TRANS> struct TileGemm {
     }
 
     // in_tile/out_tile: LDS [TM][LD].  Caller synchronises around it.
-    __device__ __forceinline__ void run(const float* in_tile, float* out_tile) const {
+    __device__ __forceinline__ void accumulate(const float* in_tile, f32x16 (&acc)[BPW]) const {
         const int h = lane >> 5, r31 = lane & 31;
 #pragma unroll
         for (int b = 0; b < BPW; ++b) {
             const int rb = rb0 + b * (4 / K::CB);
-            f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
             const float* arow = in_tile + (rb * 32 + r31) * K::LD + 4 * h;
 #pragma unroll
             for (int q = 0; q < C / 8; ++q) {
                 const float4 a = *reinterpret_cast<const float4*>(arow + 8 * q);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bf[4 * q + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bf[4 * q + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bf[4 * q + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bf[4 * q + 3], acc, 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bf[4 * q + 0], acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bf[4 * q + 1], acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bf[4 * q + 2], acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bf[4 * q + 3], acc[b], 0, 0, 0);
             }
+        }
+    }
+    __device__ __forceinline__ void store(float* out_tile, const f32x16 (&acc)[BPW]) const {
+        const int h = lane >> 5, r31 = lane & 31;
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+            const int rb = rb0 + b * (4 / K::CB);
             float* ocol = out_tile + cb * 32 + r31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                ocol[row * K::LD] = acc[r] + bias;
+                ocol[row * K::LD] = acc[b][r] + bias;
             }
         }
+    }
+    __device__ __forceinline__ void run(const float* in_tile, float* out_tile) const {
+        f32x16 acc[BPW];
+        accumulate(in_tile, acc);
+        store(out_tile, acc);
+    }
+    // out == in: every wave reads its operand rows before any wave overwrites them (two workgroup barriers inside)
+    __device__ __forceinline__ void run_in_place(float* tile) const {
+        f32x16 acc[BPW];
+        accumulate(tile, acc);
+        __syncthreads();
+        store(tile, acc);
     }
 };
 
@@ -268,20 +307,22 @@ template <int C> __device__ __forceinline__ void stage_tile(const float* __restr
 // (gadapt_tile_meta_host), so every load of the stage is issued at once: one memory round trip per tile.
 // A tile whose slice does not fit (more than CAP entries) or that has a row longer than MAXD is "slow":
 // the whole workgroup walks the HBM copy with plain loops instead.
-template <int C, int AUXW> struct TileCsr {
+// EXT: one more per-edge int32 array (separate in HBM) staged with the slice.
+template <int C, int AUXW, int EXT = 0> struct TileCsr {
     using K = Cfg<C>;
-    int* rp; int* col; float* aux; int4* metas;
-    const int32_t* rowptr_g; const int32_t* col_g; const float* aux_g; const int4* meta_g;
+    int* rp; int* col; float* aux; int* ext; int4* metas;
+    const int32_t* rowptr_g; const int32_t* col_g; const float* aux_g; const int32_t* ext_g; const int4* meta_g;
     int ebase, n_edges_m1, m_first, m_step, m_ntiles;
 
     __device__ __forceinline__ void bind(float* lds_after_tiles, const int32_t* rowptr_g_, const int32_t* col_g_, const float* aux_g_,
-                                         const int32_t* meta_g_, int n_edges) {
+                                         const int32_t* meta_g_, int n_edges, const int32_t* ext_g_ = nullptr) {
         n_edges_m1 = max(n_edges - 1, 0);
         rp = reinterpret_cast<int*>(lds_after_tiles);
         col = rp + (K::TM + 4);
         aux = reinterpret_cast<float*>(col + K::COLN);
-        metas = reinterpret_cast<int4*>(aux + AUXW * K::COLN);
-        rowptr_g = rowptr_g_; col_g = col_g_; aux_g = aux_g_; meta_g = reinterpret_cast<const int4*>(meta_g_);
+        ext = reinterpret_cast<int*>(aux + AUXW * K::COLN);
+        metas = reinterpret_cast<int4*>(ext + EXT * K::COLN);
+        rowptr_g = rowptr_g_; col_g = col_g_; aux_g = aux_g_; ext_g = ext_g_; meta_g = reinterpret_cast<const int4*>(meta_g_);
     }
     // Metadata of this workgroup's tiles first, first+step, ... -> LDS, once per launch.  Read per tile with
     // meta_at(k): a per-tile global load would be moved to SGPRs by hipcc (v_readfirstlane) and its s_waitcnt,
@@ -302,6 +343,7 @@ template <int C, int AUXW> struct TileCsr {
         int rpv, rpv2;
         int colv[CQ];
         float auxv[AUXW > 0 ? AUXW * CQ : 1];
+        int extv[EXT > 0 ? CQ : 1];
     };
     // Every load here is
     // UNCONDITIONAL with a clamped address (validity is applied in commit): a load under a branch or an exec mask
@@ -317,6 +359,7 @@ template <int C, int AUXW> struct TileCsr {
         for (int q = 0; q < CQ; ++q) {
             const int idx = q * 256 + tid;
             r.colv[q] = col_g[min(eb + idx, n_edges_m1)];
+            if constexpr (EXT > 0) r.extv[q] = ext_g[min(eb + idx, n_edges_m1)];
             if constexpr (AUXW > 0) {
 #pragma unroll
                 for (int w = 0; w < AUXW; ++w) {
@@ -347,6 +390,7 @@ template <int C, int AUXW> struct TileCsr {
             const int cnt = min(r.meta.y, K::CAP);
             const int jv = (idx < cnt) ? r.colv[q] : node0_pad;       // padding entries: a valid node of this tile
             if (idx < K::CAP + GADAPT_MAXD) col[idx] = (windowed_tile >= 0) ? ring_off(jv, windowed_tile) : jv;
+            if constexpr (EXT > 0) { if (idx < K::CAP + GADAPT_MAXD) ext[idx] = r.extv[q]; }
             if constexpr (AUXW > 0) {
 #pragma unroll
                 for (int w = 0; w < AUXW; ++w) {
@@ -707,6 +751,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     //      t-1, t, t+1 of x are resident in the ring (one new slab per tile, requested one tile ahead)
     const TileChunk ch = tile_chunk(p.n_tiles);
     if (ch.t0 >= ch.t1) return;
+    stagger_start<GADAPT_STAGGER_FWD>();
     auto slab_ptr = [&](int s_) { return ring + ((s_ + K::RING) % K::RING) * K::TILE_FLOATS; };
     // Staging runs TWO tiles ahead (two register sets, used alternately): every workgroup of the launch requests
     // its next slab at the same moment, so one tile of compute does not cover that burst.
@@ -779,27 +824,33 @@ struct BwdTArgs {
 
 template <int NROWS, int NV> struct TBuf {
     static constexpr int N = NROWS;
-    Vec<NV> r[NROWS]; Vec<NV> g;
+    Vec<NV> r[NROWS];
     int deg, el0;
 };
 
 // SUMS: also reduce d/d(dt) and d/d(score_scale) (learn_step / learnable temperature).  A separate instantiation:
 // hipcc otherwise sinks the per-edge log terms behind the pipeline and keeps dozens of registers alive for them.
+//
+// Rolling window like the forward: a workgroup walks consecutive tiles with slabs t-1, t, t+1 of x in an LDS ring,
+// so on mesh-ordered graphs the x_j gathers are LDS reads.  Per tile the fourth LDS tile holds g (staged with the
+// ring slab), then dP (written over g row by row by the lanes that read it), then dP A (in place).
 template <int C, bool SUMS>
 __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kernel(BwdTArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
-    float* xs = reinterpret_cast<float*>(smem4);
-    float* ds = xs + K::TILE_FLOATS;                            // dP tile
-    TileCsr<C, 1> csr;                                          // aux = forward alpha (target order)
-    csr.bind(ds + K::TILE_FLOATS, p.rowptr, p.col, p.alpha, p.meta, p.n_edges);
+    float* ring = reinterpret_cast<float*>(smem4);
+    float* ds = ring + K::RING * K::TILE_FLOATS;                // g tile -> dP tile -> dP A
+    using CsrT = TileCsr<C, 1, 1>;                              // aux = forward alpha (target order), ext = tpos
+    CsrT csr;
+    csr.bind(ds + K::TILE_FLOATS, p.rowptr, p.col, p.alpha, p.meta, p.n_edges, p.tpos);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
     // out = base*x + dt*(m - x): Euler step (base 1) or bare residual (base 0, dt 1)
     const float dt = p.residual_only ? 1.0f : p.lp[0], sc = p.lp[1];
     const float w1 = (p.residual_only ? 0.0f : 1.0f) - dt;
     constexpr int ROW = C * C + C;                              // slab row: dA then dp0
+    float* xs = ring;                                           // slab of the current tile
 
     TileGemm<C, true> gemm;                                     // dxd = dP A
     float acol[K::MFMA ? 1 : 4][K::MFMA ? 1 : C];               // VALU: A[o][4sub+t]
@@ -826,8 +877,9 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
     }
     V dp0acc; dp0acc.zero();
     float sum_ddt = 0.f, sum_dsc = 0.f;
+    V gk[K::ITERS];                                             // (base - dt) g_i of this lane's node slots, for the epilogue
 
-    auto finish = [&](int li, int i, const V& gi, const V& m, const V& dP) {
+    auto finish = [&](int li, int i, int it, const V& gi, const V& m, const V& dP) {
         if (i < p.n_nodes) {
             if constexpr (SUMS) {
                 // d dt = sum_i <g_i, m_i - x_i>   (GNN.py:288-289 learn_step); every lane adds its channels
@@ -842,18 +894,31 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
                 dp0acc.v[q].x += dP.v[q].x; dp0acc.v[q].y += dP.v[q].y; dp0acc.v[q].z += dP.v[q].z; dp0acc.v[q].w += dP.v[q].w;
             }
         }
-        lds_put<C>(ds, li, sub, dP);
+#pragma unroll
+        for (int q = 0; q < K::NV; ++q) {
+            gk[it].v[q].x = w1 * gi.v[q].x; gk[it].v[q].y = w1 * gi.v[q].y; gk[it].v[q].z = w1 * gi.v[q].z; gk[it].v[q].w = w1 * gi.v[q].w;
+        }
+        lds_put<C>(ds, li, sub, dP);                            // over g_i: only this lane group reads that row
     };
 
-    auto fetch = [&](auto& b, int node0, int it) {
+    // WIN (compile time): gathers from the LDS ring (col holds ring offsets) or from HBM/L2; see the forward kernel
+    auto fetch = [&](auto& b, int node0, int it, auto win_tag) {
         constexpr int DM = std::remove_reference_t<decltype(b)>::N;
+        constexpr bool WIN = decltype(win_tag)::value != 0;
         const int li = it * K::SLOTS + slot;
-        const int i = node0 + li;
         b.el0 = csr.rp[li] - csr.ebase;
-        b.deg = (i < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
-        b.g = ld_vec<C>(p.g_in, min(i, p.n_nodes - 1), sub);
+        b.deg = (node0 + li < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
+        if constexpr (WIN) {
 #pragma unroll
-        for (int k = 0; k < DM; ++k) b.r[k] = ld_vec<C>(p.x_in, csr.col[b.el0 + k], sub);   // k >= deg: some valid row, weight 0
+            for (int k = 0; k < DM; ++k) {
+                const float* row = ring + csr.col[b.el0 + k];
+#pragma unroll
+                for (int q = 0; q < K::NV; ++q) b.r[k].v[q] = *reinterpret_cast<const float4*>(row + 4 * (sub + q * K::LPN));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < DM; ++k) b.r[k] = ld_vec<C>(p.x_in, csr.col[b.el0 + k], sub);   // k >= deg: some valid row, weight 0
+        }
     };
 
     auto consume = [&](const auto& b, int node0, int it) {
@@ -861,8 +926,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
         const int deg = b.deg, e0 = b.el0;
-        V gi = b.g;
-        if (i >= p.n_nodes) gi.zero();
+        const V gi = lds_vec<C>(ds, li, sub);                   // rows past N were staged as zeros
         V dm;
 #pragma unroll
         for (int q = 0; q < K::NV; ++q) {
@@ -892,21 +956,21 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         }
         if constexpr (K::LPN >= DM) {
             const float am = pick(a, sub), dm_ = pick(da, sub);
-            if (sub < deg) p.edge_ws[p.tpos[csr.ebase + e0 + sub]] = make_float2(am * dt, dm_);
+            if (sub < deg) p.edge_ws[csr.ext[e0 + sub]] = make_float2(am * dt, dm_);
         } else {
 #pragma unroll
             for (int k = 0; k < DM; ++k)
-                if (k < deg && (k % K::LPN) == sub) p.edge_ws[p.tpos[csr.ebase + e0 + k]] = make_float2(a[k] * dt, da[k]);
+                if (k < deg && (k % K::LPN) == sub) p.edge_ws[csr.ext[e0 + k]] = make_float2(a[k] * dt, da[k]);
         }
-        finish(li, i, gi, m, dP);
+        finish(li, i, it, gi, m, dP);
     };
 
     auto slow_node = [&](int node0, int it) {
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
-        V dP, m, gi; dP.zero(); m.zero(); gi.zero();
+        V dP, m; dP.zero(); m.zero();
+        const V gi = lds_vec<C>(ds, li, sub);
         if (i < p.n_nodes) {
-            gi = ld_vec<C>(p.g_in, i, sub);
             V dm;
 #pragma unroll
             for (int q = 0; q < K::NV; ++q) {
@@ -929,119 +993,143 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
                 if ((k % K::LPN) == sub) p.edge_ws[p.tpos[e0 + k]] = make_float2(ak * dt, dss);
             }
         }
-        finish(li, i, gi, m, dP);
+        finish(li, i, it, gi, m, dP);
     };
 
-    const TileRange tr = tile_range(p.n_tiles);
-    typename TileCsr<C, 1>::Regs sr;
-    TileRows<C> xr;
-    csr.load_metas(tr.t, tr.step, p.n_tiles, tid);
-    __syncthreads();
-    int kt = 0;                                                 // index of the tile in this workgroup's sequence
-    if (tr.t < tr.t_end) {
-        csr.issue(sr, 0, tr.t * K::TM, p.n_nodes, tid);
-        xr.issue(p.x_in, tr.t * K::TM, p.n_nodes, tid);
-    }
-    for (int t = tr.t; t < tr.t_end; t += tr.step) {
-        const int node0 = t * K::TM;
-        const int tslot = ((t - tr.t) / tr.step) * 8;
-        GADAPT_STAMP(p.stamps, tslot + 0);
-        xr.commit(xs, p.n_nodes, tid);
-        const int dmax = csr.commit(sr, tid, node0);
-        __syncthreads();
-        {   // request the next tile now (unconditional, clamped past the end: see issue()): it lands during this one
-            csr.issue(sr, ++kt, (t + tr.step) * K::TM, p.n_nodes, tid);
-            xr.issue(p.x_in, (t + tr.step) * K::TM, p.n_nodes, tid);
-        }
-        GADAPT_STAMP(p.stamps, tslot + 1);
-        // ---- edge phase: dP_i per node -> LDS
-        if (dmax >= 0) {
-            dispatch_dmax(dmax, [&](auto tag) {
-                run_pipeline<K::ITERS, TBuf<decltype(tag)::value, K::NV>>(
-                    [&](auto& b, int it) { fetch(b, node0, it); },
-                    [&](const auto& b, int it) { consume(b, node0, it); },
-                    [&]() {});
-            });
-        } else {
-#pragma unroll 1
-            for (int it = 0; it < K::ITERS; ++it) slow_node(node0, it);
-        }
-        GADAPT_STAMP(p.stamps, tslot + 2);
-        if constexpr (K::MFMA) gemm.load(p.A, nullptr);         // in flight under the barrier and the dA pass
-        __syncthreads();
-        GADAPT_STAMP(p.stamps, tslot + 3);
-        // ---- dA partial:  dA[o][c] += sum_node dP[node][o] x[node][c]
-        if constexpr (K::MFMA) {
-            const int h = lane >> 5, r31 = lane & 31;
-            if constexpr (NB2 >= 4) {
-                // wave owns o-block `ob` and DPW consecutive c-blocks
-                const int ob = (wave * DPW) / K::CB, cb0 = (wave * DPW) % K::CB;
-#pragma unroll 4
-                for (int st = 0; st < K::TM / 2; ++st) {
-                    const int node = 2 * st + h;
-                    const float a = ds[node * K::LD + ob * 32 + r31];
+    // dxd rows of a finished tile leave the registers only after the NEXT tile's staging: vmcnt is in-order and hipcc
+    // waits vmcnt(0) before the staging reads its prefetch registers, so stores issued just before it would be
+    // waited for (a full write round trip per tile).
+    auto store_dxd = [&](int node0) {
 #pragma unroll
-                    for (int b = 0; b < DPW; ++b) {
-                        const float bv = xs[node * K::LD + (cb0 + b) * 32 + r31];
-                        dacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, dacc[b], 0, 0, 0);
+        for (int it = 0; it < K::ITERS; ++it) {
+            const int i = node0 + it * K::SLOTS + slot;
+            if (i < p.n_nodes) st_vec<C>(p.dxd, i, sub, gk[it]);
+        }
+    };
+    const TileChunk ch = tile_chunk(p.n_tiles);                 // an empty chunk still flushes its (zero) slab row
+    if (ch.t0 < ch.t1) {
+        stagger_start<GADAPT_STAGGER_T>();
+        auto slab_ptr = [&](int s_) { return ring + ((s_ + K::RING) % K::RING) * K::TILE_FLOATS; };
+        typename CsrT::Regs sr;
+        TileRows<C> xr, gr;
+        if constexpr (K::MFMA) gemm.load(p.A, nullptr);         // B fragments stay in registers for the whole launch
+        csr.load_metas(ch.t0, 1, p.n_tiles, tid);
+        xr.issue(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
+        xr.issue(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0), p.n_nodes, tid);
+        __syncthreads();                                        // tile metadata visible
+        xr.issue(p.x_in, (ch.t0 + 1) * K::TM, p.n_nodes, tid);
+        gr.issue(p.g_in, ch.t0 * K::TM, p.n_nodes, tid);
+        csr.issue(sr, 0, ch.t0 * K::TM, p.n_nodes, tid);
+#pragma unroll 1
+        for (int t = ch.t0; t < ch.t1; ++t) {
+            const int node0 = t * K::TM;
+            const int tslot = (t - ch.t0) * 8;
+#ifdef GADAPT_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // diagnostic: separates the prefetch wait from the LDS writes
+#endif
+            GADAPT_STAMP(p.stamps, tslot + 0);
+            xs = slab_ptr(t);
+            const bool win = sr.meta.w != 0;
+            xr.commit(slab_ptr(t + 1), p.n_nodes, tid);
+            gr.commit(ds, p.n_nodes, tid);
+            const int dmax = csr.commit(sr, tid, node0, win ? t : -1);
+            GADAPT_STAMP(p.stamps, tslot + 1);
+            __syncthreads();
+            if (t > ch.t0) store_dxd(node0 - K::TM);            // previous tile's result: see store_dxd
+            GADAPT_STAMP(p.stamps, tslot + 2);
+            // ---- edge phase: dP_i per node -> LDS
+            if (dmax >= 0) {
+                dispatch_dmax(dmax, [&](auto tag) {
+                    auto walk = [&](auto win_tag) {
+                        run_pipeline<K::ITERS, TBuf<decltype(tag)::value, K::NV>>(
+                            [&](auto& b, int it) { fetch(b, node0, it, win_tag); },
+                            [&](const auto& b, int it) { consume(b, node0, it); },
+                            [&]() {});
+                    };
+                    if (win) walk(IntTag<1>{}); else walk(IntTag<0>{});
+                });
+            } else {
+#pragma unroll
+                for (int it = 0; it < K::ITERS; ++it) slow_node(node0, it);
+            }
+            GADAPT_STAMP(p.stamps, tslot + 3);
+            {   // request the next tile (unconditional, clamped past the end: see issue()).  Here rather than at the top
+                // of the tile: the edge phase needs every register, and the MFMA phases below cover the round trip.
+                csr.issue(sr, t + 1 - ch.t0, (t + 1) * K::TM, p.n_nodes, tid);
+                xr.issue(p.x_in, (t + 2) * K::TM, p.n_nodes, tid);
+                gr.issue(p.g_in, (t + 1) * K::TM, p.n_nodes, tid);
+            }
+            __syncthreads();
+            GADAPT_STAMP(p.stamps, tslot + 4);
+            // ---- dA partial:  dA[o][c] += sum_node dP[node][o] x[node][c]
+            if constexpr (K::MFMA) {
+                const int h = lane >> 5, r31 = lane & 31;
+                if constexpr (NB2 >= 4) {
+                    // wave owns o-block `ob` and DPW consecutive c-blocks
+                    const int ob = (wave * DPW) / K::CB, cb0 = (wave * DPW) % K::CB;
+#pragma unroll 4
+                    for (int st = 0; st < K::TM / 2; ++st) {
+                        const int node = 2 * st + h;
+                        const float a = ds[node * K::LD + ob * 32 + r31];
+#pragma unroll
+                        for (int b = 0; b < DPW; ++b) {
+                            const float bv = xs[node * K::LD + (cb0 + b) * 32 + r31];
+                            dacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, dacc[b], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    // one 32x32 block: waves split the TM nodes
+                    constexpr int NPW = K::TM / 4;
+#pragma unroll 4
+                    for (int st = 0; st < NPW / 2; ++st) {
+                        const int node = wave * NPW + 2 * st + h;
+                        dacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[node * K::LD + r31], xs[node * K::LD + r31],
+                                                                       dacc[0], 0, 0, 0);
                     }
                 }
             } else {
-                // one 32x32 block: waves split the TM nodes
-                constexpr int NPW = K::TM / 4;
-#pragma unroll 4
-                for (int st = 0; st < NPW / 2; ++st) {
-                    const int node = wave * NPW + 2 * st + h;
-                    dacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[node * K::LD + r31], xs[node * K::LD + r31],
-                                                                   dacc[0], 0, 0, 0);
+                constexpr int C2 = C * C;
+                constexpr int NSUB = (256 / C2) > 0 ? (256 / C2) : 1;       // node subsets
+                const int el = tid % C2, sb = tid / C2;
+                if (sb < NSUB) {
+                    const int o = el / C, c = el % C;
+                    for (int node = sb; node < K::TM; node += NSUB) dav = fmaf(ds[node * K::LD + o], xs[node * K::LD + c], dav);
                 }
             }
-        } else {
-            constexpr int C2 = C * C;
-            constexpr int NSUB = (256 / C2) > 0 ? (256 / C2) : 1;       // node subsets
-            const int el = tid % C2, sb = tid / C2;
-            if (sb < NSUB) {
-                const int o = el / C, c = el % C;
-                for (int node = sb; node < K::TM; node += NSUB) dav = fmaf(ds[node * K::LD + o], xs[node * K::LD + c], dav);
-            }
-        }
-        __syncthreads();
-        GADAPT_STAMP(p.stamps, tslot + 4);
-        // ---- dxd = (base-dt) g + dP A
-        if constexpr (K::MFMA) {
-            gemm.run(ds, xs);                                   // xs is dead after the dA pass
-            __syncthreads();
-        }
-        GADAPT_STAMP(p.stamps, tslot + 5);
-#pragma unroll
-        for (int it = 0; it < K::ITERS; ++it) {
-            const int li = it * K::SLOTS + slot;
-            const int i = node0 + li;
-            if (i >= p.n_nodes) continue;
-            V r;
+            GADAPT_STAMP(p.stamps, tslot + 5);
+            // ---- dxd = (base-dt) g + dP A
             if constexpr (K::MFMA) {
-                r = lds_vec<C>(xs, li, sub);
-            } else {
-                r.zero();
+                gemm.run_in_place(ds);                          // reads dP (like the dA pass), barrier, writes dP A
+                __syncthreads();
+            }
+            GADAPT_STAMP(p.stamps, tslot + 6);
 #pragma unroll
-                for (int o = 0; o < C; ++o) {
-                    const float d = ds[li * K::LD + o];
-                    r.v[0].x = fmaf(d, acol[0][o], r.v[0].x); r.v[0].y = fmaf(d, acol[1][o], r.v[0].y);
-                    r.v[0].z = fmaf(d, acol[2][o], r.v[0].z); r.v[0].w = fmaf(d, acol[3][o], r.v[0].w);
+            for (int it = 0; it < K::ITERS; ++it) {
+                const int li = it * K::SLOTS + slot;
+                const int i = node0 + li;
+                V r;
+                if constexpr (K::MFMA) {
+                    r = lds_vec<C>(ds, li, sub);
+                } else {
+                    r.zero();
+#pragma unroll
+                    for (int o = 0; o < C; ++o) {
+                        const float d = ds[li * K::LD + o];
+                        r.v[0].x = fmaf(d, acol[0][o], r.v[0].x); r.v[0].y = fmaf(d, acol[1][o], r.v[0].y);
+                        r.v[0].z = fmaf(d, acol[2][o], r.v[0].z); r.v[0].w = fmaf(d, acol[3][o], r.v[0].w);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < K::NV; ++q) {
+                    gk[it].v[q].x += r.v[q].x; gk[it].v[q].y += r.v[q].y; gk[it].v[q].z += r.v[q].z; gk[it].v[q].w += r.v[q].w;
                 }
             }
-            const V gi = ld_vec<C>(p.g_in, i, sub);
-#pragma unroll
-            for (int q = 0; q < K::NV; ++q) {
-                r.v[q].x = fmaf(w1, gi.v[q].x, r.v[q].x); r.v[q].y = fmaf(w1, gi.v[q].y, r.v[q].y);
-                r.v[q].z = fmaf(w1, gi.v[q].z, r.v[q].z); r.v[q].w = fmaf(w1, gi.v[q].w, r.v[q].w);
-            }
-            st_vec<C>(p.dxd, i, sub, r);
+            __syncthreads();
+            GADAPT_STAMP(p.stamps, tslot + 7);
         }
-        GADAPT_STAMP(p.stamps, tslot + 6);
-        __syncthreads();
-        GADAPT_STAMP(p.stamps, tslot + 7);
+        store_dxd((ch.t1 - 1) * K::TM);
     }
+    xs = ring;                                                  // scratch for the flush below
 
     // ---- flush partials into this workgroup's slab row (deterministic: one owner per element)
     float* row = p.slab + (size_t)blockIdx.x * ROW;
@@ -1163,17 +1251,28 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
     __syncthreads();
     int kt = 0;                                                 // index of the tile in this workgroup's sequence
     if (tr.t < tr.t_end) csr.issue(sr, 0, tr.t * K::TM, p.n_nodes, tid);
+    V zr[K::ITERS];                                             // sum(alpha dt g_i) + sigma p0, kept across the GEMM; then the result rows
+    // g_out rows of a finished tile leave the registers only after the NEXT tile's staging (see the target pass)
+    auto store_out = [&](int node0) {
+#pragma unroll
+        for (int it = 0; it < K::ITERS; ++it) {
+            const int j = node0 + it * K::SLOTS + slot;
+            if (j < p.n_nodes) st_vec<C>(p.g_out, j, sub, zr[it]);
+        }
+    };
+    int prev_node0 = -1;
     for (int t = tr.t; t < tr.t_end; t += tr.step) {
         const int node0 = t * K::TM;
         const int tslot = ((t - tr.t) / tr.step) * 8;
         GADAPT_STAMP(p.stamps, tslot + 0);
         const int dmax = csr.commit(sr, tid, node0);
         __syncthreads();
+        if (prev_node0 >= 0) store_out(prev_node0);
+        prev_node0 = node0;
         {   // request the next tile now (unconditional, clamped past the end: see issue()): it lands during this one
             csr.issue(sr, ++kt, (t + tr.step) * K::TM, p.n_nodes, tid);
         }
         GADAPT_STAMP(p.stamps, tslot + 1);
-        V zr[K::ITERS];                                         // sum(alpha dt g_i) + sigma p0, kept across the GEMM
         if (dmax >= 0) {
             dispatch_dmax(dmax, [&](auto tag) {
                 constexpr int DM = decltype(tag)::value;
@@ -1232,6 +1331,9 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
         }
         GADAPT_STAMP(p.stamps, tslot + 2);
         if constexpr (K::MFMA) gemm.load(p.A, nullptr);         // in flight under the barrier
+        V dpre[K::ITERS];                                       // own dxd rows: requested here, used after the GEMM
+#pragma unroll
+        for (int it = 0; it < K::ITERS; ++it) dpre[it] = ld_vec<C>(p.dxd, min(node0 + it * K::SLOTS + slot, p.n_nodes - 1), sub);
         __syncthreads();
         GADAPT_STAMP(p.stamps, tslot + 3);
         if constexpr (K::MFMA) {
@@ -1256,18 +1358,18 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
                     r.v[0].z = fmaf(arow[2][c], yc, r.v[0].z); r.v[0].w = fmaf(arow[3][c], yc, r.v[0].w);
                 }
             }
-            const V d = ld_vec<C>(p.dxd, j, sub);
+            const V d = dpre[it];
 #pragma unroll
             for (int q = 0; q < K::NV; ++q) {
-                r.v[q].x = (r.v[q].x + zr[it].v[q].x) + d.v[q].x; r.v[q].y = (r.v[q].y + zr[it].v[q].y) + d.v[q].y;
-                r.v[q].z = (r.v[q].z + zr[it].v[q].z) + d.v[q].z; r.v[q].w = (r.v[q].w + zr[it].v[q].w) + d.v[q].w;
+                zr[it].v[q].x = (r.v[q].x + zr[it].v[q].x) + d.v[q].x; zr[it].v[q].y = (r.v[q].y + zr[it].v[q].y) + d.v[q].y;
+                zr[it].v[q].z = (r.v[q].z + zr[it].v[q].z) + d.v[q].z; zr[it].v[q].w = (r.v[q].w + zr[it].v[q].w) + d.v[q].w;
             }
-            st_vec<C>(p.g_out, j, sub, r);
         }
         GADAPT_STAMP(p.stamps, tslot + 5);
         __syncthreads();
         GADAPT_STAMP(p.stamps, tslot + 6);
     }
+    if (prev_node0 >= 0) store_out(prev_node0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1491,7 +1593,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
 #ifdef GADAPT_STAMPS
     pt.stamps = g_stamp_buf ? g_stamp_buf + 1024 * 32 : nullptr;
 #endif
-    constexpr int lds_t = K::lds_bytes(1), lds_s = K::lds_bytes(2);
+    constexpr int lds_t = K::lds_bytes(1, K::RING + 1, 1), lds_s = K::lds_bytes(2);
     int rc;
     {
         ProfScope prof(1, st);
@@ -1541,7 +1643,7 @@ extern "C" int gadapt_debug_occupancy(int c, int* out3) {
     case CC: {                                                                                                          \
         using K = Cfg<CC>;                                                                                              \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_kernel<CC>, 256, K::lds_bytes(0, K::RING + 1)); \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC, false>, 256, K::lds_bytes(1)); \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC, false>, 256, K::lds_bytes(1, K::RING + 1, 1)); \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], grand_bwd_source_kernel<CC>, 256, K::lds_bytes(2)); \
         return GADAPT_OK;                                                                                               \
     }

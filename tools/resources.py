@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-kernel register / scratch report of the hot kernels (hipcc -Rpass-analysis=kernel-resource-usage).
+
+    python tools/resources.py [extra hipcc flags]
+"""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Iinclude", *sys.argv[1:], "-c", "-o", "/dev/null",
+       "g_adaptivity_amd/csrc/gadapt_kernels.hip", "-Rpass-analysis=kernel-resource-usage"]
+out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True).stderr
+cur, rec = None, {}
+for line in out.splitlines():
+    m = re.search(r"remark: (.*?) \[-Rpass", line)
+    if not m:
+        continue
+    t = m.group(1).strip()
+    if t.startswith("Function Name:"):
+        cur, rec = t.split(":", 1)[1].strip(), {}
+    elif cur and ":" in t:
+        k, v = t.rsplit(":", 1)
+        rec[k.strip()] = v.strip()
+        if k.strip().startswith("LDS Size") and "grand_" in cur:
+            print("%-58s VGPR %4s  AGPR %3s  scratch %5s  spill %4s  waves/SIMD %s" % (
+                cur, rec.get("VGPRs"), rec.get("AGPRs"), rec.get("ScratchSize [bytes/lane]"), rec.get("VGPRs Spill"),
+                rec.get("Occupancy [waves/SIMD]")))

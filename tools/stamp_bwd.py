@@ -20,7 +20,7 @@ model.zero_grad(); F.mse_loss(model(data), data.x_phys).backward()
 torch.cuda.synchronize()
 handle.gadapt_debug_set_stamp_buffer(None)
 allb = buf.cpu().numpy().reshape(3, 1024, 32).astype(np.float64)
-for name, s, names in (('backward_target (last launch = layer 0)', allb[1], ['start', 'staged(b)', 'edge done', 'barrier', 'dA done(b)', 'gemm(b)', 'epilogue', 'end(b)']),
+for name, s, names in (('backward_target (last launch = layer 0)', allb[1], ['start', 'commit', 'barrier+st', 'edge done', 'issue+barrier', 'dA done', 'gemm(b)', 'epilogue(b)']),
                        ('backward_source (last launch = layer 1)', allb[2], ['start', 'staged(b)', 'edge done', 'barrier', 'gemm(b)', 'epilogue', 'end(b)', '-'])):
     print(name)
     for tile in range(4):
@@ -34,4 +34,9 @@ for name, s, names in (('backward_target (last launch = layer 0)', allb[1], ['st
             d = seg[ok, k] - seg[ok, k - 1]
             line += f"  {names[k]} {np.median(d):.0f}"
         line += f"  | total {np.median(seg[ok, nst - 1] - seg[ok, 0]):.0f}"
+        if tile < 3:
+            nxt = s[:, (tile + 1) * 8]
+            ok2 = ok & (nxt > 0)
+            if ok2.any():
+                line += f"  | gap to next tile {np.median(nxt[ok2] - seg[ok2, nst - 1]):.0f}"
         print(line)
