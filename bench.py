@@ -54,6 +54,7 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='poisson2d_64x64_b32_L4_C64', choices=list(WORKLOADS))
+    ap.add_argument('--torch-loss', action='store_true', help='torch F.mse_loss instead of the one-launch native loss')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
@@ -74,6 +75,8 @@ def main():
 
     from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt, _native
     from g_adaptivity_amd.optim import FlatAdam
+    from g_adaptivity_amd import mse_loss as native_mse_loss
+    loss_fn = F.mse_loss if args.torch_loss else native_mse_loss
 
     w = WORKLOADS[args.workload]
     opt = hot_path_opt(mesh_dims=[w['n'], w['n']], hidden_dim=w['hidden'], num_layers=w['layers'], conv_type=w['conv'],
@@ -89,7 +92,7 @@ def main():
 
     def fwd_bwd():
         out = model(data)
-        loss = F.mse_loss(out, target)
+        loss = loss_fn(out, target)
         loss.backward()
         return loss
 
@@ -115,7 +118,7 @@ def main():
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             optim.zero_grad()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=side):
                 static_loss = fwd_bwd()
             graph = g
         except Exception as e:                                        # stay correct: fall back to eager launches
@@ -125,7 +128,6 @@ def main():
 
     def step():
         if graph is not None:
-            optim.grad_bucket.zero_()
             graph.replay()                                            # forward + loss + backward as one hipGraph
             optim.step()
         else:
@@ -225,7 +227,7 @@ def main():
             'config': {'workload': args.workload, 'mesh': f"{w['n']}x{w['n']}", 'meshes_per_gpu': w['batch'],
                        'global_batch': w['batch'] * world, 'mp_layers': w['layers'], 'hidden': w['hidden'],
                        'conv_type': w['conv'], 'parallelism': f'dp{world}',
-                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'launch': 'hipgraph' if graph is not None else 'eager'},
+                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'launch': 'hipgraph' if graph is not None else 'eager'},
             'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))

@@ -1375,72 +1375,61 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
+// C is a compile-time trip count so that every load of a dot product is in flight at once (a runtime-length loop
+// pays one L2 round trip per unrolled group).
+template <int C>
 __global__ void coeffs_fwd_kernel(const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wk,
-                                  float* __restrict__ a, float* __restrict__ p0, int c) {
+                                  float* __restrict__ a, float* __restrict__ p0) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < c * c) {                    // A[o][cc] = sum_r wk[r][o] wq[r][cc]; 4 independent chains hide the load latency
-        const int o = e / c, cc = e % c;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        int r = 0;
-        for (; r + 3 < c; r += 4) {
-            v0 = fmaf(wk[(r + 0) * c + o], wq[(r + 0) * c + cc], v0);
-            v1 = fmaf(wk[(r + 1) * c + o], wq[(r + 1) * c + cc], v1);
-            v2 = fmaf(wk[(r + 2) * c + o], wq[(r + 2) * c + cc], v2);
-            v3 = fmaf(wk[(r + 3) * c + o], wq[(r + 3) * c + cc], v3);
-        }
-        for (; r < c; ++r) v0 = fmaf(wk[r * c + o], wq[r * c + cc], v0);
-        a[e] = (v0 + v1) + (v2 + v3);
-    } else if (e < c * c + c) {
-        const int o = e - c * c;
+    if (e < C * C) {                    // A[o][cc] = sum_r wk[r][o] wq[r][cc]
+        const int o = e / C, cc = e % C;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < C; ++r) v[r & 3] = fmaf(wk[r * C + o], wq[r * C + cc], v[r & 3]);
+        a[e] = (v[0] + v[1]) + (v[2] + v[3]);
+    } else if (e < C * C + C) {
+        const int o = e - C * C;
         float v = 0.f;
-        for (int r = 0; r < c; ++r) v = fmaf(wk[r * c + o], bq[r], v);
+#pragma unroll
+        for (int r = 0; r < C; ++r) v = fmaf(wk[r * C + o], bq[r], v);
         p0[o] = v;
     }
 }
 
+template <int C>
 __global__ void coeffs_bwd_kernel(const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wk,
                                   const float* __restrict__ d_a, const float* __restrict__ d_p0,
-                                  float* __restrict__ d_wq, float* __restrict__ d_bq, float* __restrict__ d_wk, float* __restrict__ d_bk, int c) {
+                                  float* __restrict__ d_wq, float* __restrict__ d_bq, float* __restrict__ d_wk, float* __restrict__ d_bk) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c2 = c * c;
+    constexpr int c2 = C * C;
     if (e < c2) {                       // d_wq[r][cc] = sum_o wk[r][o] dA[o][cc]
-        const int r = e / c, cc = e % c;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        int o = 0;
-        for (; o + 3 < c; o += 4) {
-            v0 = fmaf(wk[r * c + o + 0], d_a[(o + 0) * c + cc], v0);
-            v1 = fmaf(wk[r * c + o + 1], d_a[(o + 1) * c + cc], v1);
-            v2 = fmaf(wk[r * c + o + 2], d_a[(o + 2) * c + cc], v2);
-            v3 = fmaf(wk[r * c + o + 3], d_a[(o + 3) * c + cc], v3);
-        }
-        for (; o < c; ++o) v0 = fmaf(wk[r * c + o], d_a[o * c + cc], v0);
-        d_wq[e] = (v0 + v1) + (v2 + v3);
+        const int r = e / C, cc = e % C;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < C; ++o) v[o & 3] = fmaf(wk[r * C + o], d_a[o * C + cc], v[o & 3]);
+        d_wq[e] = (v[0] + v[1]) + (v[2] + v[3]);
     } else if (e < 2 * c2) {            // d_wk[r][o] = sum_cc wq[r][cc] dA[o][cc] + bq[r] dp0[o]
-        const int f = e - c2, r = f / c, o = f % c;
-        float v0 = bq[r] * d_p0[o], v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        int cc = 0;
-        for (; cc + 3 < c; cc += 4) {
-            v0 = fmaf(wq[r * c + cc + 0], d_a[o * c + cc + 0], v0);
-            v1 = fmaf(wq[r * c + cc + 1], d_a[o * c + cc + 1], v1);
-            v2 = fmaf(wq[r * c + cc + 2], d_a[o * c + cc + 2], v2);
-            v3 = fmaf(wq[r * c + cc + 3], d_a[o * c + cc + 3], v3);
-        }
-        for (; cc < c; ++cc) v0 = fmaf(wq[r * c + cc], d_a[o * c + cc], v0);
-        d_wk[f] = (v0 + v1) + (v2 + v3);
-    } else if (e < 2 * c2 + c) {        // d_bq[r] = sum_o wk[r][o] dp0[o]
+        const int f = e - c2, r = f / C, o = f % C;
+        float v[4] = {bq[r] * d_p0[o], 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) v[cc & 3] = fmaf(wq[r * C + cc], d_a[o * C + cc], v[cc & 3]);
+        d_wk[f] = (v[0] + v[1]) + (v[2] + v[3]);
+    } else if (e < 2 * c2 + C) {        // d_bq[r] = sum_o wk[r][o] dp0[o]
         const int r = e - 2 * c2;
         float v = 0.f;
-        for (int o = 0; o < c; ++o) v = fmaf(wk[r * c + o], d_p0[o], v);
+#pragma unroll
+        for (int o = 0; o < C; ++o) v = fmaf(wk[r * C + o], d_p0[o], v);
         d_bq[r] = v;
-    } else if (e < 2 * c2 + 2 * c) {
-        d_bk[e - 2 * c2 - c] = 0.f;
+    } else if (e < 2 * c2 + 2 * C) {
+        d_bk[e - 2 * c2 - C] = 0.f;
     }
 }
 
 // x0[i][4q..4q+3] = sum_k feats[i][k] w[4q+t][k] (+ b).  W^T sits in LDS as float4 per (k, q); C/4 consecutive
 // threads write one 4*C-byte row, and a thread keeps its q while it strides over nodes.
 #define GADAPT_ENC_MAX_WORDS 4096      /* C * F floats of LDS */
-__global__ __launch_bounds__(256) void encode_linear_kernel(const float* __restrict__ feats, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void encode_linear_kernel(const float* __restrict__ feats, int f0, const float* __restrict__ e1,
+                                                            const float* __restrict__ e2, const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ x0,
                                                             int64_t n_nodes, int f, int c) {
     __shared__ float4 wl[GADAPT_ENC_MAX_WORDS / 4];
@@ -1455,10 +1444,20 @@ __global__ __launch_bounds__(256) void encode_linear_kernel(const float* __restr
     const float4 bias = b ? *reinterpret_cast<const float4*>(b + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / c4; i < n_nodes; i += (int64_t)gridDim.x * rows_per_block) {
         float4 v = bias;
-        for (int k = 0; k < f; ++k) {
-            const float xv = feats[i * f + k];
+        // features of node i: the f0 columns of feats [N,f0], then the per-node scalars e1, e2 (GNN.py:227-239 concat)
+        const float x1 = e1 ? e1[i] : 0.f, x2 = e2 ? e2[i] : 0.f;
+        for (int k = 0; k < f0; ++k) {
+            const float xv = feats[i * f0 + k];
             const float4 wv = wl[k * c4 + q];
             v.x = fmaf(xv, wv.x, v.x); v.y = fmaf(xv, wv.y, v.y); v.z = fmaf(xv, wv.z, v.z); v.w = fmaf(xv, wv.w, v.w);
+        }
+        if (e1) {
+            const float4 wv = wl[f0 * c4 + q];
+            v.x = fmaf(x1, wv.x, v.x); v.y = fmaf(x1, wv.y, v.y); v.z = fmaf(x1, wv.z, v.z); v.w = fmaf(x1, wv.w, v.w);
+        }
+        if (e2) {
+            const float4 wv = wl[(f - 1) * c4 + q];
+            v.x = fmaf(x2, wv.x, v.x); v.y = fmaf(x2, wv.y, v.y); v.z = fmaf(x2, wv.z, v.z); v.w = fmaf(x2, wv.w, v.w);
         }
         *reinterpret_cast<float4*>(x0 + i * c + 4 * q) = v;
     }
@@ -1488,6 +1487,7 @@ __global__ void slab_reduce1_kernel(const float* slab, float* part, int n_rows, 
     const int per = (n_rows + GADAPT_SLAB_CHUNKS - 1) / GADAPT_SLAB_CHUNKS;
     const int r0 = blockIdx.y * per, r1 = min(n_rows, r0 + per);
     float v = 0.f;
+#pragma unroll 8
     for (int r = r0; r < r1; ++r) v += slab[(size_t)r * row_len + e];
     part[(size_t)blockIdx.y * row_len + e] = v;
 }
@@ -1523,6 +1523,47 @@ __global__ void mesh_loss_seed_kernel(const float* x_top, const float* target, f
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
     if (threadIdx.x == 0 && red[0] != 0.f) atomicAdd(loss_out, red[0]);
+}
+
+// loss = mean((pred - target)^2) or mean(|pred - target|) and seed = d loss / d pred in one launch.  Deterministic:
+// per-block partials, then the block that takes the last ticket adds them in index order.  scratch[0] is the ticket
+// counter (left at zero), scratch[1..] the partials.
+#define GADAPT_LOSS_BLOCKS 256
+__global__ __launch_bounds__(256) void loss_forward_kernel(const float* __restrict__ pred, int64_t pred_stride,
+                                                           const float* __restrict__ target, int64_t n_rows, int d, int l1,
+                                                           float* __restrict__ seed, float* __restrict__ loss_out, float* scratch) {
+    __shared__ float red[256];
+    __shared__ unsigned ticket;
+    const int64_t total = n_rows * d;
+    const float inv = 1.0f / (float)total;
+    float lv = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * 256) {   // one row per thread
+        for (int k = 0; k < d; ++k) {
+            const float diff = pred[i * pred_stride + k] - target[i * d + k];
+            if (l1) { lv += fabsf(diff); seed[i * d + k] = (diff > 0.f ? inv : (diff < 0.f ? -inv : 0.f)); }
+            else    { lv = fmaf(diff, diff, lv); seed[i * d + k] = 2.0f * diff * inv; }
+        }
+    }
+    red[threadIdx.x] = lv;
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(scratch + 1 + blockIdx.x, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        ticket = atomicAdd(reinterpret_cast<unsigned*>(scratch), 1u);
+    }
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    __threadfence();
+    float v = 0.f;
+    if (threadIdx.x < gridDim.x) v = __hip_atomic_load(scratch + 1 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        loss_out[0] = red[0] * inv;
+        *reinterpret_cast<unsigned*>(scratch) = 0u;            // ready for the next launch
+    }
 }
 
 __global__ void adam_step_kernel(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float b1, float b2,
@@ -1694,29 +1735,59 @@ extern "C" int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch,
 
 extern "C" int gadapt_coeffs_forward(const float* wq, const float* bq, const float* wk, float* a_out, float* p0_out, int c, void* stream) {
     if (!wq || !bq || !wk || !a_out || !p0_out || c <= 0) return fail(GADAPT_E_BADARG, "coeffs_forward: bad argument");
+    if (!gadapt_supported_hidden_dim(c)) return fail(GADAPT_E_BADARG, "coeffs_forward: unsupported hidden_dim");
     const int n = c * c + c;
-    hipLaunchKernelGGL(coeffs_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), wq, bq, wk, a_out, p0_out, c);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define GADAPT_COEFFS_F(CC) case CC: hipLaunchKernelGGL(coeffs_fwd_kernel<CC>, dim3((n + 255) / 256), dim3(256), 0, st, wq, bq, wk, a_out, p0_out); break;
+    switch (c) { GADAPT_COEFFS_F(4) GADAPT_COEFFS_F(8) GADAPT_COEFFS_F(16) GADAPT_COEFFS_F(32) GADAPT_COEFFS_F(64) GADAPT_COEFFS_F(128) default: break; }
+#undef GADAPT_COEFFS_F
     return check_launch("coeffs_fwd_kernel");
 }
 extern "C" int gadapt_coeffs_backward(const float* wq, const float* bq, const float* wk, const float* d_a, const float* d_p0,
                                       float* d_wq, float* d_bq, float* d_wk, float* d_bk, int c, void* stream) {
     if (!wq || !bq || !wk || !d_a || !d_p0 || !d_wq || !d_bq || !d_wk || !d_bk || c <= 0) return fail(GADAPT_E_BADARG, "coeffs_backward: bad argument");
+    if (!gadapt_supported_hidden_dim(c)) return fail(GADAPT_E_BADARG, "coeffs_backward: unsupported hidden_dim");
     const int n = 2 * c * c + 2 * c;
-    hipLaunchKernelGGL(coeffs_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), wq, bq, wk, d_a, d_p0,
-                       d_wq, d_bq, d_wk, d_bk, c);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define GADAPT_COEFFS_B(CC) case CC: hipLaunchKernelGGL(coeffs_bwd_kernel<CC>, dim3((n + 255) / 256), dim3(256), 0, st, wq, bq, wk, d_a, d_p0, d_wq, d_bq, d_wk, d_bk); break;
+    switch (c) { GADAPT_COEFFS_B(4) GADAPT_COEFFS_B(8) GADAPT_COEFFS_B(16) GADAPT_COEFFS_B(32) GADAPT_COEFFS_B(64) GADAPT_COEFFS_B(128) default: break; }
+#undef GADAPT_COEFFS_B
     return check_launch("coeffs_bwd_kernel");
 }
 
-extern "C" int gadapt_encode_linear(const float* feats, const float* w, const float* b, float* x0, int64_t n_nodes, int f, int c, void* stream) {
-    if (!feats || !w || !x0 || n_nodes <= 0 || f <= 0 || c <= 0) return fail(GADAPT_E_BADARG, "encode_linear: bad argument");
+static int launch_encode(const float* feats, int f0, const float* e1, const float* e2, const float* w, const float* b, float* x0,
+                         int64_t n_nodes, int c, void* stream) {
+    const int f = f0 + (e1 ? 1 : 0) + (e2 ? 1 : 0);
     if (c % 4 || c > 256 || 256 % (c / 4) || (int64_t)c * f > GADAPT_ENC_MAX_WORDS)
-        return fail(GADAPT_E_BADARG, "encode_linear: need hidden_dim in {4,8,...,256} dividing 1024 and hidden_dim*in_dim <= 4096");
+        return fail(GADAPT_E_BADARG, "encode: need hidden_dim in {4,8,...,256} dividing 1024 and hidden_dim*in_dim <= 4096");
     const int rows_per_block = 256 / (c / 4);
     int64_t blocks = (n_nodes + rows_per_block - 1) / rows_per_block;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(encode_linear_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), feats, w, b, x0, n_nodes, f, c);
+    hipLaunchKernelGGL(encode_linear_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), feats, f0, e1, e2, w, b,
+                       x0, n_nodes, f, c);
     return check_launch("encode_linear_kernel");
 }
+extern "C" int gadapt_encode_linear(const float* feats, const float* w, const float* b, float* x0, int64_t n_nodes, int f, int c, void* stream) {
+    if (!feats || !w || !x0 || n_nodes <= 0 || f <= 0 || c <= 0) return fail(GADAPT_E_BADARG, "encode_linear: bad argument");
+    return launch_encode(feats, f, nullptr, nullptr, w, b, x0, n_nodes, c, stream);
+}
+extern "C" int gadapt_encode_features(const float* x_comp, int dim, const float* f_tensor, const float* uu_tensor, const float* w,
+                                      const float* b, float* x0, int64_t n_nodes, int c, void* stream) {
+    if (!x_comp || !w || !x0 || n_nodes <= 0 || dim <= 0 || c <= 0) return fail(GADAPT_E_BADARG, "encode_features: bad argument");
+    // the kernel reads "first extra" then "second extra": with only uu present it is the first one
+    return launch_encode(x_comp, dim, f_tensor ? f_tensor : uu_tensor, f_tensor ? uu_tensor : nullptr, w, b, x0, n_nodes, c, stream);
+}
+extern "C" int gadapt_loss_forward(const float* pred, int64_t pred_stride, const float* target, int64_t n_rows, int d, int l1,
+                                   float* seed, float* loss_out, float* scratch, void* stream) {
+    if (!pred || !target || !seed || !loss_out || !scratch || n_rows <= 0 || d <= 0 || pred_stride < d)
+        return fail(GADAPT_E_BADARG, "loss_forward: bad argument");
+    int64_t blocks = (n_rows + 255) / 256;
+    if (blocks > GADAPT_LOSS_BLOCKS) blocks = GADAPT_LOSS_BLOCKS;
+    hipLaunchKernelGGL(loss_forward_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), pred, pred_stride, target,
+                       n_rows, d, l1, seed, loss_out, scratch);
+    return check_launch("loss_forward_kernel");
+}
+extern "C" int gadapt_loss_scratch_floats(void) { return GADAPT_LOSS_BLOCKS + 1; }
 
 extern "C" int gadapt_pad_columns(const float* g_phys, float* g_top, int64_t n_nodes, int d, int c, void* stream) {
     if (!g_phys || !g_top || n_nodes <= 0 || d <= 0 || d > c || c % 4) return fail(GADAPT_E_BADARG, "pad_columns: bad argument");

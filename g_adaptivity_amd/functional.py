@@ -108,7 +108,12 @@ class _GrandEulerBlock(torch.autograd.Function):
         scratch = torch.empty(32 * (c * c + c), device=dev, dtype=torch.float32)
         d_a = torch.empty(c, c, device=dev, dtype=torch.float32)
         d_p0 = torch.empty(c, device=dev, dtype=torch.float32)
-        d_wq, d_bq, d_wk, d_bk = (torch.empty_like(t) for t in (wq, bq, wk, bq))
+        # one flat tensor [dWq | dbq | dWk | dbk]: installed as the parameters' .grad without a copy, it is the
+        # gradient bucket of optim.FlatAdam (one Adam launch, one all-reduce)
+        flat = torch.empty(S * (2 * c * c + 2 * c), device=dev, dtype=torch.float32)
+        cuts = [0, S * c * c, S * (c * c + c), S * (2 * c * c + c), S * (2 * c * c + 2 * c)]
+        d_wq, d_wk = flat[cuts[0]:cuts[1]].view(S, c, c), flat[cuts[2]:cuts[3]].view(S, c, c)
+        d_bq, d_bk = flat[cuts[1]:cuts[2]].view(S, c), flat[cuts[3]:cuts[4]].view(S, c)
         for s in range(S):
             check(lib().gadapt_slab_reduce(ptr(slab[s]), slab_rows, ptr(scratch), ptr(d_a), ptr(d_p0), c, st),
                   'gadapt_slab_reduce')
@@ -205,3 +210,67 @@ def encode_linear(feats: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
                                      ptr(bias.contiguous()) if bias is not None else None,
                                      ptr(x0), n, f, c, current_stream(feats.device)), 'gadapt_encode_linear')
     return x0
+
+
+def encode_features(x_comp: torch.Tensor, f_tensor: Optional[torch.Tensor], uu_tensor: Optional[torch.Tensor],
+                    weight: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x0 = enc([x_comp | f | uu]) (`src/GNN.py:225-239,270`) without materialising the concatenated feature matrix."""
+    _require_gpu(x_comp, 'x_comp')
+    n, dim = x_comp.shape
+    c = weight.shape[0]
+    for t, name in ((f_tensor, 'f_tensor'), (uu_tensor, 'uu_tensor')):
+        if t is not None:
+            _require_gpu(t, name)
+            if t.shape != (n,) or not t.is_contiguous():
+                raise ValueError(f"{name}: expected a dense [{n}] tensor, got {tuple(t.shape)}")
+    if weight.shape[1] != dim + (f_tensor is not None) + (uu_tensor is not None):
+        raise ValueError(f"encoder weight has {weight.shape[1]} input columns for {dim} coordinates + extras")
+    x0 = torch.empty(n, c, device=x_comp.device, dtype=torch.float32) if out is None else out
+    assert x0.shape == (n, c) and x0.is_contiguous()
+    check(lib().gadapt_encode_features(ptr(x_comp.contiguous()), dim, ptr(f_tensor), ptr(uu_tensor), ptr(weight.contiguous()),
+                                       ptr(bias.contiguous()) if bias is not None else None, ptr(x0), n, c,
+                                       current_stream(x_comp.device)), 'gadapt_encode_features')
+    return x0
+
+
+_loss_scratch = {}
+
+
+class _MeshLoss(torch.autograd.Function):
+    """mean((pred-target)^2) / mean(|pred-target|) with the derivative produced by the same launch."""
+
+    @staticmethod
+    def forward(ctx, pred, target, l1: bool):
+        _require_gpu(pred, 'loss input')
+        _require_gpu(target, 'loss target')
+        if pred.shape != target.shape or pred.dim() != 2:
+            raise ValueError(f"loss: shapes {tuple(pred.shape)} vs {tuple(target.shape)} (expected equal [N,d])")
+        if pred.stride(1) != 1:
+            pred = pred.contiguous()
+        n, d = pred.shape
+        dev = pred.device
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        scratch = _loss_scratch.get(key)
+        if scratch is None:
+            scratch = _loss_scratch[key] = torch.zeros(lib().gadapt_loss_scratch_floats(), device=dev, dtype=torch.float32)
+        seed = torch.empty(n, d, device=dev, dtype=torch.float32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        check(lib().gadapt_loss_forward(pred.data_ptr(), pred.stride(0), ptr(target.contiguous()), n, d, int(bool(l1)), ptr(seed),
+                                        ptr(loss), ptr(scratch), current_stream(dev)), 'gadapt_loss_forward')
+        ctx.save_for_backward(seed)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (seed,) = ctx.saved_tensors
+        return seed * g, None, None
+
+
+def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """`F.mse_loss(out, data.x_phys)` of the training loop (`src/run_GNN.py:80-84,106`) as one launch (value + derivative)."""
+    return _MeshLoss.apply(pred, target, False)
+
+
+def l1_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """`F.l1_loss(out, data.x_phys)` (`src/run_GNN.py:82`) as one launch."""
+    return _MeshLoss.apply(pred, target, True)

@@ -166,28 +166,38 @@ class GNN(nn.Module):
         x_comp = data.x_comp.to(dev, non_blocking=True)
         if self.dim == 1 and x_comp.dim() == 1:
             x_comp = x_comp.unsqueeze(-1)                                  # GNN.py:225-226
-        feats = [x_comp]
+        f = uu = None
         if o['gnn_inc_feat_f']:
             f = data.f_tensor.to(dev, non_blocking=True)
-            feats.append((f / torch.max(f) if o.get('gnn_normalize') else f).unsqueeze(-1))    # GNN.py:230-233
+            f = f / torch.max(f) if o.get('gnn_normalize') else f          # GNN.py:230-233
         if o['gnn_inc_feat_uu']:
             uu = data.uu_tensor.to(dev, non_blocking=True)
-            feats.append((uu / torch.max(uu) if o.get('gnn_normalize') else uu).unsqueeze(-1))  # GNN.py:235-238
-        features = torch.cat(feats, dim=1).float()
-        n = features.shape[0]
+            uu = uu / torch.max(uu) if o.get('gnn_normalize') else uu      # GNN.py:235-238
+        n = x_comp.shape[0]
         graph = self._graph(data, n, dev)
+
+        def features():                                                    # the concatenated matrix, only where a caller needs it
+            return torch.cat([x_comp] + [t.unsqueeze(-1) for t in (f, uu) if t is not None], dim=1).float()
 
         fusable = self._fusable()
         x_all, sliced = None, False
+        feats = None
         if isinstance(self.enc, nn.Linear) and not self.enc.weight.requires_grad and self.enc.bias is None:
+            native_in = all(t is None or (t.dtype == torch.float32 and t.dim() == 1) for t in (f, uu)) and x_comp.dtype == torch.float32
             if fusable and not (self.training and o.get('dropout', 0.0) > 0):
                 # encoder output lands in slot 0 of the block's activation buffer: no copy
                 x_all = torch.empty(o['num_layers'] + 1, n, o['hidden_dim'], device=dev, dtype=torch.float32)
-                x = Fn.encode_linear(features, self.enc.weight, out=x_all[0])              # GNN.py:270
+                out0 = x_all[0]
             else:
-                x = Fn.encode_linear(features, self.enc.weight)
+                out0 = None
+            if native_in:                                                  # GNN.py:225-239 + :270 in one launch
+                x = Fn.encode_features(x_comp, f, uu, self.enc.weight, out=out0)
+            else:
+                feats = features()
+                x = Fn.encode_linear(feats, self.enc.weight, out=out0)
         else:
-            x = self.enc(features)
+            feats = features()
+            x = self.enc(feats)
         if x_all is None:
             x = F.dropout(x, o.get('dropout', 0.0), training=self.training)               # GNN.py:271
 
@@ -212,7 +222,7 @@ class GNN(nn.Module):
         else:
             for i, layer in enumerate(self.conv_layers):                  # GNN.py:273-296, layer by layer
                 if o['residual'] and o['conv_type'] == 'GRAND_plus':
-                    res = layer(x, graph.edge_index, features, getattr(self.dataset, 'mesh', None), graph=graph)
+                    res = layer(x, graph.edge_index, feats if feats is not None else features(), getattr(self.dataset, 'mesh', None), graph=graph)
                 else:
                     res = layer(x, graph.edge_index, graph=graph)
                     res = self.non_lin(F.dropout(res, o.get('dropout', 0.0), training=self.training))

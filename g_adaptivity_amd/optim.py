@@ -2,7 +2,8 @@
 
 `torch.optim.Adam(model.parameters(), lr, weight_decay)` followed by `.step()` is what the
 reference runs after backward (`src/run_GNN.py:88,126-131`).  Here the parameters that receive
-gradients live in ONE contiguous fp32 bucket (their `.data` / `.grad` are views of it), so a
+gradients live in ONE contiguous fp32 bucket (their `.data` are views of it, their `.grad` are views
+of the flat gradient tensor the block op returns), so a
 step is one native kernel (`gadapt_adam_step`) and, under data parallelism, one RCCL
 all-reduce of the bucket (2(C^2+C) floats with shared weights) with the
 1/world scaling folded into the Adam kernel.  Parameters that never receive a gradient
@@ -26,6 +27,16 @@ def shard_range(n_items: int, rank: int, world: int):
 
 
 class FlatAdam:
+    """Adam over ONE flat fp32 bucket.
+
+    The block op returns its weight gradients as slices of one freshly allocated flat tensor
+    (`functional._GrandEulerBlock.backward`), which autograd installs as `.grad` without a copy when `.grad` is
+    None (zero_grad's default).  `step()` then finds every gradient at its expected offset of one storage and
+    hands that memory to the kernel as the gradient bucket: no per-parameter accumulate kernels, no zero fill.
+    Any other situation (gradients accumulated over several backward calls, parameters from elsewhere) is
+    handled by gathering the gradients into an own bucket first.
+    """
+
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, process_group=None, reduce_op: str = 'mean'):
         seen, self.params = set(), []
@@ -37,34 +48,84 @@ class FlatAdam:
         self.group, self.reduce_op = process_group, reduce_op
         self.step_count = 0
         self.bucket: Optional[torch.Tensor] = None
-        self.grad_bucket: Optional[torch.Tensor] = None
+        self.grad_bucket: Optional[torch.Tensor] = None    # the flat gradient the last step()/_build() used
+        self._own_grad: Optional[torch.Tensor] = None
         self.active: List[torch.nn.Parameter] = []
+        self.offsets: List[int] = []
+
+    @staticmethod
+    def _shared_offsets(params) -> Optional[List[int]]:
+        """Element offsets of every .grad inside one storage if they tile a gap-free range of it, else None."""
+        g0 = params[0].grad
+        if g0 is None:
+            return None
+        store = g0.untyped_storage().data_ptr()
+        offs = []
+        for p in params:
+            g = p.grad
+            if (g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape
+                    or g.untyped_storage().data_ptr() != store):
+                return None
+            offs.append(g.storage_offset())
+        order = sorted(range(len(params)), key=lambda i: offs[i])
+        pos = offs[order[0]]
+        for i in order:
+            if offs[i] != pos:
+                return None                                # gap or overlap
+            pos += params[i].numel()
+        return offs
 
     def _build(self):
         self.active = [p for p in self.params if p.grad is not None]
         if not self.active:
             raise RuntimeError("FlatAdam.step() before any backward()")
         dev = self.active[0].device
+        shared = self._shared_offsets(self.active)
+        if shared is not None:                             # bucket laid out like the gradient storage
+            base = min(shared)
+            self.active = [p for _, p in sorted(zip(shared, self.active), key=lambda t: t[0])]
+            self.offsets = sorted(o - base for o in shared)
+        else:
+            self.offsets, off = [], 0
+            for p in self.active:
+                self.offsets.append(off)
+                off += p.numel()
         n = sum(p.numel() for p in self.active)
         self.bucket = torch.empty(n, device=dev, dtype=torch.float32)
-        self.grad_bucket = torch.empty(n, device=dev, dtype=torch.float32)
-        off = 0
-        for p in self.active:
+        for p, off in zip(self.active, self.offsets):
             k = p.numel()
             self.bucket[off:off + k].copy_(p.data.reshape(-1))
-            self.grad_bucket[off:off + k].copy_(p.grad.reshape(-1))
             p.data = self.bucket[off:off + k].view_as(p)
-            p.grad = self.grad_bucket[off:off + k].view_as(p)
-            off += k
         self.exp_avg = torch.zeros_like(self.bucket)
         self.exp_avg_sq = torch.zeros_like(self.bucket)
+        self.grad_bucket = self._flat_grad()
 
-    def zero_grad(self, set_to_none: bool = False):
-        if self.grad_bucket is None:
-            for p in self.params:
+    def _flat_grad(self) -> torch.Tensor:
+        """The gradients as one flat tensor in bucket order: a view when they already are one, else a gathered copy."""
+        g0 = self.active[0].grad
+        if g0 is not None:
+            store, start = g0.untyped_storage().data_ptr(), g0.storage_offset() - self.offsets[0]
+            if start >= 0 and all(
+                    p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.shape == p.shape
+                    and p.grad.untyped_storage().data_ptr() == store and p.grad.storage_offset() == start + off
+                    for p, off in zip(self.active, self.offsets)):
+                return g0.as_strided((self.bucket.numel(),), (1,), start)
+        if self._own_grad is None:
+            self._own_grad = torch.zeros_like(self.bucket)
+        for p, off in zip(self.active, self.offsets):
+            dst = self._own_grad[off:off + p.numel()]
+            if p.grad is None:
+                dst.zero_()
+            else:
+                dst.copy_(p.grad.reshape(-1))
+        return self._own_grad
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if set_to_none or p.grad is None:
                 p.grad = None
-        else:
-            self.grad_bucket.zero_()                       # views stay attached: autograd accumulates in place
+            else:
+                p.grad.zero_()
 
     def all_reduce(self):
         """SUM over ranks on the flat bucket (one RCCL collective over xGMI)."""
@@ -77,6 +138,8 @@ class FlatAdam:
     def step(self):
         if self.bucket is None:
             self._build()
+        else:
+            self.grad_bucket = self._flat_grad()
         world = self.all_reduce()
         scale = 1.0 / world if self.reduce_op == 'mean' else 1.0       # 'sum' for the modular pseudo-loss (run_GNN.py:118)
         self.step_count += 1

@@ -90,6 +90,11 @@ int gadapt_coeffs_backward(const float* wq, const float* bq, const float* wk,
  * x0 = feats @ W^T (+ b): get_enc (GNN.py:72-98, call :270).  feats [N,F], W [C,F]. */
 int gadapt_encode_linear(const float* feats, const float* w, const float* b /*nullable*/,
                          float* x0, int64_t n_nodes, int f, int c, void* stream);
+/* Same with the feature assembly of GNN.py:225-239 folded in: the node feature vector is
+ * [x_comp[i, 0..dim), f_tensor[i] (if given), uu_tensor[i] (if given)], W [C, dim + extras]. */
+int gadapt_encode_features(const float* x_comp, int dim, const float* f_tensor /*nullable*/,
+                           const float* uu_tensor /*nullable*/, const float* w, const float* b /*nullable*/,
+                           float* x0, int64_t n_nodes, int c, void* stream);
 
 /* ------------------------------------------------------------------ one layer
  * layer_params (device, 2 floats): {dt, score_scale} with score_scale = 1/(sqrt(C)*T).
@@ -152,6 +157,15 @@ int gadapt_block_backward(const gadapt_graph* g, const float* x_all, const float
 int gadapt_mesh_loss_seed(const float* x_top, const float* target, float* x_phys, float* g_top,
                           float* loss_out, int64_t n_nodes, int d, int c, int l1, float grad_scale,
                           void* stream);
+
+/* The training loop's loss, F.mse_loss / F.l1_loss(out, data.x_phys) with reduction 'mean'
+ * (run_GNN.py:80-84,106), forward AND its derivative in one launch: pred [N,d] with a row stride of
+ * pred_stride floats (the x[:, :dim] view of GNN.py:299 is not dense), target [N,d] dense;
+ * loss_out[0] = the loss (fixed summation order), seed [N,d] = d loss / d pred.
+ * scratch: gadapt_loss_scratch_floats() floats, zero-filled once by the caller; left zero-filled. */
+int gadapt_loss_forward(const float* pred, int64_t pred_stride, const float* target, int64_t n_rows, int d,
+                        int l1, float* seed, float* loss_out, float* scratch, void* stream);
+int gadapt_loss_scratch_floats(void);
 
 /* Backward of the slice x_phys = x_top[:, :d] (GNN.py:299): g_top [N,C] = g_phys [N,d] zero-padded. */
 int gadapt_pad_columns(const float* g_phys, float* g_top, int64_t n_nodes, int d, int c, void* stream);

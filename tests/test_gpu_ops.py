@@ -226,3 +226,76 @@ def test_full_size_properties(gpu_device):
     assert torch.equal(a[:, :2], out) and torch.equal(z, xin)
     for col in range(4):                                                 # live columns: x, y, f, uu
         assert rel_err(a[:, col], b[:, col])[0] <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('l1', [False, True])
+def test_native_loss_matches_torch(gpu_device, l1):
+    from g_adaptivity_amd import l1_loss, mse_loss
+    torch.manual_seed(1)
+    n, C, d = 4099, 16, 2
+    x_top = torch.randn(n, C, device=gpu_device)
+    tgt = torch.randn(n, d, device=gpu_device)
+    for trial in range(3):                                  # the ticket counter must come back to zero every time
+        a = x_top.clone().requires_grad_(True)
+        b = x_top.clone().requires_grad_(True)
+        ours = (l1_loss if l1 else mse_loss)(a[:, :d], tgt)             # strided view, as GNN returns it
+        ref = (F.l1_loss if l1 else F.mse_loss)(b[:, :d], tgt)
+        (3.0 * ours).backward(); (3.0 * ref).backward()
+        assert torch.allclose(ours, ref, rtol=1e-5)
+        assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-12)
+    again = (l1_loss if l1 else mse_loss)(x_top[:, :d], tgt)
+    assert torch.equal(again, ours.detach())                # fixed summation order: bit-identical repeats
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('with_f,with_uu', [(True, True), (True, False), (False, True), (False, False)])
+def test_encode_features_equals_concat_then_linear(gpu_device, with_f, with_uu):
+    from g_adaptivity_amd import functional as Fn
+    torch.manual_seed(2)
+    n, dim, C = 1237, 2, 64
+    xc = torch.randn(n, dim, device=gpu_device)
+    f = torch.randn(n, device=gpu_device) if with_f else None
+    uu = torch.randn(n, device=gpu_device) if with_uu else None
+    cols = [xc] + [t.unsqueeze(-1) for t in (f, uu) if t is not None]
+    feats = torch.cat(cols, dim=1)
+    w = torch.randn(C, feats.shape[1], device=gpu_device)
+    ours = Fn.encode_features(xc, f, uu, w)
+    ref = Fn.encode_linear(feats, w)
+    assert torch.equal(ours, ref)
+    assert torch.allclose(ours, feats @ w.t(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_flat_adam_adopts_the_block_gradient_tensor(gpu_device):
+    """After backward the four weight gradients are views of one tensor; FlatAdam steps on that memory directly."""
+    from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt, mse_loss
+    opt = hot_path_opt(mesh_dims=[9, 9], hidden_dim=16, num_layers=2, device=str(gpu_device), show_mesh_evol_plots='False')
+    ds = MeshDataset([9, 9], 4, seed=0)
+    data = collate(ds.samples).to(gpu_device)
+    torch.manual_seed(0)
+    model = GNN(ds, opt).to(gpu_device).train()
+    twin = GNN(ds, opt).to(gpu_device).train()
+    twin.load_state_dict(model.state_dict())
+    ours = FlatAdam(model.parameters(), lr=1e-2)
+    ref = torch.optim.Adam([p for p in twin.parameters() if p.requires_grad], lr=1e-2)
+    for step in range(3):
+        ours.zero_grad(); ref.zero_grad()
+        mse_loss(model(data), data.x_phys).backward()
+        F.mse_loss(twin(data), data.x_phys).backward()
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        assert len({g.untyped_storage().data_ptr() for g in grads}) == 1
+        ours.step(); ref.step()
+        assert ours.grad_bucket.untyped_storage().data_ptr() == grads[0].untyped_storage().data_ptr()
+    torch.cuda.synchronize()
+    for (k, p), q in zip(model.named_parameters(), twin.parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), k
+    # gradients accumulated over two backward calls: no longer one tensor -> gathered copy, same result as torch
+    ours.zero_grad(); ref.zero_grad()
+    for _ in range(2):
+        mse_loss(model(data), data.x_phys).backward()
+        F.mse_loss(twin(data), data.x_phys).backward()
+    ours.step(); ref.step()
+    torch.cuda.synchronize()
+    for (k, p), q in zip(model.named_parameters(), twin.parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), k
