@@ -212,10 +212,44 @@ __device__ __forceinline__ TileChunk tile_chunk(int n_tiles) {
 // permuted so each lane-half reads 16 contiguous bytes of its IN row per 4 MFMAs (half h owns
 // k in {8q+4h .. 8q+4h+3}); any permutation is valid as long as A and B agree.
 // ------------------------------------------------------------------------------------------------
+#ifndef GADAPT_GEMM_SPLIT
+#define GADAPT_GEMM_SPLIT 1
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// fp32 values on the bf16 matrix cores without losing fp32 accuracy: x = h + m + l exactly, three bf16 pieces of 8
+// mantissa bits each (truncation; every subtraction is exact).  A product x*y keeps the six piece products down to
+// 2^-16 relative (hh, hm, mh, mm, hl, lh); the dropped ones (ml, lm, ll) are below 2^-23 of |x*y|, the rounding
+// level of an fp32 product, and every piece product is exact in the fp32 accumulator.  v_mfma_f32_32x32x16_bf16
+// does 16x the work of v_mfma_f32_32x32x2_f32 in half its cycles, so six of them per 16 k cost 3/8 of the fp32 form.
+struct Split3 { u32x4 h, m, l; };
+__device__ __forceinline__ Split3 split8(const float (&x)[8]) {
+    float r[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        r[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xFFFF0000u);
+        r2[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xFFFF0000u);
+    }
+    Split3 s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                       // element 2q in the low half, 2q+1 in the high half
+        s.h[q] = __builtin_amdgcn_perm(__float_as_uint(x[2 * q + 1]), __float_as_uint(x[2 * q]), 0x07060302u);
+        s.m[q] = __builtin_amdgcn_perm(__float_as_uint(r[2 * q + 1]), __float_as_uint(r[2 * q]), 0x07060302u);
+        s.l[q] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * q + 1]), __float_as_uint(r2[2 * q]), 0x07060302u);
+    }
+    return s;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 template <int C, bool TRANS> struct TileGemm {
     using K = Cfg<C>;
     static constexpr int BPW = (K::CB * K::RB) / 4;    // 32x32 output blocks per wave
-    float bf[C / 2];
+    static constexpr bool SPLIT = GADAPT_GEMM_SPLIT && C <= 64;   // wider C: the split B fragments do not fit the registers
+    static constexpr int KS = C / 16;                  // k-steps of the bf16 form
+    float bf[SPLIT ? 1 : C / 2];
+    Split3 bs[SPLIT ? KS : 1];
     float bias;
     int cb, rb0, lane;
 
@@ -224,18 +258,34 @@ template <int C, bool TRANS> struct TileGemm {
         cb = wave % K::CB;
         rb0 = wave / K::CB;
     }
-    // Issue the B-operand loads ([C,C] matrix: L2-resident, same lines for every workgroup).  Called per
-    // tile, ahead of the barrier that precedes run(), so the fragments occupy registers only around the GEMM.
+    // Issue the B-operand loads ([C,C] matrix: L2-resident, same lines for every workgroup).
     __device__ __forceinline__ void load(const float* __restrict__ M, const float* __restrict__ bias_vec) {
         const int h = lane >> 5, j = cb * 32 + (lane & 31);
+        if constexpr (SPLIT) {
+            // lane (j, h) holds B[k][j] for k = 16 ks + 8 h + e, e = 0..7 (both operands use this k order)
 #pragma unroll
-        for (int q = 0; q < C / 8; ++q) {
-            if (!TRANS) {
-                const float4 v = *reinterpret_cast<const float4*>(M + (size_t)j * C + 8 * q + 4 * h);
-                bf[4 * q + 0] = v.x; bf[4 * q + 1] = v.y; bf[4 * q + 2] = v.z; bf[4 * q + 3] = v.w;
-            } else {
+            for (int ks = 0; ks < KS; ++ks) {
+                float v[8];
+                if (!TRANS) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(M + (size_t)j * C + 16 * ks + 8 * h);
+                    const float4 v1 = *reinterpret_cast<const float4*>(M + (size_t)j * C + 16 * ks + 8 * h + 4);
+                    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+                } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bf[4 * q + t] = M[(size_t)(8 * q + 4 * h + t) * C + j];
+                    for (int e = 0; e < 8; ++e) v[e] = M[(size_t)(16 * ks + 8 * h + e) * C + j];
+                }
+                bs[ks] = split8(v);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < C / 8; ++q) {
+                if (!TRANS) {
+                    const float4 v = *reinterpret_cast<const float4*>(M + (size_t)j * C + 8 * q + 4 * h);
+                    bf[4 * q + 0] = v.x; bf[4 * q + 1] = v.y; bf[4 * q + 2] = v.z; bf[4 * q + 3] = v.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bf[4 * q + t] = M[(size_t)(8 * q + 4 * h + t) * C + j];
+                }
             }
         }
         bias = bias_vec ? bias_vec[j] : 0.f;
@@ -249,14 +299,31 @@ template <int C, bool TRANS> struct TileGemm {
             const int rb = rb0 + b * (4 / K::CB);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-            const float* arow = in_tile + (rb * 32 + r31) * K::LD + 4 * h;
+            if constexpr (SPLIT) {
+                const float* arow = in_tile + (rb * 32 + r31) * K::LD + 8 * h;
 #pragma unroll
-            for (int q = 0; q < C / 8; ++q) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + 8 * q);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bf[4 * q + 0], acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bf[4 * q + 1], acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bf[4 * q + 2], acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bf[4 * q + 3], acc[b], 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * ks);
+                    const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * ks + 4);
+                    const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    const Split3 as = split8(v);
+                    acc[b] = mfma_bf16(as.h, bs[ks].l, acc[b]);         // small pieces first
+                    acc[b] = mfma_bf16(as.l, bs[ks].h, acc[b]);
+                    acc[b] = mfma_bf16(as.m, bs[ks].m, acc[b]);
+                    acc[b] = mfma_bf16(as.h, bs[ks].m, acc[b]);
+                    acc[b] = mfma_bf16(as.m, bs[ks].h, acc[b]);
+                    acc[b] = mfma_bf16(as.h, bs[ks].h, acc[b]);
+                }
+            } else {
+                const float* arow = in_tile + (rb * 32 + r31) * K::LD + 4 * h;
+#pragma unroll
+                for (int q = 0; q < C / 8; ++q) {
+                    const float4 a = *reinterpret_cast<const float4*>(arow + 8 * q);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bf[4 * q + 0], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bf[4 * q + 1], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bf[4 * q + 2], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bf[4 * q + 3], acc[b], 0, 0, 0);
+                }
             }
         }
     }
@@ -1062,7 +1129,34 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             __syncthreads();
             GADAPT_STAMP(p.stamps, tslot + 4);
             // ---- dA partial:  dA[o][c] += sum_node dP[node][o] x[node][c]
-            if constexpr (K::MFMA) {
+            if constexpr (K::MFMA && TileGemm<C, true>::SPLIT) {
+                // bf16 three-piece form (see split8): k = node, 16 nodes per step; lane (i, h) feeds nodes 8h..8h+7 of the step
+                const int h = lane >> 5, r31 = lane & 31;
+                constexpr int NODES = (NB2 >= 4) ? K::TM : K::TM / 4;   // one 32x32 block: the waves split the nodes
+                const int nbase = (NB2 >= 4) ? 0 : wave * NODES;
+                const int ob = (NB2 >= 4) ? (wave * DPW) / K::CB : 0, cb0 = (NB2 >= 4) ? (wave * DPW) % K::CB : 0;
+#pragma unroll 2
+                for (int ks = 0; ks < NODES / 16; ++ks) {
+                    const int n0 = nbase + 16 * ks + 8 * h;
+                    float av[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) av[e] = ds[(n0 + e) * K::LD + ob * 32 + r31];
+                    const Split3 as = split8(av);
+#pragma unroll
+                    for (int b = 0; b < DPW; ++b) {
+                        float bv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bv[e] = xs[(n0 + e) * K::LD + (cb0 + b) * 32 + r31];
+                        const Split3 bs = split8(bv);
+                        dacc[b] = mfma_bf16(as.h, bs.l, dacc[b]);
+                        dacc[b] = mfma_bf16(as.l, bs.h, dacc[b]);
+                        dacc[b] = mfma_bf16(as.m, bs.m, dacc[b]);
+                        dacc[b] = mfma_bf16(as.h, bs.m, dacc[b]);
+                        dacc[b] = mfma_bf16(as.m, bs.h, dacc[b]);
+                        dacc[b] = mfma_bf16(as.h, bs.h, dacc[b]);
+                    }
+                }
+            } else if constexpr (K::MFMA) {
                 const int h = lane >> 5, r31 = lane & 31;
                 if constexpr (NB2 >= 4) {
                     // wave owns o-block `ob` and DPW consecutive c-blocks
