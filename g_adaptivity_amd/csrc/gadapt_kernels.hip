@@ -1339,6 +1339,11 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
 #pragma unroll
     for (int q = 0; q < K::NV; ++q) p0v.v[q] = *reinterpret_cast<const float4*>(p.p0 + 4 * (sub + q * K::LPN));
 
+#ifndef GADAPT_S_RESIDENT_B
+#define GADAPT_S_RESIDENT_B 1
+#endif
+    constexpr bool RESIDENT_B = K::MFMA && TileGemm<C, false>::SPLIT && GADAPT_S_RESIDENT_B;   // split fragments: built once per launch
+    if constexpr (RESIDENT_B) gemm.load(p.A, nullptr);
     const TileRange tr = tile_range(p.n_tiles);
     typename TileCsr<C, 2>::Regs sr;
     csr.load_metas(tr.t, tr.step, p.n_tiles, tid);
@@ -1424,7 +1429,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
             }
         }
         GADAPT_STAMP(p.stamps, tslot + 2);
-        if constexpr (K::MFMA) gemm.load(p.A, nullptr);         // in flight under the barrier
+        if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, nullptr);   // in flight under the barrier
         V dpre[K::ITERS];                                       // own dxd rows: requested here, used after the GEMM
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) dpre[it] = ld_vec<C>(p.dxd, min(node0 + it * K::SLOTS + slot, p.n_nodes - 1), sub);
