@@ -130,7 +130,9 @@ template <int C> struct Cfg {
     // LDS: `tiles` [TM][LD] tiles, rowptr[TM+1] (padded to TM+4), col[COLN], aux[AUXW*COLN]
     static constexpr int MAXM = 64;                    // tile-metadata words of this workgroup's tiles kept in LDS
     static constexpr int lds_bytes(int auxw, int tiles = 2, int ext = 0) { return (tiles * TILE_FLOATS + (TM + 4) + COLN + (auxw + ext) * COLN + 4 * MAXM) * 4; }
-    static constexpr int RING = 3;                     // LDS slabs of x rows kept by the rolling-window kernels
+    static constexpr int RING = (C <= 64) ? 3 : 1;     // LDS slabs of x rows kept by the rolling-window kernels; C = 128: a
+                                                       //   3-slab window would leave one workgroup per CU, so only the tile itself
+    static constexpr int LEAD = (RING == 3) ? 1 : 0;   // the slab staged during tile t is slab t + LEAD
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
         p0v = *reinterpret_cast<const float4*>(p.p0 + 4 * sub);
     }
 
-    auto projected = [&](int li) {                               // P_i = A x_i + p0 for this lane's channels
+    auto projected = [&](int li) __attribute__((always_inline)) {                               // P_i = A x_i + p0 for this lane's channels
         V Pi;
         if constexpr (K::MFMA) {
             Pi = lds_vec<C>(ps, li, sub);
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
         }
         return Pi;
     };
-    auto finish = [&](int li, int i, const V& m) {               // res = m - x (GRAND_plus.py:267); x + dt*res (GNN.py:291)
+    auto finish = [&](int li, int i, const V& m) __attribute__((always_inline)) {               // res = m - x (GRAND_plus.py:267); x + dt*res (GNN.py:291)
         const V xi = lds_vec<C>(xs, li, sub);
         V o;
 #pragma unroll
@@ -728,7 +730,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     // WIN (compile time): the tile gathers from the LDS ring (col holds ring offsets) or from HBM/L2.  The two
     // variants must not share a join point: a pending-global-load possibility on one side makes hipcc put
     // s_waitcnt vmcnt(0) in front of every use of the rows on the other side too.
-    auto fetch = [&](auto& b, int node0, int it, auto win_tag) {
+    auto fetch = [&](auto& b, int node0, int it, auto win_tag) __attribute__((always_inline)) {
         constexpr int DM = std::remove_reference_t<decltype(b)>::N;
         constexpr bool WIN = decltype(win_tag)::value != 0;
         const int li = it * K::SLOTS + slot;
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
         }
     };
 
-    auto consume = [&](const auto& b, int node0, int it) {
+    auto consume = [&](const auto& b, int node0, int it) __attribute__((always_inline)) {
         constexpr int DM = std::remove_reference_t<decltype(b)>::N;
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     };
 
     // any row length, CSR straight from HBM: three sweeps over the row
-    auto slow_node = [&](int node0, int it) {
+    auto slow_node = [&](int node0, int it) __attribute__((always_inline)) {
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
         if (i >= p.n_nodes) return;
@@ -819,44 +821,65 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     const TileChunk ch = tile_chunk(p.n_tiles);
     if (ch.t0 >= ch.t1) return;
     stagger_start<GADAPT_STAGGER_FWD>();
-    auto slab_ptr = [&](int s_) { return ring + ((s_ + K::RING) % K::RING) * K::TILE_FLOATS; };
+    auto slab_ptr = [&](int s_) __attribute__((always_inline)) { return ring + ((s_ + K::RING) % K::RING) * K::TILE_FLOATS; };
     // Staging runs TWO tiles ahead (two register sets, used alternately): every workgroup of the launch requests
     // its next slab at the same moment, so one tile of compute does not cover that burst.
+    // C = 128 does not have the registers for that (nor for resident B fragments): one set, one tile ahead.
+    constexpr int AHEAD = (C <= 64) ? 2 : 1;
+    constexpr bool RESIDENT_B = (C <= 64);
     typename TileCsr<C, 0>::Regs srA, srB;
     TileRows<C> xrA, xrB;
-    if constexpr (K::MFMA) gemm.load(p.A, p.p0);                 // B fragments stay in registers for the whole launch
+    if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, p.p0);   // B fragments stay in registers for the whole launch
     csr.load_metas(ch.t0, 1, p.n_tiles, tid);
-    xrA.issue(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
-    xrA.issue(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0), p.n_nodes, tid);
+    if constexpr (K::RING == 3) {
+        xrA.issue(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
+        xrA.issue(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0), p.n_nodes, tid);
+    }
     __syncthreads();                                             // tile metadata visible
-    xrA.issue(p.x_in, (ch.t0 + 1) * K::TM, p.n_nodes, tid);      // rows past N come back as zeros
+    xrA.issue(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);   // rows past N come back as zeros
     csr.issue(srA, 0, ch.t0 * K::TM, p.n_nodes, tid);
-    xrB.issue(p.x_in, (ch.t0 + 2) * K::TM, p.n_nodes, tid);
-    csr.issue(srB, 1, (ch.t0 + 1) * K::TM, p.n_nodes, tid);
+    if constexpr (AHEAD == 2) {
+        xrB.issue(p.x_in, (ch.t0 + 2) * K::TM, p.n_nodes, tid);
+        csr.issue(srB, 1, (ch.t0 + 1) * K::TM, p.n_nodes, tid);
+    }
 
     // Order inside a tile: GEMM first (its A operand, slab t, was committed during tile t-1; B fragments are
     // resident), THEN commit the prefetched slab t+1 / CSR slice of tile t.  vmcnt is in-order and hipcc waits
     // conservatively (vmcnt(0)) before the commit reads the prefetch registers, so anything still in flight -
     // the previous tile's output stores included - is paid for there: behind the MFMA phase it is (mostly) free.
-    auto do_tile = [&](int t, TileRows<C>& xr, typename TileCsr<C, 0>::Regs& sr) {
+    auto do_tile = [&](int t, TileRows<C>& xr, typename TileCsr<C, 0>::Regs& sr) __attribute__((always_inline)) {
         const int node0 = t * K::TM;
         const int tslot = (t - ch.t0) * 8;                      // stamps of the first 4 tiles of this workgroup
         GADAPT_STAMP(p.stamps, tslot + 0);
         xs = slab_ptr(t);
-        if constexpr (K::MFMA) gemm.run(xs, ps);
-        GADAPT_STAMP(p.stamps, tslot + 1);
-        win = sr.meta.w != 0;
-        xr.commit(slab_ptr(t + 1), p.n_nodes, tid);
-        const int dmax = csr.commit(sr, tid, node0, win ? t : -1);
-        __syncthreads();                                        // P tile, slab t+1 and the CSR slice are complete
-        {   // this register set's next job: tile t+2 (slab t+3).  Unconditional (clamped past the chunk end): see issue()
-            csr.issue(sr, t + 2 - ch.t0, (t + 2) * K::TM, p.n_nodes, tid);
-            xr.issue(p.x_in, (t + 3) * K::TM, p.n_nodes, tid);
+        int dmax;
+        if constexpr (K::RING == 3) {
+            if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, p.p0);
+            if constexpr (K::MFMA) gemm.run(xs, ps);
+            GADAPT_STAMP(p.stamps, tslot + 1);
+            win = sr.meta.w != 0;
+            xr.commit(slab_ptr(t + 1), p.n_nodes, tid);
+            dmax = csr.commit(sr, tid, node0, win ? t : -1);
+            __syncthreads();                                    // P tile, slab t+1 and the CSR slice are complete
+        } else {                                                // no window: the tile itself is staged first, then projected
+            win = false;
+            xr.commit(xs, p.n_nodes, tid);
+            dmax = csr.commit(sr, tid, node0, -1);
+            if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, p.p0);
+            __syncthreads();
+        }
+        {   // this register set's next job: tile t+AHEAD (slab t+AHEAD+LEAD).  Unconditional (clamped past the chunk end): see issue()
+            csr.issue(sr, t + AHEAD - ch.t0, (t + AHEAD) * K::TM, p.n_nodes, tid);
+            xr.issue(p.x_in, (t + AHEAD + K::LEAD) * K::TM, p.n_nodes, tid);
+        }
+        if constexpr (K::RING != 3) {
+            if constexpr (K::MFMA) { gemm.run(xs, ps); __syncthreads(); }
+            GADAPT_STAMP(p.stamps, tslot + 1);
         }
         GADAPT_STAMP(p.stamps, tslot + 2);
         if (dmax >= 0) {
             dispatch_dmax(dmax, [&](auto tag) {
-                auto walk = [&](auto win_tag) {
+                auto walk = [&](auto win_tag) __attribute__((always_inline)) {
                     run_pipeline<K::ITERS, RowBuf<decltype(tag)::value, K::NV>>(
                         [&](auto& b, int it) { fetch(b, node0, it, win_tag); },
                         [&](const auto& b, int it) { consume(b, node0, it); GADAPT_STAMP(p.stamps, tslot + 3 + (it & 3)); },
@@ -871,9 +894,14 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
         __syncthreads();                                        // edge walk done: P tile and ring slot t-1 may be rewritten
         GADAPT_STAMP(p.stamps, tslot + 7);
     };
-    for (int t = ch.t0; t < ch.t1; t += 2) {
-        do_tile(t, xrA, srA);
-        if (t + 1 < ch.t1) do_tile(t + 1, xrB, srB);
+    if constexpr (AHEAD == 2) {
+        for (int t = ch.t0; t < ch.t1; t += 2) {
+            do_tile(t, xrA, srA);
+            if (t + 1 < ch.t1) do_tile(t + 1, xrB, srB);
+        }
+    } else {
+#pragma unroll 1
+        for (int t = ch.t0; t < ch.t1; ++t) do_tile(t, xrA, srA);
     }
 }
 
@@ -946,7 +974,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
     float sum_ddt = 0.f, sum_dsc = 0.f;
     V gk[K::ITERS];                                             // (base - dt) g_i of this lane's node slots, for the epilogue
 
-    auto finish = [&](int li, int i, int it, const V& gi, const V& m, const V& dP) {
+    auto finish = [&](int li, int i, int it, const V& gi, const V& m, const V& dP) __attribute__((always_inline)) {
         if (i < p.n_nodes) {
             if constexpr (SUMS) {
                 // d dt = sum_i <g_i, m_i - x_i>   (GNN.py:288-289 learn_step); every lane adds its channels
@@ -969,7 +997,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
     };
 
     // WIN (compile time): gathers from the LDS ring (col holds ring offsets) or from HBM/L2; see the forward kernel
-    auto fetch = [&](auto& b, int node0, int it, auto win_tag) {
+    auto fetch = [&](auto& b, int node0, int it, auto win_tag) __attribute__((always_inline)) {
         constexpr int DM = std::remove_reference_t<decltype(b)>::N;
         constexpr bool WIN = decltype(win_tag)::value != 0;
         const int li = it * K::SLOTS + slot;
@@ -988,7 +1016,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         }
     };
 
-    auto consume = [&](const auto& b, int node0, int it) {
+    auto consume = [&](const auto& b, int node0, int it) __attribute__((always_inline)) {
         constexpr int DM = std::remove_reference_t<decltype(b)>::N;
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
@@ -1032,7 +1060,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         finish(li, i, it, gi, m, dP);
     };
 
-    auto slow_node = [&](int node0, int it) {
+    auto slow_node = [&](int node0, int it) __attribute__((always_inline)) {
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
         V dP, m; dP.zero(); m.zero();
@@ -1066,7 +1094,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
     // dxd rows of a finished tile leave the registers only after the NEXT tile's staging: vmcnt is in-order and hipcc
     // waits vmcnt(0) before the staging reads its prefetch registers, so stores issued just before it would be
     // waited for (a full write round trip per tile).
-    auto store_dxd = [&](int node0) {
+    auto store_dxd = [&](int node0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) {
             const int i = node0 + it * K::SLOTS + slot;
@@ -1076,28 +1104,40 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
     const TileChunk ch = tile_chunk(p.n_tiles);                 // an empty chunk still flushes its (zero) slab row
     if (ch.t0 < ch.t1) {
         stagger_start<GADAPT_STAGGER_T>();
-        auto slab_ptr = [&](int s_) { return ring + ((s_ + K::RING) % K::RING) * K::TILE_FLOATS; };
+        auto slab_ptr = [&](int s_) __attribute__((always_inline)) { return ring + ((s_ + K::RING) % K::RING) * K::TILE_FLOATS; };
         typename CsrT::Regs sr;
         TileRows<C> xr, gr;
-        if constexpr (K::MFMA) gemm.load(p.A, nullptr);         // B fragments stay in registers for the whole launch
+        constexpr bool RESIDENT_B = TileGemm<C, true>::SPLIT;  // C = 128: fp32 fragments, re-read per tile (registers)
+        if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
         csr.load_metas(ch.t0, 1, p.n_tiles, tid);
-        xr.issue(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
-        xr.issue(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0), p.n_nodes, tid);
+        if constexpr (K::RING == 3) {
+            xr.issue(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
+            xr.issue(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0), p.n_nodes, tid);
+        }
         __syncthreads();                                        // tile metadata visible
-        xr.issue(p.x_in, (ch.t0 + 1) * K::TM, p.n_nodes, tid);
-        gr.issue(p.g_in, ch.t0 * K::TM, p.n_nodes, tid);
-        csr.issue(sr, 0, ch.t0 * K::TM, p.n_nodes, tid);
+        // C = 128 has no registers to hold a tile across the edge walk: it stages at the top of the tile instead
+        constexpr bool PREFETCH = (C <= 64);
+        if constexpr (PREFETCH) {
+            xr.issue(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);
+            gr.issue(p.g_in, ch.t0 * K::TM, p.n_nodes, tid);
+            csr.issue(sr, 0, ch.t0 * K::TM, p.n_nodes, tid);
+        }
 #pragma unroll 1
         for (int t = ch.t0; t < ch.t1; ++t) {
             const int node0 = t * K::TM;
             const int tslot = (t - ch.t0) * 8;
+            if constexpr (!PREFETCH) {
+                xr.issue(p.x_in, (t + K::LEAD) * K::TM, p.n_nodes, tid);
+                gr.issue(p.g_in, t * K::TM, p.n_nodes, tid);
+                csr.issue(sr, t - ch.t0, t * K::TM, p.n_nodes, tid);
+            }
 #ifdef GADAPT_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // diagnostic: separates the prefetch wait from the LDS writes
 #endif
             GADAPT_STAMP(p.stamps, tslot + 0);
             xs = slab_ptr(t);
-            const bool win = sr.meta.w != 0;
-            xr.commit(slab_ptr(t + 1), p.n_nodes, tid);
+            const bool win = K::RING == 3 && sr.meta.w != 0;
+            xr.commit(slab_ptr(t + K::LEAD), p.n_nodes, tid);
             gr.commit(ds, p.n_nodes, tid);
             const int dmax = csr.commit(sr, tid, node0, win ? t : -1);
             GADAPT_STAMP(p.stamps, tslot + 1);
@@ -1107,7 +1147,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             // ---- edge phase: dP_i per node -> LDS
             if (dmax >= 0) {
                 dispatch_dmax(dmax, [&](auto tag) {
-                    auto walk = [&](auto win_tag) {
+                    auto walk = [&](auto win_tag) __attribute__((always_inline)) {
                         run_pipeline<K::ITERS, TBuf<decltype(tag)::value, K::NV>>(
                             [&](auto& b, int it) { fetch(b, node0, it, win_tag); },
                             [&](const auto& b, int it) { consume(b, node0, it); },
@@ -1120,10 +1160,11 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
                 for (int it = 0; it < K::ITERS; ++it) slow_node(node0, it);
             }
             GADAPT_STAMP(p.stamps, tslot + 3);
-            {   // request the next tile (unconditional, clamped past the end: see issue()).  Here rather than at the top
+            if constexpr (PREFETCH) {
+                // request the next tile (unconditional, clamped past the end: see issue()).  Here rather than at the top
                 // of the tile: the edge phase needs every register, and the MFMA phases below cover the round trip.
                 csr.issue(sr, t + 1 - ch.t0, (t + 1) * K::TM, p.n_nodes, tid);
-                xr.issue(p.x_in, (t + 2) * K::TM, p.n_nodes, tid);
+                xr.issue(p.x_in, (t + 1 + K::LEAD) * K::TM, p.n_nodes, tid);
                 gr.issue(p.g_in, (t + 1) * K::TM, p.n_nodes, tid);
             }
             __syncthreads();
@@ -1192,6 +1233,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             }
             GADAPT_STAMP(p.stamps, tslot + 5);
             // ---- dxd = (base-dt) g + dP A
+            if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, nullptr);
             if constexpr (K::MFMA) {
                 gemm.run_in_place(ds);                          // reads dP (like the dA pass), barrier, writes dP A
                 __syncthreads();
@@ -1352,7 +1394,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
     if (tr.t < tr.t_end) csr.issue(sr, 0, tr.t * K::TM, p.n_nodes, tid);
     V zr[K::ITERS];                                             // sum(alpha dt g_i) + sigma p0, kept across the GEMM; then the result rows
     // g_out rows of a finished tile leave the registers only after the NEXT tile's staging (see the target pass)
-    auto store_out = [&](int node0) {
+    auto store_out = [&](int node0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) {
             const int j = node0 + it * K::SLOTS + slot;
@@ -1377,7 +1419,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
                 constexpr int DM = decltype(tag)::value;
                 constexpr int HN = (DM + 1) / 2;
                 // pipeline steps = (node slot, half): rows of the next half are requested before this one is summed
-                auto fetch = [&](SBuf<HN, K::NV>& b, int step) {
+                auto fetch = [&](SBuf<HN, K::NV>& b, int step) __attribute__((always_inline)) {
                     const int it = step >> 1, half = step & 1;
                     const int li = it * K::SLOTS + slot;
                     const int e0 = csr.rp[li] - csr.ebase + half * HN;
@@ -1392,7 +1434,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
                     }
                 };
                 V z, y; float sig = 0.f;
-                auto consume = [&](const SBuf<HN, K::NV>& b, int step) {
+                auto consume = [&](const SBuf<HN, K::NV>& b, int step) __attribute__((always_inline)) {
                     const int it = step >> 1, half = step & 1;
                     if (half == 0) { z.zero(); y.zero(); sig = 0.f; }
 #pragma unroll
@@ -1698,7 +1740,9 @@ static inline int grid_for(int n_tiles, int max_blocks) {
 #ifndef GADAPT_BWD_S_MAX_BLOCKS
 #define GADAPT_BWD_S_MAX_BLOCKS 1024
 #endif
+#ifndef GADAPT_BWD_T_MAX_BLOCKS
 #define GADAPT_BWD_T_MAX_BLOCKS 512      /* target pass grid = slab row count */
+#endif
 
 // per-tile metadata pointer for this kernel's tile height (the graph carries one array per supported height)
 template <int TM> static const int32_t* meta_for(const int32_t* const (&m)[3]) {
