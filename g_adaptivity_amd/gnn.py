@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from . import functional as Fn
 from .conv import GRAND_conv, GRAND_plusConv
+from .features import GlobalFeatureExtractorCNN, expand_to_nodes, field_to_grid
 from .graph import MeshGraph, prepare_edge_index
 
 
@@ -93,15 +94,18 @@ class GNN(nn.Module):
                            ('gnn_inc_glob_feat_uu', opt.get('global_feat_dim'))):
             if opt.get(key):
                 self.in_dims.append(width)
-        if opt.get('gnn_inc_glob_feat_f') or opt.get('gnn_inc_glob_feat_uu'):
-            raise NotImplementedError("global CNN features (src/feature_extractors.py) are a later scope row "
-                                      "(SURVEY.md §8(f) rank 4)")
         opt['hidden_dims_list'] = self.in_dims                            # GNN.py:161
         in_dim, hid = sum(self.in_dims), opt['hidden_dim']
         self.enc = get_enc(opt, in_dim, hid, nonlin_type=opt['non_lin'])
         self.conv_layers = build_conv_list(opt)
         self.non_lin = get_nonlin(opt['non_lin'])
         self.dec = get_dec(opt, hid, self.dim, nonlin_type=opt['non_lin'])
+        if opt.get('gnn_inc_glob_feat_f'):                                # GNN.py:170-175
+            self.global_out_dim = opt['global_feat_dim']
+            self.global_feature_extractor_cnn_f = GlobalFeatureExtractorCNN(1, hid, self.global_out_dim, dim=self.dim)
+        if opt.get('gnn_inc_glob_feat_uu'):
+            self.global_out_dim = opt['global_feat_dim']
+            self.global_feature_extractor_cnn_uu = GlobalFeatureExtractorCNN(1, hid, self.global_out_dim, dim=self.dim)
         if opt.get('learn_step'):
             self.steps = nn.ParameterList([nn.Parameter(torch.tensor([opt['time_step']]))
                                            for _ in range(opt['num_layers'])])       # GNN.py:179-180
@@ -175,14 +179,31 @@ class GNN(nn.Module):
             uu = uu / torch.max(uu) if o.get('gnn_normalize') else uu      # GNN.py:235-238
         n = x_comp.shape[0]
         graph = self._graph(data, n, dev)
+        glob = []                                                          # per-mesh CNN features, GNN.py:240-268
+        if o.get('gnn_inc_glob_feat_f') or o.get('gnn_inc_glob_feat_uu'):
+            batch = data.batch.to(dev)
+            n_meshes = int(data.batch.max().item()) + 1
+            mapping = getattr(data, 'mapping_tensor', None) if o.get('data_type') == 'randg_mix' else \
+                getattr(self.dataset, 'mapping_tensor', None)
+            for flag, name, extractor in (('gnn_inc_glob_feat_f', 'f_tensor', 'global_feature_extractor_cnn_f'),
+                                          ('gnn_inc_glob_feat_uu', 'uu_tensor', 'global_feature_extractor_cnn_uu')):
+                if o.get(flag):
+                    field = getattr(data, name).to(dev).float()
+                    if o.get('gnn_normalize'):
+                        field = field / torch.max(field)
+                    grid = field_to_grid(field, mapping, self.mesh_dims, n_meshes, self.dim)
+                    glob.append(expand_to_nodes(getattr(self, extractor)(grid.unsqueeze(1)), batch))
 
         def features():                                                    # the concatenated matrix, only where a caller needs it
-            return torch.cat([x_comp] + [t.unsqueeze(-1) for t in (f, uu) if t is not None], dim=1).float()
+            return torch.cat([x_comp] + [t.unsqueeze(-1) for t in (f, uu) if t is not None] + glob, dim=1).float()
 
         fusable = self._fusable()
         x_all, sliced = None, False
         feats = None
-        if isinstance(self.enc, nn.Linear) and not self.enc.weight.requires_grad and self.enc.bias is None:
+        if glob:                                                           # differentiable wrt the CNN parameters
+            feats = features()
+            x = F.linear(feats, self.enc.weight, self.enc.bias) if isinstance(self.enc, nn.Linear) else self.enc(feats)
+        elif isinstance(self.enc, nn.Linear) and not self.enc.weight.requires_grad and self.enc.bias is None:
             native_in = all(t is None or (t.dtype == torch.float32 and t.dim() == 1) for t in (f, uu)) and x_comp.dtype == torch.float32
             if fusable and not (self.training and o.get('dropout', 0.0) > 0):
                 # encoder output lands in slot 0 of the block's activation buffer: no copy

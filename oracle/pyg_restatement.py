@@ -149,6 +149,35 @@ class _QK(nn.Module):
         self.lin_skip = nn.Linear(c, c, bias=False)           # allocated, never used (root_weight=False)
 
 
+class _GlobalCNN(nn.Module):
+    """`GlobalFeatureExtractorCNN` (`src/feature_extractors.py:6-34`): 3x3 convs + SELU, global average pool."""
+
+    def __init__(self, in_channels, mid_channels, out_channels, dim=2, num_layers=4):
+        super().__init__()
+        conv = nn.Conv1d if dim == 1 else nn.Conv2d
+        chans = [in_channels] + [mid_channels] * (num_layers - 1) + [out_channels]
+        self.convs = nn.ModuleList([conv(chans[k], chans[k + 1], kernel_size=3, stride=1, padding=1)
+                                    for k in range(num_layers)])
+        self.dim = dim
+
+    def forward(self, u):
+        u = u / u.abs().max()                                                              # :29
+        for conv in self.convs:
+            u = F.selu(conv(u))                                                            # :30-31
+        return u.mean(dim=tuple(range(2, u.dim())))                                        # adaptive avg pool to 1 + flatten
+
+
+def fd_tensor_to_grid(u, mapping, mesh_dims, batch_size, dim):
+    """`reshape_fd_tensor_to_grid` (`src/utils_data.py:125-141`)."""
+    ub = u.reshape(batch_size, -1)
+    if dim == 1:
+        return ub
+    if mapping is not None:
+        ub = torch.gather(ub, 1, mapping.unsqueeze(0).expand(batch_size, -1))
+    g = ub.reshape(batch_size, mesh_dims[0], mesh_dims[1])
+    return torch.flip(torch.transpose(g, 1, 2), [1])
+
+
 class OracleGNN(nn.Module):
     """`GNN` (`src/GNN.py:144-306`) for enc='identity', GRAND/GRAND_plus, mesh_loss|modular."""
 
@@ -158,6 +187,12 @@ class OracleGNN(nn.Module):
         self.dim = dataset.num_x_comp_features
         in_dim = self.dim + int(bool(opt['gnn_inc_feat_f'])) + int(bool(opt['gnn_inc_feat_uu']))
         c = opt['hidden_dim']
+        self.dataset = dataset
+        for flag, name in (('gnn_inc_glob_feat_f', 'global_feature_extractor_cnn_f'),
+                           ('gnn_inc_glob_feat_uu', 'global_feature_extractor_cnn_uu')):           # GNN.py:170-175
+            if opt.get(flag):
+                in_dim += opt['global_feat_dim']
+                setattr(self, name, _GlobalCNN(1, c, opt['global_feat_dim'], dim=self.dim))
         assert opt['enc'] == 'identity' and opt['conv_type'] in ('GRAND', 'GRAND_plus')
         self.enc = nn.Linear(in_dim, c, bias=False)
         self.enc.weight.data = identity_encoder_weight(in_dim, c)
@@ -183,6 +218,16 @@ class OracleGNN(nn.Module):
             edge_index = with_self_loops(edge_index, data.x_comp.shape[0])                 # :220-223
         feats = node_features(data, self.dim, opt['gnn_inc_feat_f'], opt['gnn_inc_feat_uu'],
                               opt.get('gnn_normalize', False))
+        for flag, field, name in (('gnn_inc_glob_feat_f', 'f_tensor', 'global_feature_extractor_cnn_f'),
+                                  ('gnn_inc_glob_feat_uu', 'uu_tensor', 'global_feature_extractor_cnn_uu')):   # :240-268
+            if opt.get(flag):
+                u = getattr(data, field)
+                if opt.get('gnn_normalize', False):
+                    u = u / torch.max(u)
+                nb = int(data.batch.max()) + 1
+                grid = fd_tensor_to_grid(u, getattr(self.dataset, 'mapping_tensor', None), opt['mesh_dims'], nb, self.dim)
+                per_mesh = getattr(self, name)(grid.unsqueeze(1).to(self.enc.weight.dtype))
+                feats = torch.cat([feats.to(per_mesh.dtype), per_mesh.repeat_interleave(torch.bincount(data.batch), dim=0)], dim=-1)
         x = self.enc(feats.to(self.enc.weight.dtype))                                      # :270
         alphas = []
         for i, layer in enumerate(self.conv_layers):                                       # :273

@@ -64,3 +64,28 @@ def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, c
         # d/d lin_key.bias vanishes analytically (softmax shift invariance); the oracle's is rounding noise
         assert lh.lin_key.bias.grad.abs().max().item() == 0.0
         assert l64.lin_key.bias.grad.abs().max().item() <= 1e-9 * max(l64.lin_query.bias.grad.abs().max().item(), 1e-30) + 1e-18
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh_dims,hidden", [((9, 9), 16), ((12, 12), 64)], ids=['9x9-C16', '12x12-C64'])
+def test_global_cnn_features_parity(gpu_device, mesh_dims, hidden):
+    """gnn_inc_glob_feat_f/uu (GNN.py:240-268): the per-mesh CNN features ride on the node features; gradients reach the
+    convolution weights through d/dx0 of the block op (source pass also run for layer 0)."""
+    extra = dict(gnn_inc_glob_feat_f=True, gnn_inc_glob_feat_uu=True)
+    oracle, o64, model, ref, ref64, out = _run(gpu_device, mesh_dims, 3, hidden, 2, 'GRAND_plus', extra)
+    norm, elem = rel_err(out, ref)
+    assert norm <= COORD_TOL and elem <= COORD_TOL, f"x_phys: normwise {norm:.2e} elementwise {elem:.2e}"
+    assert rel_err(out, ref64)[0] <= COORD_TOL
+    checked = 0
+    d32, d64 = dict(oracle.named_parameters()), dict(o64.named_parameters())
+    for name, ph in model.named_parameters():
+        p32, p64 = d32[name], d64[name]
+        if p64.grad is None:
+            assert ph.grad is None, name
+            continue
+        if name.endswith('lin_key.bias'):
+            continue                                            # analytically zero; the oracle's is rounding noise
+        e64, noise = rel_err(ph.grad, p64.grad)[0], rel_err(p32.grad, p64.grad)[0]
+        assert e64 <= max(GRAD_TOL, 1.5 * noise), f"{name}.grad vs fp64 oracle: {e64:.2e} (fp32 oracle: {noise:.2e})"
+        checked += name.startswith('global_feature_extractor')
+    assert checked == 16                                        # 2 extractors x 4 convs x (weight, bias)

@@ -128,3 +128,35 @@ def test_no_cpu_fallback():
     m = GNN(ds, opt)
     with pytest.raises(_native.NativeError):
         m(collate(ds.samples))
+
+
+def test_global_cnn_feature_modules_have_the_reference_keys():
+    """gnn_inc_glob_feat_*: `global_feature_extractor_cnn_{f,uu}.convs.{k}.{weight,bias}` (SURVEY.md §8(b) state_dict row)."""
+    from g_adaptivity_amd import GNN, MeshDataset, hot_path_opt
+    from oracle.pyg_restatement import OracleGNN
+    opt = hot_path_opt(mesh_dims=[7, 7], hidden_dim=16, num_layers=2, gnn_inc_glob_feat_f=True, gnn_inc_glob_feat_uu=True)
+    ds = MeshDataset([7, 7], 2, seed=0)
+    model, oracle = GNN(ds, dict(opt)), OracleGNN(ds, dict(opt))
+    keys = set(model.state_dict())
+    for tag in ('f', 'uu'):
+        for k in range(4):
+            assert f'global_feature_extractor_cnn_{tag}.convs.{k}.weight' in keys
+            assert f'global_feature_extractor_cnn_{tag}.convs.{k}.bias' in keys
+    assert model.enc.weight.shape == (16, 2 + 1 + 1 + 8 + 8)
+    assert keys == set(oracle.state_dict())
+    model.load_state_dict(oracle.state_dict(), strict=True)
+
+
+def test_field_to_grid_matches_the_gather_transpose_flip_recipe():
+    import torch
+    from g_adaptivity_amd.features import expand_to_nodes, field_to_grid
+    from oracle.pyg_restatement import fd_tensor_to_grid
+    torch.manual_seed(0)
+    B, n = 3, 5
+    u = torch.randn(B * n * n)
+    mapping = torch.randperm(n * n)
+    assert torch.equal(field_to_grid(u, mapping, [n, n], B, 2), fd_tensor_to_grid(u, mapping, [n, n], B, 2))
+    assert torch.equal(field_to_grid(u, None, [n, n], B, 2)[1, 0], u.reshape(B, n, n)[1, :, n - 1])   # transpose + flip
+    batch = torch.arange(B).repeat_interleave(torch.tensor([2, 1, 3]))
+    per_mesh = torch.arange(6.).reshape(3, 2)
+    assert torch.equal(expand_to_nodes(per_mesh, batch), per_mesh[batch])
