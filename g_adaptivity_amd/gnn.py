@@ -257,7 +257,7 @@ class GNN(nn.Module):
         else:
             x = self.dec(x) if self.dec is not None else x                 # GNN.py:298
             x_phys = x[:, :self.dim]                                       # GNN.py:299
-        if not self.training:
+        if not self.training and not torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream(dev).synchronize()                  # the stamp is read as a latency (utils_eval.py:201)
         self.end_MLmodel = time.time()                                    # GNN.py:301
         if o['loss_type'] in ('mesh_loss', 'modular'):

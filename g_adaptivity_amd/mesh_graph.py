@@ -289,6 +289,56 @@ class MeshLoader:
             yield collate([self.dataset[i] for i in order[s:s + self.batch_size]])
 
 
+class DeviceMeshLoader:
+    """Device-resident collation for a fixed-mesh dataset.
+
+    Every sample of a `MeshDataset` shares one mesh (`src/data.py:290`), so a batch of B samples always has the same
+    topology: `edge_index`, the edge masks, `corner_nodes` and `batch` are those of ANY B samples.  They are collated
+    once per batch size; the per-sample node fields live stacked on the device ([S, n, ...]) and a batch is one
+    `index_select` per field - no host work, no H2D copy per step, and the model's CSR cache is hit every time.
+    Yields the same duck-typed batch objects as `MeshLoader` / PyG's `DataLoader` (`src/run_GNN.py:76`).
+    """
+
+    NODE_FIELDS = ('x_comp', 'x_phys', 'f_tensor', 'uu_tensor', 'u_true_tensor')
+
+    def __init__(self, dataset: MeshDataset, batch_size: int = 1, shuffle: bool = False, device='cuda',
+                 generator: Optional[torch.Generator] = None):
+        self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
+        self.device, self.generator = torch.device(device), generator
+        self.fields = {k: torch.stack([getattr(s, k) for s in dataset.samples]).to(self.device)
+                       for k in self.NODE_FIELDS if hasattr(dataset.samples[0], k)}
+        self._templates = {}
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def _template(self, b: int) -> MeshData:
+        t = self._templates.get(b)
+        if t is None:
+            t = collate(self.dataset.samples[:b])
+            for k in self.NODE_FIELDS + ('pde_params',):
+                t.__dict__.pop(k, None)
+            t = self._templates[b] = t.to(self.device)
+        return t
+
+    def __iter__(self) -> Iterable[MeshData]:
+        n = len(self.dataset)
+        if self.shuffle:
+            gen = self.generator if (self.generator is not None and self.generator.device == self.device) else None
+            order = torch.randperm(n, device=self.device, generator=gen)
+        else:
+            order = torch.arange(n, device=self.device)
+        for s in range(0, n, self.batch_size):
+            idx = order[s:s + self.batch_size]
+            out = copy.copy(self._template(int(idx.numel())))         # shares the topology tensors
+            out.__dict__ = dict(out.__dict__)
+            for k, stacked in self.fields.items():
+                sel = stacked.index_select(0, idx)
+                out.__dict__[k] = sel.reshape(-1, *sel.shape[2:])
+            out.idx = idx
+            yield out
+
+
 def synthetic_batch(mesh_dims: Sequence[int], batch_size: int, seed: int = 0, num_gauss: int = 2) -> MeshData:
     """Convenience: one collated batch of `batch_size` samples."""
     ds = MeshDataset(mesh_dims, batch_size, seed=seed, num_gauss=num_gauss)

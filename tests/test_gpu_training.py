@@ -45,3 +45,27 @@ def test_training_steps_track_the_oracle(gpu_device):
     with torch.no_grad():
         out = model(data.clone().to(gpu_device))
     assert model.end_MLmodel is not None and rel_err(out, oracle.eval()(data))[0] <= 1e-4
+
+
+@pytest.mark.gpu
+def test_rollout_reuses_the_graph_and_hipgraph_replay_equals_eager(gpu_device):
+    """Burgers-style rollout (utils_eval_Burgers.py:282-300): same mesh, new uu_tensor every call.  The CSR is built once,
+    and the captured forward gives bit-identical coordinates."""
+    from g_adaptivity_amd.inference import GraphedForward
+    opt = hot_path_opt(mesh_dims=[21], hidden_dim=8, num_layers=3, device=str(gpu_device), conv_type='GRAND',
+                       gnn_inc_feat_f=False, show_mesh_evol_plots='False')
+    ds = MeshDataset([21], 1, seed=0)
+    data = collate(ds.samples).to(gpu_device)
+    torch.manual_seed(0)
+    model = GNN(ds, opt).to(gpu_device).eval()
+    runner = GraphedForward(model, data)
+    outs_e, outs_g = [], []
+    with torch.no_grad():
+        for k in range(6):
+            data.uu_tensor = torch.sin((k + 1) * data.x_comp.reshape(-1)).to(data.uu_tensor.dtype)
+            outs_e.append(model(data).clone())
+            outs_g.append(runner(data).clone())
+    assert len(model._graphs) == 1
+    assert all(torch.equal(a, b) for a, b in zip(outs_e, outs_g))
+    assert not torch.equal(outs_e[0], outs_e[-1])
+    assert model.end_MLmodel is not None

@@ -160,3 +160,24 @@ def test_field_to_grid_matches_the_gather_transpose_flip_recipe():
     batch = torch.arange(B).repeat_interleave(torch.tensor([2, 1, 3]))
     per_mesh = torch.arange(6.).reshape(3, 2)
     assert torch.equal(expand_to_nodes(per_mesh, batch), per_mesh[batch])
+
+
+def test_device_loader_batches_equal_cpu_collation():
+    """DeviceMeshLoader (device='cpu' here): same batch contents as collate() of the same samples, topology shared."""
+    import torch
+    from g_adaptivity_amd import DeviceMeshLoader, MeshDataset, collate
+    ds = MeshDataset([6, 6], 7, seed=3)
+    loader = DeviceMeshLoader(ds, batch_size=3, shuffle=False, device='cpu')
+    assert len(loader) == 3
+    batches = list(loader)
+    assert [b.num_graphs for b in batches] == [3, 3, 1]
+    for k, b in enumerate(batches):
+        ref = collate(ds.samples[3 * k:3 * k + 3])
+        for key in ('x_comp', 'x_phys', 'f_tensor', 'uu_tensor', 'edge_index', 'batch', 'to_boundary_edge_mask',
+                    'to_corner_nodes_mask', 'diff_boundary_edges_mask'):
+            assert torch.equal(getattr(b, key), getattr(ref, key)), key
+        assert all((a == c).all() for a, c in zip(b.corner_nodes, ref.corner_nodes))
+    assert batches[0].edge_index.data_ptr() == batches[1].edge_index.data_ptr()      # one topology object per batch size
+    g = torch.Generator().manual_seed(0)
+    shuffled = list(DeviceMeshLoader(ds, batch_size=7, shuffle=True, device='cpu', generator=g))[0]
+    assert sorted(shuffled.idx.tolist()) == list(range(7)) and shuffled.idx.tolist() != list(range(7))
