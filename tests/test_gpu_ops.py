@@ -299,3 +299,79 @@ def test_flat_adam_adopts_the_block_gradient_tensor(gpu_device):
     torch.cuda.synchronize()
     for (k, p), q in zip(model.named_parameters(), twin.parameters()):
         assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [32, 64])
+def test_mixed_window_tiles(gpu_device, C):
+    """A mesh batch (every tile's neighbours within +-1 tile: LDS-ring gathers) plus a few long-range edges and one
+    hub node: windowed tiles, HBM-gather tiles and loop-path tiles in ONE launch, forward and backward."""
+    ds = MeshDataset([16, 16], 4, seed=5)
+    from oracle.pyg_restatement import masked_edge_index
+    ei = masked_edge_index(collate(ds.samples), 2, 16)
+    n = 4 * 256
+    g = torch.Generator().manual_seed(11)
+    far = torch.stack([torch.randint(0, n, (12,), generator=g), torch.randint(300, 420, (12,), generator=g)])   # into tiles 4..6
+    hub = torch.stack([torch.randint(0, n, (20,), generator=g), torch.full((20,), 777)])                        # in-degree > 8
+    ei = torch.cat([ei, far, hub], dim=1)
+    wq, bq, wk, bk = _random_layer(C, 13)
+    x = torch.randn(n, C, generator=torch.Generator().manual_seed(14))
+    up = torch.randn(n, C, generator=torch.Generator().manual_seed(15))
+    x64 = x.double().requires_grad_(True)
+    p64 = [w.double().requires_grad_(True) for w in (wq, bq, wk, bk)]
+    ref64 = grand_residual(x64, ei, *p64)
+    (ref64 * up.double()).sum().backward()
+
+    graph = MeshGraph(ei, n, gpu_device)
+    tm = 128 if C == 32 else 64
+    meta = graph._metas[('t', tm)].cpu().view(-1, 4)
+    assert (meta[:, 3] == 1).any() and (meta[:, 3] == 0).any() and (meta[:, 2] > 8).any()   # all three kinds of tile present
+    opt = hot_path_opt(hidden_dim=C, device=str(gpu_device))
+    conv = GRAND_plusConv(opt, C, C, global_feat_dim=8, heads=1, concat=False, beta=False, dropout=0.0, edge_dim=None,
+                          bias=False, root_weight=False).to(gpu_device)
+    with torch.no_grad():
+        conv.lin_query.weight.copy_(wq); conv.lin_query.bias.copy_(bq); conv.lin_key.weight.copy_(wk); conv.lin_key.bias.copy_(bk)
+    xh = x.to(gpu_device).requires_grad_(True)
+    res = conv(xh, ei.to(gpu_device), None, None)
+    (res * up.to(gpu_device)).sum().backward()
+    torch.cuda.synchronize()
+    assert rel_err(res, ref64)[0] <= 1e-5, rel_err(res, ref64)
+    assert rel_err(xh.grad, x64.grad)[0] <= 1e-4, rel_err(xh.grad, x64.grad)
+    for got, want in ((conv.lin_query.weight.grad, p64[0].grad), (conv.lin_query.bias.grad, p64[1].grad),
+                      (conv.lin_key.weight.grad, p64[2].grad)):
+        assert rel_err(got, want)[0] <= 1e-4, rel_err(got, want)
+
+
+@pytest.mark.gpu
+def test_full_size_backward_properties(gpu_device):
+    """Backward at the BASELINE size (64x64, batch 32, C=64, L=4): gradients are linear in the upstream gradient,
+    invariant to the caller's edge order (within fp32 reassociation) and bit-reproducible."""
+    from g_adaptivity_amd import mse_loss
+    n, B, C, L = 64, 32, 64, 4
+    opt = hot_path_opt(mesh_dims=[n, n], hidden_dim=C, num_layers=L, device=str(gpu_device), show_mesh_evol_plots='False')
+    ds = MeshDataset([n, n], B, seed=0)
+    data = collate(ds.samples).to(gpu_device)
+    torch.manual_seed(0)
+    model = GNN(ds, opt).to(gpu_device).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def grads(scale, d=data):
+        for p in params:
+            p.grad = None
+        (scale * mse_loss(model(d), d.x_phys)).backward()
+        return [p.grad.clone() for p in params if p.grad is not None]
+
+    g1, g1b, g3 = grads(1.0), grads(1.0), grads(4.0)         # a power of two: scaling commutes with fp32 rounding
+    assert len(g1) == 4 and all(torch.equal(a, b) for a, b in zip(g1, g1b))
+    for a, b in zip(g1, g3):
+        assert rel_err(4.0 * a, b)[0] <= 1e-6
+    d2 = data.clone()
+    perm = torch.randperm(d2.edge_index.shape[1], generator=torch.Generator().manual_seed(2)).to(gpu_device)
+    d2.edge_index = d2.edge_index[:, perm]
+    for k in ('to_boundary_edge_mask', 'to_corner_nodes_mask', 'diff_boundary_edges_mask'):
+        setattr(d2, k, getattr(d2, k)[perm])
+    model._graphs.clear()                                        # the cache is keyed on sizes, not on edge order
+    gp = grads(1.0, d2)
+    for a, b in zip(g1, gp):
+        if a.abs().max() > 0:
+            assert rel_err(b, a)[0] <= 1e-4, rel_err(b, a)
