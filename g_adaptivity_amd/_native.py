@@ -53,6 +53,7 @@ PROTOTYPES = {
     'gadapt_profile_read': (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'gadapt_profile_samples': (_I, [_I, C.POINTER(C.c_double), _I]),
     'gadapt_profile_reset': (_I, []),
+    'gadapt_profile_calibrate': (_I, [_I, _P]),
     'gadapt_debug_occupancy': (_I, [_I, C.POINTER(C.c_int)]),
 }
 

@@ -103,6 +103,25 @@ extern "C" int gadapt_profile_samples(int kernel_id, double* out_ms, int cap) {
     }
     return n;
 }
+// An event pair around a launch also times the dispatch of that launch.  gadapt_profile_calibrate brackets, the same
+// way, n times ONE empty launch (kernel id 3) and n times TWO consecutive empty launches (id 4): with e = what one
+// empty launch occupies, p1 = D + e and p2 = D + 2e, so the dispatch share of a pair is D = 2 p1 - p2.
+__global__ void profile_empty_kernel() {}
+extern "C" int gadapt_profile_calibrate(int n, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < n; ++i) {
+        {
+            ProfScope prof(3, st);
+            hipLaunchKernelGGL(profile_empty_kernel, dim3(1), dim3(64), 0, st);
+        }
+        {
+            ProfScope prof(4, st);
+            hipLaunchKernelGGL(profile_empty_kernel, dim3(1), dim3(64), 0, st);
+            hipLaunchKernelGGL(profile_empty_kernel, dim3(1), dim3(64), 0, st);
+        }
+    }
+    return check_launch("profile_empty_kernel");
+}
 extern "C" int gadapt_profile_reset(void) {
     for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();

@@ -186,6 +186,9 @@ int gadapt_profile_enable(int on);
 int gadapt_profile_read(int kernel_id, double* total_ms, int* count);
 int gadapt_profile_samples(int kernel_id, double* out_ms, int cap);   /* returns the number written */
 int gadapt_profile_reset(void);
+/* Dispatch share D of an event pair: n x one empty launch (kernel id 3, p1) and n x two empty launches (id 4, p2),
+ * bracketed like the hot kernels; D = 2 p1 - p2. */
+int gadapt_profile_calibrate(int n, void* stream);
 /* Diagnostic: runtime-reported workgroups per CU of {forward, backward target, backward source}. */
 int gadapt_debug_occupancy(int c, int* out3);
 
