@@ -1,15 +1,16 @@
 // gadapt_kernels.hip - fused GRAND attention-diffusion layer for gfx950 (MI355X).
 //
-// Three kernels carry the hot path (DESIGN.md §4):
+// Three kernels carry the hot path (DESIGN.md §5):
 //   grand_fwd_kernel<C>        x' = x + dt (sum_j alpha_ij x_j - x)            (target-centric)
 //   grand_bwd_target_kernel<C> d(score), dP, weight-gradient partials, dxd     (target-centric)
 //   grand_bwd_source_kernel<C> g_out = dxd + sum over out-edges                (source-centric)
-// All three share one shape: a 256-thread workgroup owns a tile of TM consecutive nodes,
-// C/4 lanes cover one node (float4 per lane => a gathered neighbour row is one coalesced
-// 4*C-byte read), the [TM,C]x[C,C] projection runs on the fp32 matrix cores
-// (v_mfma_f32_32x32x2_f32, B operand resident in registers) for C >= 32 and on the VALU
-// for C < 32, and tiles are dealt to workgroups so that one XCD walks a contiguous node
-// range (neighbour rows are shared through that XCD's L2).
+// All three share one shape: a 256-thread workgroup owns tiles of TM consecutive nodes, C/8 lanes
+// cover one node (two float4 per lane for C >= 32, one for C < 32: a gathered neighbour row is one or
+// two coalesced reads), the tile's CSR slice sits in LDS, and workgroups of one XCD walk a contiguous
+// node range.  The forward and the target pass keep the x rows of tiles t-1..t+1 in an LDS ring and
+// gather from it when the tile's neighbours all lie there (per-tile metadata built with the graph);
+// the [TM,C]x[C,C] projections run on the bf16 matrix cores with a three-piece split of both operands
+// (fp32 accuracy, C <= 64), on v_mfma_f32_32x32x2_f32 for C = 128 and on the VALU for C < 32.
 //
 // Arithmetic follows /root/reference/src/GRAND_plus.py:225-343 and src/GNN.py:273-291 in the
 // (A, p0) formulation described in include/gadapt_hip.h.
@@ -38,9 +39,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 #ifndef GADAPT_STAGGER_T
 #define GADAPT_STAGGER_T 0
-#endif
-#ifndef GADAPT_STAGGER_S
-#define GADAPT_STAGGER_S 0
 #endif
 #define GADAPT_SLAB_CHUNKS 32   // second-level partials of the slab reduction
 
@@ -374,21 +372,6 @@ template <int C, bool TRANS> struct TileGemm {
         store(tile, acc);
     }
 };
-
-// Stage TM rows of a [N,C] matrix into a padded LDS tile (zero rows past N).
-template <int C> __device__ __forceinline__ void stage_tile(const float* __restrict__ src, float* tile,
-                                                            int node0, int n_nodes, int tid) {
-    using K = Cfg<C>;
-    constexpr int V = C / 4;
-#pragma unroll
-    for (int idx = tid; idx < K::TM * V; idx += 256) {
-        const int r = idx / V, c4 = idx % V;
-        const int node = node0 + r;
-        float4 v = f4zero();
-        if (node < n_nodes) v = ld_row4<C>(src, node, c4);
-        *reinterpret_cast<float4*>(tile + r * K::LD + 4 * c4) = v;
-    }
-}
 
 // The tile's slice of one CSR orientation in LDS: rowptr[TM+1], col[COLN] and AUXW per-edge words.  Where the slice
 // starts, how long it is and the tile's longest row come from per-tile metadata built with the graph
