@@ -61,3 +61,27 @@ extern "C" int gadapt_tile_meta_host(const int32_t* rowptr, const int32_t* col, 
     }
     return GADAPT_OK;
 }
+
+// ELL-8 copy of one CSR orientation for the wide kernels (see include/gadapt_hip.h): row i -> ell[8i..8i+7], unused
+// entries -1, rows padded to a multiple of 256.  *max_deg_out = the longest row if the orientation qualifies
+// (every row <= 8 entries and every neighbour of node i inside rows [256*(i/256) - 64, 256*(i/256) + 320)), else 0.
+extern "C" int gadapt_ell_build_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t* ell_out, int32_t* max_deg_out) {
+    if (!rowptr || !col || !ell_out || !max_deg_out || n_nodes <= 0) return GADAPT_E_BADARG;
+    const int64_t n_pad = (n_nodes + 255) / 256 * 256;
+    for (int64_t k = 0; k < n_pad * 8; ++k) ell_out[k] = -1;
+    int32_t longest = 0;
+    bool ok = true;
+    for (int64_t i = 0; i < n_nodes && ok; ++i) {
+        const int32_t e0 = rowptr[i], d = rowptr[i + 1] - e0;
+        if (d > 8) { ok = false; break; }
+        if (d > longest) longest = d;
+        const int64_t lo = i / 256 * 256 - 64, hi = lo + 384;
+        for (int32_t k = 0; k < d; ++k) {
+            const int32_t j = col[e0 + k];
+            if (j < lo || j >= hi) { ok = false; break; }
+            ell_out[8 * i + k] = j;
+        }
+    }
+    *max_deg_out = ok ? longest : 0;
+    return GADAPT_OK;
+}

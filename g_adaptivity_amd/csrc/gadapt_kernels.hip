@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "gadapt_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -53,7 +54,7 @@ static int check_launch(const char* what) {
     return GADAPT_OK;
 }
 extern "C" const char* gadapt_last_error(void) { return g_err; }
-extern "C" int gadapt_abi_version(void) { return 1; }
+extern "C" int gadapt_abi_version(void) { return 2; }
 extern "C" int gadapt_supported_hidden_dim(int c) {
     return c == 4 || c == 8 || c == 16 || c == 32 || c == 64 || c == 128;
 }
@@ -600,9 +601,20 @@ extern "C" int gadapt_debug_set_stamp_buffer(void* p) { g_stamp_buf = static_cas
             __builtin_amdgcn_sched_barrier(0);                                                     \
         }                                                                                          \
     } while (0)
+#define GADAPT_STAMP_RT(buf, slot_)                                                                \
+    do {                                                                                           \
+        if ((buf) && threadIdx.x == 0 && (slot_) < 32) {                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            (buf)[(size_t)blockIdx.x * 32 + (slot_)] = t_;                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+    } while (0)
 #else
 #define GADAPT_STAMP(buf, slot_) do { } while (0)
 #define GADAPT_STAMP_L(buf, slot_) do { } while (0)
+#define GADAPT_STAMP_RT(buf, slot_) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1723,9 +1735,12 @@ __global__ void adam_step_kernel(float* param, const float* grad, float* m, floa
     param[e] = pv - (lr / bc1) * (mn / denom);
 }
 
+#include "gadapt_wide.inc"
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+
 // Workgroups of a launch: a multiple of 8 (XCD groups), at most max_blocks (the resident set) unless that would
 // give a workgroup more than 64 tiles (Cfg::MAXM: its tile metadata must fit the LDS table).
 static inline int grid_for(int n_tiles, int max_blocks) {
@@ -1755,9 +1770,37 @@ template <typename KernelT> static void allow_lds(KernelT k, int bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// The wide kernels (gadapt_wide.inc) take over for hidden size 64 when the graph qualifies; GADAPT_WIDE=0 in the
+// environment keeps the tiled kernels (A/B runs and the tests of the tiled path).
+static bool wide_enabled() {
+    static const bool on = [] { const char* e = getenv("GADAPT_WIDE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static inline int wide_grid(int n_steps) {
+    int g = (n_steps + 7) & ~7;
+    if (g > 256) g = 256;                                       // one 512-thread workgroup per CU
+    return g;
+}
+static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
+                           const float* lp, float* alpha_out, int residual_only, hipStream_t st) {
+    const int n_steps = (g->n_nodes + wide::STEP - 1) / wide::STEP;
+    wide::FwdArgs p{x_in, x_out, a, p0, lp, g->ell_t, g->rowptr_t, alpha_out, g->n_nodes, n_steps, residual_only, g->wide_deg_t, nullptr};
+#ifdef GADAPT_STAMPS
+    p.stamps = g_stamp_buf;
+#endif
+    ProfScope prof(0, st);
+    constexpr int lds = wide::fwd_lds_bytes();
+    allow_lds(wide::fwd_kernel, lds);
+    hipLaunchKernelGGL(wide::fwd_kernel, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
+    return check_launch("wide::fwd_kernel");
+}
+
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                                        const float* lp, float* alpha_out, int residual_only, hipStream_t st) {
     using K = Cfg<C>;
+    if constexpr (C == 64) {
+        if (g->ell_t && g->wide_deg_t > 0 && wide_enabled()) return launch_wide_fwd(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, st);
+    }
     FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t), alpha_out, g->n_nodes,
               (g->n_nodes + K::TM - 1) / K::TM, residual_only, g->n_edges, nullptr};
 #ifdef GADAPT_STAMPS

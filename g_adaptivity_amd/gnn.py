@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from . import functional as Fn
 from .conv import GRAND_conv, GRAND_plusConv
 from .features import GlobalFeatureExtractorCNN, expand_to_nodes, field_to_grid
+from . import graph as _graph_mod
 from .graph import MeshGraph, prepare_edge_index
 
 
@@ -126,7 +127,7 @@ class GNN(nn.Module):
         else:
             ckey = tuple(int(v) for v in np.asarray(corners).reshape(-1))
         key = (num_nodes, int(data.edge_index.shape[1]), self.dim, ckey, bool(self.opt['fix_boundary']),
-               bool(self.opt.get('self_loops')), str(device))
+               bool(self.opt.get('self_loops')), str(device), _graph_mod.WIDE_KERNELS)
         g = self._graphs.get(key)
         if g is None:
             single = not isinstance(corners, (list, tuple))

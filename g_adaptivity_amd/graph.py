@@ -45,6 +45,11 @@ def prepare_edge_index(data, dim: int, mesh_n: int, fix_boundary: bool, self_loo
     return edge_index.contiguous()
 
 
+# The wide (hidden 64) kernels run on graphs that qualify (gadapt_ell_build_host); False keeps the tiled kernels
+# everywhere (tests compare the two).  Read when a MeshGraph is built; part of the cache key.
+WIDE_KERNELS = True
+
+
 class MeshGraph:
     """Both CSR orientations of one edge list, int32, resident on `device`."""
 
@@ -70,6 +75,16 @@ class MeshGraph:
                     raise _native.NativeError("gadapt_tile_meta_host failed")
                 metas[(tag, tm)] = m.to(self.device)
         self._metas = metas
+        # ELL-8 copies + eligibility for the wide (hidden 64) kernels
+        n_pad = (n + 255) // 256 * 256
+        ells, wide_deg = {}, {}
+        for tag, rp, cl in (('t', rowptr_t, col_t), ('s', rowptr_s, col_s)):
+            ell = torch.empty(n_pad * 8, dtype=torch.int32)
+            md = C.c_int32(0)
+            if _native.lib().gadapt_ell_build_host(rp.data_ptr(), cl.data_ptr(), n, ell.data_ptr(), C.addressof(md)) != 0:
+                raise _native.NativeError("gadapt_ell_build_host failed")
+            ells[tag], wide_deg[tag] = ell.to(self.device), (int(md.value) if WIDE_KERNELS else 0)
+        self._ells, self.wide_deg = ells, wide_deg
         self.edge_index = edge_index                        # as given (original order/device)
         self.rowptr_t, self.col_t, self.eid_t = (t.to(self.device) for t in (rowptr_t, col_t, eid_t))
         self.rowptr_s, self.col_s, self.perm_s, self.tpos_s = (t.to(self.device) for t in (rowptr_s, col_s, perm_s, tpos_s))
@@ -78,7 +93,8 @@ class MeshGraph:
                                     self.rowptr_s.data_ptr(), self.col_s.data_ptr(), self.perm_s.data_ptr(),
                                     self.tpos_s.data_ptr(),
                                     (C.c_void_p * 3)(*[metas[('t', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]),
-                                    (C.c_void_p * 3)(*[metas[('s', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]))
+                                    (C.c_void_p * 3)(*[metas[('s', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]),
+                                    ells['t'].data_ptr(), ells['s'].data_ptr(), wide_deg['t'], wide_deg['s'])
         self.c_ref = C.byref(self.c_struct)
 
     def alpha_to_edge_order(self, alpha_t: torch.Tensor) -> torch.Tensor:
@@ -102,8 +118,8 @@ class GraphCache:
             # device-side fingerprint without a full D2H copy: three order-sensitive checksums
             w = torch.arange(1, ei.shape[1] + 1, device=ei.device, dtype=torch.int64)
             fp = torch.stack([(ei[0] * w).sum(), (ei[1] * w).sum(), (ei[0] ^ (ei[1] << 1)).sum()]).tolist()
-            return (int(ei.shape[1]), int(num_nodes), str(device), tuple(fp))
-        return (int(ei.shape[1]), int(num_nodes), str(device), hash(ei.numpy().tobytes()))
+            return (int(ei.shape[1]), int(num_nodes), str(device), tuple(fp), WIDE_KERNELS)
+        return (int(ei.shape[1]), int(num_nodes), str(device), hash(ei.numpy().tobytes()), WIDE_KERNELS)
 
     def get(self, edge_index: torch.Tensor, num_nodes: int, device) -> MeshGraph:
         key = self._key(edge_index, num_nodes, device)

@@ -73,7 +73,19 @@ typedef struct gadapt_graph {
     const int32_t* tpos_s;
     const int32_t* meta_t[3];  /* device: tile metadata of the target CSR for tile heights 64, 128, 256 */
     const int32_t* meta_s[3];  /* device: same for the source CSR */
+    /* optional (NULL / 0 = absent): ELL-8 copies for the wide kernels (gadapt_ell_build_host) */
+    const int32_t* ell_t;      /* device [round_up(N,256)][8]: in-neighbours of node i, -1 = unused */
+    const int32_t* ell_s;      /* device: out-neighbours (targets), same layout */
+    int32_t wide_deg_t;        /* longest in-row if the target orientation qualifies for the wide kernels, else 0 */
+    int32_t wide_deg_s;        /* same for the source orientation */
 } gadapt_graph;
+
+/* ELL-8 copy of one CSR orientation (host pointers).  The wide kernels (hidden size 64: one wave owns 32 consecutive
+ * nodes, two lanes per node, a 256-node workgroup step gathers from a 384-row LDS window) run when every row has at
+ * most 8 entries and every neighbour of node i lies in rows [256*(i/256) - 64, 256*(i/256) + 320): row-major mesh
+ * batches do; any other graph takes the tiled kernels.  ell_out: round_up(N,256)*8 int32; *max_deg_out = longest
+ * row when the orientation qualifies, else 0. */
+int gadapt_ell_build_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t* ell_out, int32_t* max_deg_out);
 
 /* ------------------------------------------------------------------ weights
  * A[o][c] = sum_r Wk[r][o] Wq[r][c],  p0[o] = sum_r Wk[r][o] bq[r].

@@ -375,3 +375,71 @@ def test_full_size_backward_properties(gpu_device):
     for a, b in zip(g1, gp):
         if a.abs().max() > 0:
             assert rel_err(b, a)[0] <= 1e-4, rel_err(b, a)
+
+
+def _conv_run(gpu_device, ei, x, up, layer, wide):
+    """GRAND_plusConv residual forward + backward on dense x with the wide kernels on or off."""
+    from g_adaptivity_amd import graph as graph_mod
+    C = x.shape[1]
+    old = graph_mod.WIDE_KERNELS
+    graph_mod.WIDE_KERNELS = wide
+    try:
+        opt = hot_path_opt(hidden_dim=C, show_mesh_evol_plots=True, device=str(gpu_device))
+        conv = GRAND_plusConv(opt, C, C, global_feat_dim=8, heads=1, concat=False, beta=False, dropout=0.0, edge_dim=None,
+                              bias=False, root_weight=False).to(gpu_device)
+        with torch.no_grad():
+            conv.lin_query.weight.copy_(layer[0]); conv.lin_query.bias.copy_(layer[1])
+            conv.lin_key.weight.copy_(layer[2]); conv.lin_key.bias.copy_(layer[3])
+        xh = x.to(gpu_device).requires_grad_(True)
+        res, (_, (alpha, _, _)) = conv(xh, ei.to(gpu_device), None, None, return_attention_weights=True)
+        (res * up.to(gpu_device)).sum().backward()
+        torch.cuda.synchronize()
+        return (res.detach().cpu(), alpha.detach().cpu().view(-1), xh.grad.cpu(), conv.lin_query.weight.grad.cpu(),
+                conv.lin_query.bias.grad.cpu(), conv.lin_key.weight.grad.cpu())
+    finally:
+        graph_mod.WIDE_KERNELS = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh_n,batch", [(64, 32), (40, 45), (23, 7)], ids=['64x64-b32', '40x40-b45', '23x23-b7'])
+def test_wide_kernels_match_tiled_kernels(gpu_device, mesh_n, batch):
+    """Hidden 64 on row-major mesh batches runs the wide kernels (one wave per 32 nodes, 256-node workgroup steps);
+    every other graph runs the tiled ones.  Same inputs through both: several steps per workgroup (64x64 b32: 512 steps
+    on 256 workgroups), a ragged last step (40x40 b45: 72 000 nodes), a batch smaller than the grid (23x23 b7)."""
+    from oracle.pyg_restatement import masked_edge_index
+    from g_adaptivity_amd.graph import MeshGraph as MG
+    C = 64
+    ds = MeshDataset([mesh_n, mesh_n], batch, seed=3)
+    ei = masked_edge_index(collate(ds.samples), 2, mesh_n)
+    n = batch * mesh_n * mesh_n
+    assert MG(ei, n, gpu_device).wide_deg['t'] > 0                  # the mesh batch qualifies
+    layer = _random_layer(C, 11)
+    x = torch.randn(n, C, generator=torch.Generator().manual_seed(12))
+    up = torch.randn(n, C, generator=torch.Generator().manual_seed(13))
+    wide = _conv_run(gpu_device, ei, x, up, layer, True)
+    tiled = _conv_run(gpu_device, ei, x, up, layer, False)
+    names = ('residual', 'alpha', 'dx', 'd lin_query.weight', 'd lin_query.bias', 'd lin_key.weight')
+    tols = (2e-6, 2e-6, 1e-5, 1e-5, 1e-5, 1e-5)
+    for name, a, b, tol in zip(names, wide, tiled, tols):
+        assert rel_err(a, b)[0] <= tol, (name, rel_err(a, b))
+
+
+@pytest.mark.gpu
+def test_wide_kernels_rebase_large_scores(gpu_device):
+    """The wide forward takes softmax weights relative to the first score of a row and re-bases when a later score
+    exceeds it by more than 16: scores spread over +-60 must still give the max-shifted softmax of the reference."""
+    from oracle.pyg_restatement import masked_edge_index
+    C, mesh_n, batch = 64, 16, 3
+    ds = MeshDataset([mesh_n, mesh_n], batch, seed=5)
+    ei = masked_edge_index(collate(ds.samples), 2, mesh_n)
+    n = batch * mesh_n * mesh_n
+    wq, bq, wk, bk = _random_layer(C, 21)
+    wq, wk = wq * 6.0, wk * 6.0                                     # scores of order +-60
+    x = torch.randn(n, C, generator=torch.Generator().manual_seed(22))
+    up = torch.randn(n, C, generator=torch.Generator().manual_seed(23))
+    ref, (alpha_ref, _, _) = grand_residual(x.double(), ei, wq.double(), bq.double(), wk.double(), bk.double(), return_attention=True)
+    res, alpha, *_ = _conv_run(gpu_device, ei, x, up, (wq, bq, wk, bk), True)
+    sc = (alpha_ref.view(-1) > 0.5).float().mean().item()
+    assert sc > 0.3                                                 # the case is what it claims: mostly one-hot rows
+    assert rel_err(alpha, alpha_ref.view(-1))[0] <= 2e-5, rel_err(alpha, alpha_ref.view(-1))
+    assert rel_err(res, ref)[0] <= 2e-5, rel_err(res, ref)
