@@ -475,6 +475,14 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
     }
 };
 
+// Chunk c4 of row `row` of a matrix stored as [N,d] (d <= 4) but read as [N,C] with zeros beyond column d: the top
+// layer's upstream gradient (backward of x[:, :dim], GNN.py:299).  Loads are unconditional (see TileCsr::issue).
+__device__ __forceinline__ float4 ld_row4_compact(const float* __restrict__ base, int row, int c4, int d) {
+    const float* r = base + (size_t)row * d;
+    const float v0 = r[0], v1 = r[min(1, d - 1)], v2 = r[min(2, d - 1)], v3 = r[min(3, d - 1)];
+    float4 o = make_float4(v0, d > 1 ? v1 : 0.f, d > 2 ? v2 : 0.f, d > 3 ? v3 : 0.f);
+    return c4 == 0 ? o : f4zero();
+}
 // x-tile rows of a tile held in registers between issue and commit (same split as TileCsr)
 template <int C> struct TileRows {
     using K = Cfg<C>;
@@ -489,6 +497,15 @@ template <int C> struct TileRows {
         for (int q = 0; q < XQ; ++q) {
             const int idx = min(q * 256 + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
             v[q] = ld_row4<C>(src, min(max(node0 + r, 0), n_nodes - 1), c4);
+        }
+    }
+    // same for a compact [N,d] source (ld_row4_compact)
+    __device__ __forceinline__ void issue_compact(const float* __restrict__ src, int d, int node0, int n_nodes, int tid) {
+        node0_ = node0;
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = min(q * 256 + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
+            v[q] = ld_row4_compact(src, min(max(node0 + r, 0), n_nodes - 1), c4, d);
         }
     }
     __device__ __forceinline__ void commit(float* tile, int n_nodes, int tid) const {
@@ -929,6 +946,7 @@ struct BwdTArgs {
     float2* edge_ws; float* dxd; float* slab; float* sums_out;
     int n_nodes, n_tiles, accumulate, residual_only, n_edges;
     unsigned long long* stamps;
+    int g_cols;                                                 // GC kernels: g_in is [N,g_cols] (zero beyond), else unused
 };
 
 template <int NROWS, int NV> struct TBuf {
@@ -943,7 +961,8 @@ template <int NROWS, int NV> struct TBuf {
 // Rolling window like the forward: a workgroup walks consecutive tiles with slabs t-1, t, t+1 of x in an LDS ring,
 // so on mesh-ordered graphs the x_j gathers are LDS reads.  Per tile the fourth LDS tile holds g (staged with the
 // ring slab), then dP (written over g row by row by the lanes that read it), then dP A (in place).
-template <int C, bool SUMS>
+// GC: the upstream gradient is compact, [N,g_cols] (top layer: backward of the x[:, :dim] slice) - only its staging differs.
+template <int C, bool SUMS, bool GC = false>
 __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kernel(BwdTArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
@@ -1133,7 +1152,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         constexpr bool PREFETCH = (C <= 64);
         if constexpr (PREFETCH) {
             xr.issue(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);
-            gr.issue(p.g_in, ch.t0 * K::TM, p.n_nodes, tid);
+            if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, ch.t0 * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, ch.t0 * K::TM, p.n_nodes, tid);
             csr.issue(sr, 0, ch.t0 * K::TM, p.n_nodes, tid);
         }
 #pragma unroll 1
@@ -1142,7 +1161,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             const int tslot = (t - ch.t0) * 8;
             if constexpr (!PREFETCH) {
                 xr.issue(p.x_in, (t + K::LEAD) * K::TM, p.n_nodes, tid);
-                gr.issue(p.g_in, t * K::TM, p.n_nodes, tid);
+                if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, t * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, t * K::TM, p.n_nodes, tid);
                 csr.issue(sr, t - ch.t0, t * K::TM, p.n_nodes, tid);
             }
 #ifdef GADAPT_STAMPS
@@ -1179,7 +1198,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
                 // of the tile: the edge phase needs every register, and the MFMA phases below cover the round trip.
                 csr.issue(sr, t + 1 - ch.t0, (t + 1) * K::TM, p.n_nodes, tid);
                 xr.issue(p.x_in, (t + 1 + K::LEAD) * K::TM, p.n_nodes, tid);
-                gr.issue(p.g_in, (t + 1) * K::TM, p.n_nodes, tid);
+                if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, (t + 1) * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, (t + 1) * K::TM, p.n_nodes, tid);
             }
             __syncthreads();
             GADAPT_STAMP(p.stamps, tslot + 4);
@@ -1360,6 +1379,7 @@ struct BwdSArgs {
     float* g_out;
     int n_nodes, n_tiles, n_edges;
     unsigned long long* stamps;
+    int g_cols;                                                 // GC kernels: g_in is [N,g_cols]
 };
 
 // Half of one node's out-edge rows: g_i and x_i of HN targets (two halves cover DM edges)
@@ -1369,7 +1389,7 @@ template <int HN_, int NV> struct SBuf {
     float2 ev[HN_];
 };
 
-template <int C>
+template <int C, bool GC = false>
 __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kernel(BwdSArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
@@ -1381,6 +1401,17 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
 
+    // row i of the upstream gradient, this lane's chunks (GC: compact [N,g_cols] source)
+    auto ld_g = [&](int i) __attribute__((always_inline)) {
+        if constexpr (GC) {
+            V r;
+#pragma unroll
+            for (int q = 0; q < K::NV; ++q) r.v[q] = ld_row4_compact(p.g_in, i, sub + q * K::LPN, p.g_cols);
+            return r;
+        } else {
+            return ld_vec<C>(p.g_in, i, sub);
+        }
+    };
     TileGemm<C, false> gemm;                                    // os = y A^T
     float arow[K::MFMA ? 1 : 4][K::MFMA ? 1 : C];
     if constexpr (K::MFMA) {
@@ -1443,7 +1474,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
                         const int i = csr.col[e0 + k];               // past the row end: some valid row, weight 0
                         b.ev[k] = *reinterpret_cast<const float2*>(csr.aux + 2 * (e0 + k));
                         if (half * HN + k >= deg) b.ev[k] = make_float2(0.f, 0.f);
-                        b.g[k] = ld_vec<C>(p.g_in, i, sub);
+                        b.g[k] = ld_g(i);
                         b.x[k] = ld_vec<C>(p.x_in, i, sub);
                     }
                 };
@@ -1474,7 +1505,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kern
                     for (int k = 0; k < deg; ++k) {
                         const int i = p.col[e0 + k];
                         const float2 ev = *reinterpret_cast<const float2*>(p.edge_ws + 2 * (size_t)(e0 + k));
-                        vaxpy(z, ev.x, ld_vec<C>(p.g_in, i, sub));
+                        vaxpy(z, ev.x, ld_g(i));
                         vaxpy(y, ev.y, ld_vec<C>(p.x_in, i, sub));
                         sig += ev.y;
                     }
@@ -1597,24 +1628,51 @@ __global__ __launch_bounds__(256) void encode_linear_kernel(const float* __restr
     const int q = threadIdx.x % c4;
     const int rows_per_block = blockDim.x / c4;
     const float4 bias = b ? *reinterpret_cast<const float4*>(b + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / c4; i < n_nodes; i += (int64_t)gridDim.x * rows_per_block) {
-        float4 v = bias;
-        // features of node i: the f0 columns of feats [N,f0], then the per-node scalars e1, e2 (GNN.py:227-239 concat)
-        const float x1 = e1 ? e1[i] : 0.f, x2 = e2 ? e2[i] : 0.f;
-        for (int k = 0; k < f0; ++k) {
-            const float xv = feats[i * f0 + k];
-            const float4 wv = wl[k * c4 + q];
-            v.x = fmaf(xv, wv.x, v.x); v.y = fmaf(xv, wv.y, v.y); v.z = fmaf(xv, wv.z, v.z); v.w = fmaf(xv, wv.w, v.w);
+    // features of node i: the f0 columns of feats [N,f0], then the per-node scalars e1, e2 (GNN.py:227-239 concat).
+    // Four rows per thread and iteration, every load of the four issued before the first use (the kernel is a pure
+    // HBM write stream: what limits it is how many stores a wave keeps in flight).
+    constexpr int R = 4;
+    const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+    for (int64_t i0 = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / c4; i0 < n_nodes; i0 += R * stride) {
+        float xv[R][4], x1[R], x2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = min(i0 + r * stride, n_nodes - 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xv[r][k] = feats[i * f0 + min(k, f0 - 1)];
+            x1[r] = e1 ? e1[i] : 0.f;
+            x2[r] = e2 ? e2[i] : 0.f;
         }
-        if (e1) {
-            const float4 wv = wl[f0 * c4 + q];
-            v.x = fmaf(x1, wv.x, v.x); v.y = fmaf(x1, wv.y, v.y); v.z = fmaf(x1, wv.z, v.z); v.w = fmaf(x1, wv.w, v.w);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = i0 + r * stride;
+            if (i >= n_nodes) break;
+            float4 v = bias;
+            if (f0 <= 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < f0) {
+                        const float4 wv = wl[k * c4 + q];
+                        v.x = fmaf(xv[r][k], wv.x, v.x); v.y = fmaf(xv[r][k], wv.y, v.y); v.z = fmaf(xv[r][k], wv.z, v.z); v.w = fmaf(xv[r][k], wv.w, v.w);
+                    }
+                }
+            } else {
+                for (int k = 0; k < f0; ++k) {
+                    const float xk = feats[i * f0 + k];
+                    const float4 wv = wl[k * c4 + q];
+                    v.x = fmaf(xk, wv.x, v.x); v.y = fmaf(xk, wv.y, v.y); v.z = fmaf(xk, wv.z, v.z); v.w = fmaf(xk, wv.w, v.w);
+                }
+            }
+            if (e1) {
+                const float4 wv = wl[f0 * c4 + q];
+                v.x = fmaf(x1[r], wv.x, v.x); v.y = fmaf(x1[r], wv.y, v.y); v.z = fmaf(x1[r], wv.z, v.z); v.w = fmaf(x1[r], wv.w, v.w);
+            }
+            if (e2) {
+                const float4 wv = wl[(f - 1) * c4 + q];
+                v.x = fmaf(x2[r], wv.x, v.x); v.y = fmaf(x2[r], wv.y, v.y); v.z = fmaf(x2[r], wv.z, v.z); v.w = fmaf(x2[r], wv.w, v.w);
+            }
+            *reinterpret_cast<float4*>(x0 + i * c + 4 * q) = v;
         }
-        if (e2) {
-            const float4 wv = wl[(f - 1) * c4 + q];
-            v.x = fmaf(x2, wv.x, v.x); v.y = fmaf(x2, wv.y, v.y); v.z = fmaf(x2, wv.z, v.z); v.w = fmaf(x2, wv.w, v.w);
-        }
-        *reinterpret_cast<float4*>(x0 + i * c + 4 * q) = v;
     }
 }
 
@@ -1692,11 +1750,40 @@ __global__ __launch_bounds__(256) void loss_forward_kernel(const float* __restri
     const int64_t total = n_rows * d;
     const float inv = 1.0f / (float)total;
     float lv = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * 256) {   // one row per thread
-        for (int k = 0; k < d; ++k) {
-            const float diff = pred[i * pred_stride + k] - target[i * d + k];
-            if (l1) { lv += fabsf(diff); seed[i * d + k] = (diff > 0.f ? inv : (diff < 0.f ? -inv : 0.f)); }
-            else    { lv = fmaf(diff, diff, lv); seed[i * d + k] = 2.0f * diff * inv; }
+    // one row per thread and slot, four slots per iteration with every load issued before the first use (rows of `pred`
+    // are pred_stride floats apart: each read is its own cache line, so the kernel lives on loads in flight)
+    constexpr int R = 4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n_rows; i0 += R * stride) {
+        float pv[R][4], tv[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = min(i0 + r * stride, n_rows - 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < d) { pv[r][k] = pred[i * pred_stride + k]; tv[r][k] = target[i * d + k]; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = i0 + r * stride;
+            if (i >= n_rows) break;
+            if (d <= 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < d) {
+                        const float diff = pv[r][k] - tv[r][k];
+                        if (l1) { lv += fabsf(diff); seed[i * d + k] = (diff > 0.f ? inv : (diff < 0.f ? -inv : 0.f)); }
+                        else    { lv = fmaf(diff, diff, lv); seed[i * d + k] = 2.0f * diff * inv; }
+                    }
+                }
+            } else {
+                for (int k = 0; k < d; ++k) {
+                    const float diff = pred[i * pred_stride + k] - target[i * d + k];
+                    if (l1) { lv += fabsf(diff); seed[i * d + k] = (diff > 0.f ? inv : (diff < 0.f ? -inv : 0.f)); }
+                    else    { lv = fmaf(diff, diff, lv); seed[i * d + k] = 2.0f * diff * inv; }
+                }
+            }
         }
     }
     red[threadIdx.x] = lv;
@@ -1711,7 +1798,8 @@ __global__ __launch_bounds__(256) void loss_forward_kernel(const float* __restri
     if (ticket != gridDim.x - 1) return;
     __threadfence();
     float v = 0.f;
-    if (threadIdx.x < gridDim.x) v = __hip_atomic_load(scratch + 1 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned k = threadIdx.x; k < gridDim.x; k += 256)      // fixed order per thread, then the fixed tree below
+        v += __hip_atomic_load(scratch + 1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     red[threadIdx.x] = v;
     __syncthreads();
     for (int s_ = 128; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_]; __syncthreads(); }
@@ -1784,6 +1872,7 @@ static inline int wide_grid(int n_steps) {
 static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                            const float* lp, float* alpha_out, int residual_only, hipStream_t st) {
     const int n_steps = (g->n_nodes + wide::STEP - 1) / wide::STEP;
+    (void)0;
     wide::FwdArgs p{x_in, x_out, a, p0, lp, g->ell_t, g->rowptr_t, alpha_out, g->n_nodes, n_steps, residual_only, g->wide_deg_t, nullptr};
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
@@ -1793,6 +1882,30 @@ static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_ou
     allow_lds(wide::fwd_kernel, lds);
     hipLaunchKernelGGL(wide::fwd_kernel, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
     return check_launch("wide::fwd_kernel");
+}
+static bool wide_bwd_t_enabled() {
+    static const bool on = [] { const char* e = getenv("GADAPT_WIDE_BWD_T"); return e && e[0] == '1'; }();   // opt-in: slower than the tiled pass (register spills)
+    return on;
+}
+extern "C" int gadapt_backward_slab_rows(int64_t n_nodes, int c);
+static int launch_wide_bwd_t(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha, const float* a,
+                             const float* lp, float* edge_ws, float* dxd, float* slab, int accumulate, int residual_only, bool with_g, hipStream_t st) {
+    const int n_steps = (g->n_nodes + wide::STEP - 1) / wide::STEP;
+    wide::BwdTArgs p{x_in, g_in, alpha, a, lp, g->ell_t, g->rowptr_t, g->tpos_s, reinterpret_cast<float2*>(edge_ws), dxd, slab,
+                     g->n_nodes, n_steps, g->n_edges, accumulate, residual_only, g->wide_deg_t, gadapt_backward_slab_rows(g->n_nodes, 64), nullptr};
+#ifdef GADAPT_STAMPS
+    p.stamps = g_stamp_buf ? g_stamp_buf + 1024 * 32 : nullptr;
+#endif
+    ProfScope prof(1, st);
+    constexpr int lds = wide::bwd_t_lds_bytes();
+    if (with_g) {
+        allow_lds(wide::bwd_target_kernel<true>, lds);
+        hipLaunchKernelGGL(wide::bwd_target_kernel<true>, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
+    } else {
+        allow_lds(wide::bwd_target_kernel<false>, lds);
+        hipLaunchKernelGGL(wide::bwd_target_kernel<false>, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
+    }
+    return check_launch("wide::bwd_target_kernel");
 }
 
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
@@ -1814,19 +1927,27 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
 }
 template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha,
                                        const float* a, const float* p0, const float* lp, float* edge_ws, float* dxd, float* slab,
-                                       int accumulate, float* sums_out, float* g_out, int residual_only, hipStream_t st) {
+                                       int accumulate, float* sums_out, float* g_out, int residual_only, int g_cols, hipStream_t st) {
     using K = Cfg<C>;
     const int n_tiles = (g->n_nodes + K::TM - 1) / K::TM;
+    if (g_cols < 0 || g_cols > 4 || (g_cols && sums_out)) return fail(GADAPT_E_BADARG, "compact upstream gradient: 1..4 columns, without d dt / d scale sums");
     BwdTArgs pt{x_in, g_in, alpha, a, lp, g->rowptr_t, g->col_t, g->tpos_s, meta_for<K::TM>(g->meta_t), reinterpret_cast<float2*>(edge_ws), dxd, slab, sums_out,
-                g->n_nodes, n_tiles, accumulate, residual_only, g->n_edges, nullptr};
+                g->n_nodes, n_tiles, accumulate, residual_only, g->n_edges, nullptr, g_cols};
 #ifdef GADAPT_STAMPS
     pt.stamps = g_stamp_buf ? g_stamp_buf + 1024 * 32 : nullptr;
 #endif
     constexpr int lds_t = K::lds_bytes(1, K::RING + 1, 1), lds_s = K::lds_bytes(2);
     int rc;
-    {
+    bool wide_t = false;
+    if constexpr (C == 64) wide_t = g->ell_t && g->wide_deg_t > 0 && !sums_out && !g_cols && g->n_edges > 0 && wide_enabled() && wide_bwd_t_enabled();
+    if (wide_t) {
+        rc = launch_wide_bwd_t(g, x_in, g_in, alpha, a, lp, edge_ws, dxd, slab, accumulate, residual_only, /*with_g=*/true, st);
+    } else {
         ProfScope prof(1, st);
-        if (sums_out) {
+        if (g_cols) {
+            allow_lds(grand_bwd_target_kernel<C, false, true>, lds_t);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true>), dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
+        } else if (sums_out) {
             allow_lds(grand_bwd_target_kernel<C, true>, lds_t);
             hipLaunchKernelGGL((grand_bwd_target_kernel<C, true>), dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
         } else {
@@ -1836,13 +1957,18 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
         rc = check_launch("grand_bwd_target_kernel");
     }
     if (rc || !g_out) return rc;
-    BwdSArgs ps{x_in, g_in, edge_ws, dxd, a, p0, g->rowptr_s, g->col_s, meta_for<K::TM>(g->meta_s), g_out, g->n_nodes, n_tiles, g->n_edges, nullptr};
+    BwdSArgs ps{x_in, g_in, edge_ws, dxd, a, p0, g->rowptr_s, g->col_s, meta_for<K::TM>(g->meta_s), g_out, g->n_nodes, n_tiles, g->n_edges, nullptr, g_cols};
 #ifdef GADAPT_STAMPS
     ps.stamps = g_stamp_buf ? g_stamp_buf + 2 * 1024 * 32 : nullptr;
 #endif
-    allow_lds(grand_bwd_source_kernel<C>, lds_s);
     ProfScope prof(2, st);
-    hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, GADAPT_BWD_S_MAX_BLOCKS)), dim3(256), lds_s, st, ps);
+    if (g_cols) {
+        allow_lds(grand_bwd_source_kernel<C, true>, lds_s);
+        hipLaunchKernelGGL((grand_bwd_source_kernel<C, true>), dim3(grid_for(n_tiles, GADAPT_BWD_S_MAX_BLOCKS)), dim3(256), lds_s, st, ps);
+    } else {
+        allow_lds(grand_bwd_source_kernel<C>, lds_s);
+        hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, GADAPT_BWD_S_MAX_BLOCKS)), dim3(256), lds_s, st, ps);
+    }
     return check_launch("grand_bwd_source_kernel");
 }
 
@@ -1908,7 +2034,7 @@ extern "C" int gadapt_layer_backward(const gadapt_graph* g, const float* x_in, c
     if (!g->tpos_s || (g_out && (!g->rowptr_s || !g->col_s))) return fail(GADAPT_E_BADARG, "layer_backward: source CSR missing");
     if (g_out == g_in || g_out == dxd_ws) return fail(GADAPT_E_BADARG, "layer_backward: g_out aliases an input");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, residual_only, st));
+    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, residual_only, 0, st));
 }
 
 extern "C" int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch, float* d_a, float* d_p0, int c, void* stream) {
@@ -1949,8 +2075,9 @@ static int launch_encode(const float* feats, int f0, const float* e1, const floa
     if (c % 4 || c > 256 || 256 % (c / 4) || (int64_t)c * f > GADAPT_ENC_MAX_WORDS)
         return fail(GADAPT_E_BADARG, "encode: need hidden_dim in {4,8,...,256} dividing 1024 and hidden_dim*in_dim <= 4096");
     const int rows_per_block = 256 / (c / 4);
-    int64_t blocks = (n_nodes + rows_per_block - 1) / rows_per_block;
-    if (blocks > 4096) blocks = 4096;
+    int64_t blocks = (n_nodes + 4 * rows_per_block - 1) / (4 * rows_per_block);    // four rows per thread and iteration
+    if (blocks > 1024) blocks = 1024;                                              // resident set: the W^T table is staged once per block
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(encode_linear_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), feats, f0, e1, e2, w, b,
                        x0, n_nodes, f, c);
     return check_launch("encode_linear_kernel");
@@ -2019,7 +2146,12 @@ extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int n_l
     return GADAPT_OK;
 }
 
-extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, const float* alpha_all, const float* g_top, int n_layers,
+static int layer_backward_cols(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha, const float* a,
+                               const float* p0, const float* layer_params, float* edge_ws, float* dxd_ws, float* slab, int accumulate,
+                               float* sums_out, float* g_out, int g_cols, int c, hipStream_t st) {
+    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, 0, g_cols, st));
+}
+extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, const float* alpha_all, const float* g_top, int g_top_cols, int n_layers,
                                      const float* a, int64_t a_stride, const float* p0, int64_t p0_stride, const float* layer_params,
                                      float* g_ws, float* dxd_ws, float* edge_ws, float* slab, float* d_layer_params, float* d_x0,
                                      int c, void* stream) {
@@ -2035,9 +2167,17 @@ extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, 
         float* g_next = (l == 0) ? d_x0 : g_ws + ((n_layers - 1 - l) & 1) * nc;
         float* slab_l = shared ? slab : slab + (size_t)l * slab_floats;
         const int accumulate = (shared && l != n_layers - 1) ? 1 : 0;
-        int rc = gadapt_layer_backward(g, x_all + l * nc, g_cur, alpha_all + (size_t)l * g->n_edges, a + l * a_stride, p0 + l * p0_stride,
+        int rc;
+        if (l == n_layers - 1 && g_top_cols > 0) {                  // compact upstream gradient [N,g_top_cols]
+            if (!g->tpos_s || (g_next && (!g->rowptr_s || !g->col_s))) return fail(GADAPT_E_BADARG, "block_backward: source CSR missing");
+            rc = layer_backward_cols(g, x_all + l * nc, g_cur, alpha_all + (size_t)l * g->n_edges, a + l * a_stride, p0 + l * p0_stride,
+                                     layer_params + 2 * l, edge_ws, dxd_ws, slab_l, accumulate,
+                                     d_layer_params ? d_layer_params + 2 * l : nullptr, g_next, g_top_cols, c, static_cast<hipStream_t>(stream));
+        } else {
+            rc = gadapt_layer_backward(g, x_all + l * nc, g_cur, alpha_all + (size_t)l * g->n_edges, a + l * a_stride, p0 + l * p0_stride,
                                        layer_params + 2 * l, edge_ws, dxd_ws, slab_l, accumulate,
                                        d_layer_params ? d_layer_params + 2 * l : nullptr, g_next, 0, c, stream);
+        }
         if (rc) return rc;
         g_cur = g_next;
     }

@@ -89,9 +89,13 @@ class _GrandEulerBlock(torch.autograd.Function):
         n = graph.num_nodes
         dev, st = g_top.device, current_stream(g_top.device)
         g_top = g_top.contiguous()
-        if ctx.out_cols is not None:            # one zero-padding pass instead of autograd's zeros + slice copy
-            g_phys, g_top = g_top, torch.empty(n, c, device=dev, dtype=torch.float32)
-            check(lib().gadapt_pad_columns(ptr(g_phys), ptr(g_top), n, ctx.out_cols, c, st), 'gadapt_pad_columns')
+        g_cols = 0
+        if ctx.out_cols is not None:
+            if ctx.out_cols <= 4 and not ctx.needs_input_grad[5]:
+                g_cols = int(ctx.out_cols)      # the top layer's kernels read the compact [N,dim] gradient directly
+            else:                               # one zero-padding pass instead of autograd's zeros + slice copy
+                g_phys, g_top = g_top, torch.empty(n, c, device=dev, dtype=torch.float32)
+                check(lib().gadapt_pad_columns(ptr(g_phys), ptr(g_top), n, ctx.out_cols, c, st), 'gadapt_pad_columns')
         need_x0 = ctx.needs_input_grad[0]
         slab_floats = lib().gadapt_backward_slab_floats(n, c)
         slab_rows = lib().gadapt_backward_slab_rows(n, c)
@@ -101,7 +105,7 @@ class _GrandEulerBlock(torch.autograd.Function):
         slab = torch.empty(S, slab_floats, device=dev, dtype=torch.float32)
         d_lp = torch.zeros(L, 2, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
         d_x0 = torch.empty(n, c, device=dev, dtype=torch.float32) if need_x0 else None
-        check(lib().gadapt_block_backward(graph.c_ref, ptr(x_all), ptr(alpha), ptr(g_top), L,
+        check(lib().gadapt_block_backward(graph.c_ref, ptr(x_all), ptr(alpha), ptr(g_top), g_cols, L,
                                           ptr(a), c * c if S > 1 else 0, ptr(p0), c if S > 1 else 0, ptr(layer_params),
                                           ptr(g_ws), ptr(dxd_ws), ptr(edge_ws), ptr(slab), ptr(d_lp), ptr(d_x0), c, st),
               'gadapt_block_backward')

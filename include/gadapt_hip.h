@@ -150,12 +150,14 @@ int gadapt_block_forward(const gadapt_graph* g, float* x_all, int n_layers,
                          const float* a, int64_t a_stride, const float* p0, int64_t p0_stride,
                          const float* layer_params, float* alpha_all, int c, void* stream);
 
-/* Backward of the block.  g_top = dL/dx_all[L] (not modified).  g_ws: 2*N*C floats,
+/* Backward of the block.  g_top = dL/dx_all[L] (not modified): [N,C] when g_top_cols = 0, or the compact [N,g_top_cols]
+ * (1..4 columns, zero beyond: the backward of x_phys = x[:, :dim], GNN.py:299, without materialising the padded
+ * matrix; not together with d_layer_params).  g_ws: 2*N*C floats,
  * dxd_ws: N*C, edge_ws: 2*E, slab: n_slots*gadapt_backward_slab_floats(N,c) with
  * n_slots = 1 (shared weights) or L.  d_layer_params (nullable) [L,2] accumulates.
  * d_x0 (nullable) [N,C] receives dL/dx_all[0]. */
 int gadapt_block_backward(const gadapt_graph* g, const float* x_all, const float* alpha_all,
-                          const float* g_top, int n_layers,
+                          const float* g_top, int g_top_cols, int n_layers,
                           const float* a, int64_t a_stride, const float* p0, int64_t p0_stride,
                           const float* layer_params,
                           float* g_ws, float* dxd_ws, float* edge_ws, float* slab,

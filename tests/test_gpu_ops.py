@@ -440,6 +440,6 @@ def test_wide_kernels_rebase_large_scores(gpu_device):
     ref, (alpha_ref, _, _) = grand_residual(x.double(), ei, wq.double(), bq.double(), wk.double(), bk.double(), return_attention=True)
     res, alpha, *_ = _conv_run(gpu_device, ei, x, up, (wq, bq, wk, bk), True)
     sc = (alpha_ref.view(-1) > 0.5).float().mean().item()
-    assert sc > 0.3                                                 # the case is what it claims: mostly one-hot rows
+    assert sc > 0.12                                                # the case is what it claims: most rows (~6 edges) are one-hot
     assert rel_err(alpha, alpha_ref.view(-1))[0] <= 2e-5, rel_err(alpha, alpha_ref.view(-1))
     assert rel_err(res, ref)[0] <= 2e-5, rel_err(res, ref)
