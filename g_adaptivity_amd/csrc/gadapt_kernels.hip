@@ -483,6 +483,16 @@ __device__ __forceinline__ float4 ld_row4_compact(const float* __restrict__ base
     float4 o = make_float4(v0, d > 1 ? v1 : 0.f, d > 2 ? v2 : 0.f, d > 3 ? v3 : 0.f);
     return c4 == 0 ? o : f4zero();
 }
+// Chunk c4 of row `row` of x: dense [N,C], or (XC) the compact [N,4] whose columns 4.. are zero by construction - the
+// output of the identity encoder (zero-pad, GNN.py:75-82) that layer 0 reads without it ever being materialised.
+template <int C, bool XC> __device__ __forceinline__ float4 ld_row4x(const float* __restrict__ base, int row, int c4) {
+    if constexpr (XC) {
+        const float4 t = *reinterpret_cast<const float4*>(base + 4 * (size_t)row);   // unconditional (see TileCsr::issue)
+        return c4 == 0 ? t : f4zero();
+    } else {
+        return ld_row4<C>(base, row, c4);
+    }
+}
 // x-tile rows of a tile held in registers between issue and commit (same split as TileCsr)
 template <int C> struct TileRows {
     using K = Cfg<C>;
@@ -497,6 +507,14 @@ template <int C> struct TileRows {
         for (int q = 0; q < XQ; ++q) {
             const int idx = min(q * 256 + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
             v[q] = ld_row4<C>(src, min(max(node0 + r, 0), n_nodes - 1), c4);
+        }
+    }
+    template <bool XC> __device__ __forceinline__ void issue_sel(const float* __restrict__ src, int node0, int n_nodes, int tid) {
+        node0_ = node0;
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = min(q * 256 + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
+            v[q] = ld_row4x<C, XC>(src, min(max(node0 + r, 0), n_nodes - 1), c4);
         }
     }
     // same for a compact [N,d] source (ld_row4_compact)
@@ -663,6 +681,12 @@ template <int C> __device__ __forceinline__ Vec<Cfg<C>::NV> ld_vec(const float* 
     for (int i = 0; i < Cfg<C>::NV; ++i) r.v[i] = ld_row4<C>(base, row, sub + i * Cfg<C>::LPN);
     return r;
 }
+template <int C, bool XC> __device__ __forceinline__ Vec<Cfg<C>::NV> ld_xsel(const float* __restrict__ base, int row, int sub) {
+    Vec<Cfg<C>::NV> r;
+#pragma unroll
+    for (int i = 0; i < Cfg<C>::NV; ++i) r.v[i] = ld_row4x<C, XC>(base, row, sub + i * Cfg<C>::LPN);
+    return r;
+}
 template <int C> __device__ __forceinline__ void st_vec(float* __restrict__ base, int row, int sub, const Vec<Cfg<C>::NV>& x) {
 #pragma unroll
     for (int i = 0; i < Cfg<C>::NV; ++i) st_row4<C>(base, row, sub + i * Cfg<C>::LPN, x.v[i]);
@@ -697,7 +721,8 @@ template <int NROWS, int NV> struct RowBuf {
     int deg, el0;
 };
 
-template <int C>
+// XC: x_in is the compact [N,4] encoder output (layer 0, identity encoder): see ld_row4x
+template <int C, bool XC = false>
 __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
@@ -776,7 +801,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < DM; ++k) b.r[k] = ld_vec<C>(p.x_in, csr.col[b.el0 + k], sub);
+            for (int k = 0; k < DM; ++k) b.r[k] = ld_xsel<C, XC>(p.x_in, csr.col[b.el0 + k], sub);
         }
     };
 
@@ -832,14 +857,14 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
         const int e0 = p.rowptr[i], deg = p.rowptr[i + 1] - e0;
         float mx = -INFINITY;
         for (int k = 0; k < deg; ++k)
-            mx = fmaxf(mx, group_sum<K::LPN>(vdot(Pi, ld_vec<C>(p.x_in, p.col[e0 + k], sub))) * sc);
+            mx = fmaxf(mx, group_sum<K::LPN>(vdot(Pi, ld_xsel<C, XC>(p.x_in, p.col[e0 + k], sub))) * sc);
         float den = 0.f;
         for (int k = 0; k < deg; ++k)
-            den += __expf(group_sum<K::LPN>(vdot(Pi, ld_vec<C>(p.x_in, p.col[e0 + k], sub))) * sc - mx);
+            den += __expf(group_sum<K::LPN>(vdot(Pi, ld_xsel<C, XC>(p.x_in, p.col[e0 + k], sub))) * sc - mx);
         const float inv = 1.0f / (den + 1e-16f);
         V m; m.zero();
         for (int k = 0; k < deg; ++k) {
-            const V v = ld_vec<C>(p.x_in, p.col[e0 + k], sub);
+            const V v = ld_xsel<C, XC>(p.x_in, p.col[e0 + k], sub);
             const float a = __expf(group_sum<K::LPN>(vdot(Pi, v)) * sc - mx) * inv;
             vaxpy(m, a, v);
             if (p.alpha_out && (k % K::LPN) == sub) p.alpha_out[e0 + k] = a;
@@ -863,14 +888,14 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, p.p0);   // B fragments stay in registers for the whole launch
     csr.load_metas(ch.t0, 1, p.n_tiles, tid);
     if constexpr (K::RING == 3) {
-        xrA.issue(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
-        xrA.issue(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0), p.n_nodes, tid);
+        xrA.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
+        xrA.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0), p.n_nodes, tid);
     }
     __syncthreads();                                             // tile metadata visible
-    xrA.issue(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);   // rows past N come back as zeros
+    xrA.template issue_sel<XC>(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);   // rows past N come back as zeros
     csr.issue(srA, 0, ch.t0 * K::TM, p.n_nodes, tid);
     if constexpr (AHEAD == 2) {
-        xrB.issue(p.x_in, (ch.t0 + 2) * K::TM, p.n_nodes, tid);
+        xrB.template issue_sel<XC>(p.x_in, (ch.t0 + 2) * K::TM, p.n_nodes, tid);
         csr.issue(srB, 1, (ch.t0 + 1) * K::TM, p.n_nodes, tid);
     }
 
@@ -901,7 +926,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
         }
         {   // this register set's next job: tile t+AHEAD (slab t+AHEAD+LEAD).  Unconditional (clamped past the chunk end): see issue()
             csr.issue(sr, t + AHEAD - ch.t0, (t + AHEAD) * K::TM, p.n_nodes, tid);
-            xr.issue(p.x_in, (t + AHEAD + K::LEAD) * K::TM, p.n_nodes, tid);
+            xr.template issue_sel<XC>(p.x_in, (t + AHEAD + K::LEAD) * K::TM, p.n_nodes, tid);
         }
         if constexpr (K::RING != 3) {
             if constexpr (K::MFMA) { gemm.run(xs, ps); __syncthreads(); }
@@ -962,7 +987,8 @@ template <int NROWS, int NV> struct TBuf {
 // so on mesh-ordered graphs the x_j gathers are LDS reads.  Per tile the fourth LDS tile holds g (staged with the
 // ring slab), then dP (written over g row by row by the lanes that read it), then dP A (in place).
 // GC: the upstream gradient is compact, [N,g_cols] (top layer: backward of the x[:, :dim] slice) - only its staging differs.
-template <int C, bool SUMS, bool GC = false>
+// XC: x_in is the compact [N,4] encoder output (layer 0): see ld_row4x.
+template <int C, bool SUMS, bool GC = false, bool XC = false>
 __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kernel(BwdTArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
@@ -1045,7 +1071,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < DM; ++k) b.r[k] = ld_vec<C>(p.x_in, csr.col[b.el0 + k], sub);   // k >= deg: some valid row, weight 0
+            for (int k = 0; k < DM; ++k) b.r[k] = ld_xsel<C, XC>(p.x_in, csr.col[b.el0 + k], sub);   // k >= deg: some valid row, weight 0
         }
     };
 
@@ -1107,9 +1133,9 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             const int e0 = p.rowptr[i], deg = p.rowptr[i + 1] - e0;
             float D = 0.f;
             for (int k = 0; k < deg; ++k)
-                D = fmaf(p.alpha[e0 + k], group_sum<K::LPN>(vdot(dm, ld_vec<C>(p.x_in, p.col[e0 + k], sub))), D);
+                D = fmaf(p.alpha[e0 + k], group_sum<K::LPN>(vdot(dm, ld_xsel<C, XC>(p.x_in, p.col[e0 + k], sub))), D);
             for (int k = 0; k < deg; ++k) {
-                const V v = ld_vec<C>(p.x_in, p.col[e0 + k], sub);
+                const V v = ld_xsel<C, XC>(p.x_in, p.col[e0 + k], sub);
                 const float ak = p.alpha[e0 + k];
                 const float dsp = ak * (group_sum<K::LPN>(vdot(dm, v)) - D);
                 const float dss = dsp * sc;
@@ -1144,14 +1170,14 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
         csr.load_metas(ch.t0, 1, p.n_tiles, tid);
         if constexpr (K::RING == 3) {
-            xr.issue(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
-            xr.issue(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0), p.n_nodes, tid);
+            xr.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
+            xr.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0), p.n_nodes, tid);
         }
         __syncthreads();                                        // tile metadata visible
         // C = 128 has no registers to hold a tile across the edge walk: it stages at the top of the tile instead
         constexpr bool PREFETCH = (C <= 64);
         if constexpr (PREFETCH) {
-            xr.issue(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);
+            xr.template issue_sel<XC>(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);
             if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, ch.t0 * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, ch.t0 * K::TM, p.n_nodes, tid);
             csr.issue(sr, 0, ch.t0 * K::TM, p.n_nodes, tid);
         }
@@ -1160,7 +1186,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             const int node0 = t * K::TM;
             const int tslot = (t - ch.t0) * 8;
             if constexpr (!PREFETCH) {
-                xr.issue(p.x_in, (t + K::LEAD) * K::TM, p.n_nodes, tid);
+                xr.template issue_sel<XC>(p.x_in, (t + K::LEAD) * K::TM, p.n_nodes, tid);
                 if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, t * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, t * K::TM, p.n_nodes, tid);
                 csr.issue(sr, t - ch.t0, t * K::TM, p.n_nodes, tid);
             }
@@ -1197,7 +1223,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
                 // request the next tile (unconditional, clamped past the end: see issue()).  Here rather than at the top
                 // of the tile: the edge phase needs every register, and the MFMA phases below cover the round trip.
                 csr.issue(sr, t + 1 - ch.t0, (t + 1) * K::TM, p.n_nodes, tid);
-                xr.issue(p.x_in, (t + 1 + K::LEAD) * K::TM, p.n_nodes, tid);
+                xr.template issue_sel<XC>(p.x_in, (t + 1 + K::LEAD) * K::TM, p.n_nodes, tid);
                 if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, (t + 1) * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, (t + 1) * K::TM, p.n_nodes, tid);
             }
             __syncthreads();
@@ -1870,7 +1896,7 @@ static inline int wide_grid(int n_steps) {
     return g;
 }
 static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
-                           const float* lp, float* alpha_out, int residual_only, hipStream_t st) {
+                           const float* lp, float* alpha_out, int residual_only, int x_cols, hipStream_t st) {
     const int n_steps = (g->n_nodes + wide::STEP - 1) / wide::STEP;
     (void)0;
     wide::FwdArgs p{x_in, x_out, a, p0, lp, g->ell_t, g->rowptr_t, alpha_out, g->n_nodes, n_steps, residual_only, g->wide_deg_t, nullptr};
@@ -1879,8 +1905,13 @@ static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_ou
 #endif
     ProfScope prof(0, st);
     constexpr int lds = wide::fwd_lds_bytes();
-    allow_lds(wide::fwd_kernel, lds);
-    hipLaunchKernelGGL(wide::fwd_kernel, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
+    if (x_cols) {
+        allow_lds(wide::fwd_kernel<true>, lds);
+        hipLaunchKernelGGL(wide::fwd_kernel<true>, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
+    } else {
+        allow_lds(wide::fwd_kernel<false>, lds);
+        hipLaunchKernelGGL(wide::fwd_kernel<false>, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
+    }
     return check_launch("wide::fwd_kernel");
 }
 static bool wide_bwd_t_enabled() {
@@ -1909,10 +1940,11 @@ static int launch_wide_bwd_t(const gadapt_graph* g, const float* x_in, const flo
 }
 
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
-                                       const float* lp, float* alpha_out, int residual_only, hipStream_t st) {
+                                       const float* lp, float* alpha_out, int residual_only, int x_cols, hipStream_t st) {
     using K = Cfg<C>;
+    if (x_cols != 0 && x_cols != 4) return fail(GADAPT_E_BADARG, "compact layer input: 4 columns");
     if constexpr (C == 64) {
-        if (g->ell_t && g->wide_deg_t > 0 && wide_enabled()) return launch_wide_fwd(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, st);
+        if (g->ell_t && g->wide_deg_t > 0 && wide_enabled()) return launch_wide_fwd(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, x_cols, st);
     }
     FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t), alpha_out, g->n_nodes,
               (g->n_nodes + K::TM - 1) / K::TM, residual_only, g->n_edges, nullptr};
@@ -1921,16 +1953,23 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
 #endif
     ProfScope prof(0, st);
     constexpr int lds = K::lds_bytes(0, K::RING + 1);
-    allow_lds(grand_fwd_kernel<C>, lds);
-    hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds, st, p);
+    if (x_cols) {
+        allow_lds(grand_fwd_kernel<C, true>, lds);
+        hipLaunchKernelGGL((grand_fwd_kernel<C, true>), dim3(grid_for(p.n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds, st, p);
+    } else {
+        allow_lds(grand_fwd_kernel<C>, lds);
+        hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds, st, p);
+    }
     return check_launch("grand_fwd_kernel");
 }
 template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha,
                                        const float* a, const float* p0, const float* lp, float* edge_ws, float* dxd, float* slab,
-                                       int accumulate, float* sums_out, float* g_out, int residual_only, int g_cols, hipStream_t st) {
+                                       int accumulate, float* sums_out, float* g_out, int residual_only, int g_cols, int x_cols, hipStream_t st) {
     using K = Cfg<C>;
     const int n_tiles = (g->n_nodes + K::TM - 1) / K::TM;
     if (g_cols < 0 || g_cols > 4 || (g_cols && sums_out)) return fail(GADAPT_E_BADARG, "compact upstream gradient: 1..4 columns, without d dt / d scale sums");
+    if ((x_cols != 0 && x_cols != 4) || (x_cols && (sums_out || g_cols || g_out)))
+        return fail(GADAPT_E_BADARG, "compact layer input: 4 columns, layer 0 of a block of >= 2 layers, no d x0 / d dt / d scale");
     BwdTArgs pt{x_in, g_in, alpha, a, lp, g->rowptr_t, g->col_t, g->tpos_s, meta_for<K::TM>(g->meta_t), reinterpret_cast<float2*>(edge_ws), dxd, slab, sums_out,
                 g->n_nodes, n_tiles, accumulate, residual_only, g->n_edges, nullptr, g_cols};
 #ifdef GADAPT_STAMPS
@@ -1939,12 +1978,15 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     constexpr int lds_t = K::lds_bytes(1, K::RING + 1, 1), lds_s = K::lds_bytes(2);
     int rc;
     bool wide_t = false;
-    if constexpr (C == 64) wide_t = g->ell_t && g->wide_deg_t > 0 && !sums_out && !g_cols && g->n_edges > 0 && wide_enabled() && wide_bwd_t_enabled();
+    if constexpr (C == 64) wide_t = g->ell_t && g->wide_deg_t > 0 && !sums_out && !g_cols && !x_cols && g->n_edges > 0 && wide_enabled() && wide_bwd_t_enabled();
     if (wide_t) {
         rc = launch_wide_bwd_t(g, x_in, g_in, alpha, a, lp, edge_ws, dxd, slab, accumulate, residual_only, /*with_g=*/true, st);
     } else {
         ProfScope prof(1, st);
-        if (g_cols) {
+        if (x_cols) {
+            allow_lds(grand_bwd_target_kernel<C, false, false, true>, lds_t);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, true>), dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
+        } else if (g_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, true>, lds_t);
             hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true>), dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
         } else if (sums_out) {
@@ -2012,7 +2054,7 @@ extern "C" int gadapt_layer_forward(const gadapt_graph* g, const float* x_in, fl
     if (int rc = check_graph(g, c)) return rc;
     if (!x_in || !x_out || !a || !p0 || !layer_params || x_in == x_out) return fail(GADAPT_E_BADARG, "layer_forward: null or aliased pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    GADAPT_DISPATCH_C(c, launch_fwd<CC>(g, x_in, x_out, a, p0, layer_params, alpha_out, residual_only, st));
+    GADAPT_DISPATCH_C(c, launch_fwd<CC>(g, x_in, x_out, a, p0, layer_params, alpha_out, residual_only, 0, st));
 }
 
 template <int C> static int tiles_for(int64_t n_nodes) { return (int)((n_nodes + Cfg<C>::TM - 1) / Cfg<C>::TM); }
@@ -2034,7 +2076,7 @@ extern "C" int gadapt_layer_backward(const gadapt_graph* g, const float* x_in, c
     if (!g->tpos_s || (g_out && (!g->rowptr_s || !g->col_s))) return fail(GADAPT_E_BADARG, "layer_backward: source CSR missing");
     if (g_out == g_in || g_out == dxd_ws) return fail(GADAPT_E_BADARG, "layer_backward: g_out aliases an input");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, residual_only, 0, st));
+    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, residual_only, 0, 0, st));
 }
 
 extern "C" int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch, float* d_a, float* d_p0, int c, void* stream) {
@@ -2133,13 +2175,22 @@ extern "C" int gadapt_adam_step(float* param, const float* grad, float* exp_avg,
 // ------------------------------------------------------------------------------------------------
 // L-step Euler block (GNN.py:273-291)
 // ------------------------------------------------------------------------------------------------
-extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int n_layers, const float* a, int64_t a_stride,
+static int layer_forward_cols(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0, const float* layer_params,
+                              float* alpha_out, int x_cols, int c, hipStream_t st) {
+    GADAPT_DISPATCH_C(c, launch_fwd<CC>(g, x_in, x_out, a, p0, layer_params, alpha_out, 0, x_cols, st));
+}
+extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_cols, int n_layers, const float* a, int64_t a_stride,
                                     const float* p0, int64_t p0_stride, const float* layer_params, float* alpha_all, int c, void* stream) {
     if (int rc = check_graph(g, c)) return rc;
     if (!x_all || n_layers <= 0 || !a || !p0 || !layer_params) return fail(GADAPT_E_BADARG, "block_forward: bad argument");
+    if (x0_cols != 0 && (x0_cols != 4 || n_layers < 2 || c < 8)) return fail(GADAPT_E_BADARG, "block_forward: compact x0 needs 4 columns, >= 2 layers, hidden >= 8");
     const size_t nc = (size_t)g->n_nodes * c;
     for (int l = 0; l < n_layers; ++l) {
-        int rc = gadapt_layer_forward(g, x_all + l * nc, x_all + (l + 1) * nc, a + l * a_stride, p0 + l * p0_stride,
+        int rc;
+        if (l == 0 && x0_cols)
+            rc = layer_forward_cols(g, x_all, x_all + nc, a, p0, layer_params, alpha_all, x0_cols, c, static_cast<hipStream_t>(stream));
+        else
+            rc = gadapt_layer_forward(g, x_all + l * nc, x_all + (l + 1) * nc, a + l * a_stride, p0 + l * p0_stride,
                                       layer_params + 2 * l, alpha_all ? alpha_all + (size_t)l * g->n_edges : nullptr, 0, c, stream);
         if (rc) return rc;
     }
@@ -2148,16 +2199,18 @@ extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int n_l
 
 static int layer_backward_cols(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha, const float* a,
                                const float* p0, const float* layer_params, float* edge_ws, float* dxd_ws, float* slab, int accumulate,
-                               float* sums_out, float* g_out, int g_cols, int c, hipStream_t st) {
-    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, 0, g_cols, st));
+                               float* sums_out, float* g_out, int g_cols, int x_cols, int c, hipStream_t st) {
+    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, 0, g_cols, x_cols, st));
 }
-extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, const float* alpha_all, const float* g_top, int g_top_cols, int n_layers,
+extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all, const float* g_top, int g_top_cols, int n_layers,
                                      const float* a, int64_t a_stride, const float* p0, int64_t p0_stride, const float* layer_params,
                                      float* g_ws, float* dxd_ws, float* edge_ws, float* slab, float* d_layer_params, float* d_x0,
                                      int c, void* stream) {
     if (int rc = check_graph(g, c)) return rc;
     if (!x_all || !alpha_all || !g_top || n_layers <= 0 || !a || !p0 || !layer_params || !g_ws || !dxd_ws || !edge_ws || !slab)
         return fail(GADAPT_E_BADARG, "block_backward: bad argument");
+    if (x0_cols != 0 && (x0_cols != 4 || n_layers < 2 || c < 8 || d_x0 || d_layer_params))
+        return fail(GADAPT_E_BADARG, "block_backward: compact x0 needs 4 columns, >= 2 layers, hidden >= 8, no d_x0 / d_layer_params");
     const size_t nc = (size_t)g->n_nodes * c;
     const bool shared = (a_stride == 0);
     const int64_t slab_floats = gadapt_backward_slab_floats(g->n_nodes, c);
@@ -2168,11 +2221,14 @@ extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, 
         float* slab_l = shared ? slab : slab + (size_t)l * slab_floats;
         const int accumulate = (shared && l != n_layers - 1) ? 1 : 0;
         int rc;
-        if (l == n_layers - 1 && g_top_cols > 0) {                  // compact upstream gradient [N,g_top_cols]
+        if (l == 0 && x0_cols) {                                    // compact layer-0 input [N,4]; no d x0 (checked in launch_bwd)
+            rc = layer_backward_cols(g, x_all, g_cur, alpha_all, a, p0, layer_params, edge_ws, dxd_ws, slab_l, accumulate,
+                                     d_layer_params, g_next, 0, x0_cols, c, static_cast<hipStream_t>(stream));
+        } else if (l == n_layers - 1 && g_top_cols > 0) {           // compact upstream gradient [N,g_top_cols]
             if (!g->tpos_s || (g_next && (!g->rowptr_s || !g->col_s))) return fail(GADAPT_E_BADARG, "block_backward: source CSR missing");
             rc = layer_backward_cols(g, x_all + l * nc, g_cur, alpha_all + (size_t)l * g->n_edges, a + l * a_stride, p0 + l * p0_stride,
                                      layer_params + 2 * l, edge_ws, dxd_ws, slab_l, accumulate,
-                                     d_layer_params ? d_layer_params + 2 * l : nullptr, g_next, g_top_cols, c, static_cast<hipStream_t>(stream));
+                                     d_layer_params ? d_layer_params + 2 * l : nullptr, g_next, g_top_cols, 0, c, static_cast<hipStream_t>(stream));
         } else {
             rc = gadapt_layer_backward(g, x_all + l * nc, g_cur, alpha_all + (size_t)l * g->n_edges, a + l * a_stride, p0 + l * p0_stride,
                                        layer_params + 2 * l, edge_ws, dxd_ws, slab_l, accumulate,

@@ -42,11 +42,14 @@ class _GrandEulerBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, wq, bq, wk, bk, layer_params, graph: MeshGraph, num_layers: int, want_alpha: bool, x_all=None,
-                out_cols=None):
+                out_cols=None, x0_cols=0):
         for t, n in ((x0, 'x'), (wq, 'lin_query.weight'), (bq, 'lin_query.bias'), (wk, 'lin_key.weight'),
                      (layer_params, 'layer_params')):
             _require_gpu(t, n)
         n, c = x0.shape
+        if x0_cols:                            # x0 = the compact [N,4] identity-encoder output at the start of x_all's slot 0
+            assert x0_cols == 4 and c == 4 and x_all is not None and not ctx.needs_input_grad[0] and not ctx.needs_input_grad[5]
+            c = x_all[0].shape[2]
         if n != graph.num_nodes:
             raise ValueError(f"x has {n} rows but the graph has {graph.num_nodes} nodes")
         if c not in _native.SUPPORTED_HIDDEN:
@@ -70,11 +73,11 @@ class _GrandEulerBlock(torch.autograd.Function):
             assert x_all.shape == (L + 1, n, c) and x_all.is_contiguous() and x_all.data_ptr() == x0.data_ptr()
         keep_alpha = need_grad or want_alpha
         alpha = torch.empty(L, max(graph.num_edges, 1), device=dev, dtype=torch.float32) if keep_alpha else None
-        check(lib().gadapt_block_forward(graph.c_ref, ptr(x_all), L, ptr(a), c * c if S > 1 else 0,
+        check(lib().gadapt_block_forward(graph.c_ref, ptr(x_all), int(x0_cols), L, ptr(a), c * c if S > 1 else 0,
                                          ptr(p0), c if S > 1 else 0, ptr(layer_params), ptr(alpha), c, st),
               'gadapt_block_forward')
         ctx.graph, ctx.L, ctx.S, ctx.c = graph, L, S, c
-        ctx.out_cols = out_cols
+        ctx.out_cols, ctx.x0_cols = out_cols, int(x0_cols)
         ctx.save_for_backward(x_all, alpha if need_grad else None, a, p0, wq, bq, wk, layer_params)
         out = x_all[L] if out_cols is None else x_all[L][:, :out_cols]    # x[:, :dim] (GNN.py:299)
         if want_alpha:
@@ -105,7 +108,7 @@ class _GrandEulerBlock(torch.autograd.Function):
         slab = torch.empty(S, slab_floats, device=dev, dtype=torch.float32)
         d_lp = torch.zeros(L, 2, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
         d_x0 = torch.empty(n, c, device=dev, dtype=torch.float32) if need_x0 else None
-        check(lib().gadapt_block_backward(graph.c_ref, ptr(x_all), ptr(alpha), ptr(g_top), g_cols, L,
+        check(lib().gadapt_block_backward(graph.c_ref, ptr(x_all), ctx.x0_cols, ptr(alpha), ptr(g_top), g_cols, L,
                                           ptr(a), c * c if S > 1 else 0, ptr(p0), c if S > 1 else 0, ptr(layer_params),
                                           ptr(g_ws), ptr(dxd_ws), ptr(edge_ws), ptr(slab), ptr(d_lp), ptr(d_x0), c, st),
               'gadapt_block_backward')
@@ -124,7 +127,7 @@ class _GrandEulerBlock(torch.autograd.Function):
             check(lib().gadapt_coeffs_backward(ptr(wq[s]), ptr(bq[s]), ptr(wk[s]), ptr(d_a), ptr(d_p0),
                                                ptr(d_wq[s]), ptr(d_bq[s]), ptr(d_wk[s]), ptr(d_bk[s]), c, st),
                   'gadapt_coeffs_backward')
-        return d_x0, d_wq, d_bq, d_wk, d_bk, d_lp, None, None, None, None, None
+        return d_x0, d_wq, d_bq, d_wk, d_bk, d_lp, None, None, None, None, None, None
 
 
 class _GrandResidual(torch.autograd.Function):
@@ -186,14 +189,16 @@ def grand_residual(x, wq, bq, wk, bk, scale: torch.Tensor, graph: MeshGraph, wan
 
 def grand_euler_block(x0: torch.Tensor, wq, bq, wk, bk, layer_params: torch.Tensor, graph: MeshGraph,
                       num_layers: int, want_alpha: bool = False, x_all: Optional[torch.Tensor] = None,
-                      out_cols: Optional[int] = None):
+                      out_cols: Optional[int] = None, x0_cols: int = 0):
     """Returns (x_L [N,C], alpha [L,E] in target-CSR order or None).
 
     `x_all` (optional): a contiguous [(L+1),N,C] buffer whose slot 0 IS `x0` (same memory); the
     layers then write straight into it and no copy of x0 is made.  `out_cols`: return only the first
-    columns of x_L (the `x[:, :dim]` slice of `src/GNN.py:299`) with a single-pass backward."""
+    columns of x_L (the `x[:, :dim]` slice of `src/GNN.py:299`) with a single-pass backward.
+    `x0_cols=4`: `x0` is the compact [N,4] output of the identity encoder (zero-pad, `src/GNN.py:75-82`) stored at the
+    start of `x_all`'s slot 0; layer 0 reads it directly and the padded [N,C] matrix is never written."""
     return _GrandEulerBlock.apply(x0.contiguous(), wq, bq, wk, bk, layer_params, graph, num_layers, want_alpha,
-                                  None if x_all is None else [x_all], out_cols)
+                                  None if x_all is None else [x_all], out_cols, x0_cols)
 
 
 def score_scale(hidden_dim: int, temperature=None):

@@ -159,6 +159,16 @@ class GNN(nn.Module):
         scales = torch.stack([layer._scale(device) for layer in self.conv_layers])
         return torch.stack([dts, scales], dim=1)
 
+    def _enc_is_zero_pad(self) -> bool:
+        """True when the frozen encoder weight is the identity zero-pad eye(C, F) that `get_enc('identity')` installs
+        (checked once per weight version: a loaded state_dict may carry anything)."""
+        w = self.enc.weight
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        if getattr(self, '_zero_pad_key', None) != key:
+            self._zero_pad_key = key
+            self._zero_pad = bool(torch.equal(w.detach(), torch.eye(w.shape[0], w.shape[1], device=w.device, dtype=w.dtype)))
+        return self._zero_pad
+
     def _fusable(self) -> bool:
         o = self.opt
         plain = o['conv_type'] == 'GRAND_plus' or (o['non_lin'] == 'identity')     # GNN.py:284-286 only for non-GRAND_plus
@@ -199,7 +209,7 @@ class GNN(nn.Module):
             return torch.cat([x_comp] + [t.unsqueeze(-1) for t in (f, uu) if t is not None] + glob, dim=1).float()
 
         fusable = self._fusable()
-        x_all, sliced = None, False
+        x_all, sliced, x0_cols = None, False, 0
         feats = None
         if glob:                                                           # differentiable wrt the CNN parameters
             feats = features()
@@ -212,7 +222,14 @@ class GNN(nn.Module):
                 out0 = x_all[0]
             else:
                 out0 = None
-            if native_in:                                                  # GNN.py:225-239 + :270 in one launch
+            learnable = o.get('learn_step') or o.get('softmax_temp_type') == 'learnable_a'
+            if (native_in and x_all is not None and not learnable and o['num_layers'] >= 2 and o['hidden_dim'] >= 8
+                    and self.enc.weight.shape[1] <= 4 and self._enc_is_zero_pad()):
+                # identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the compact [N,4] features, the padded
+                # [N,C] matrix is never written (nor read back by the layer-0 backward)
+                x0_cols = 4
+                x = Fn.encode_features(x_comp, f, uu, self.enc.weight[:4], out=x_all[0].view(-1)[:4 * n].view(n, 4))
+            elif native_in:                                                # GNN.py:225-239 + :270 in one launch
                 x = Fn.encode_features(x_comp, f, uu, self.enc.weight, out=out0)
             else:
                 feats = features()
@@ -236,7 +253,7 @@ class GNN(nn.Module):
             store = o['conv_type'] == 'GRAND' or isinstance(o.get('show_mesh_evol_plots'), bool)
             x, alpha = Fn.grand_euler_block(x, wq, bq, wk, bk, self._layer_params(dev), graph,
                                             o['num_layers'], want_alpha=store, x_all=x_all,
-                                            out_cols=self.dim if isinstance(self.dec, nn.Identity) else None)
+                                            out_cols=self.dim if isinstance(self.dec, nn.Identity) else None, x0_cols=x0_cols)
             sliced = isinstance(self.dec, nn.Identity)
             if store:                                                      # GRAND_plus.py:253-256, :381
                 for l, layer in enumerate(self.conv_layers):

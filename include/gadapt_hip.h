@@ -145,18 +145,22 @@ int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch, float* d_a
  * The loop of GNN.py:273-291 with weight sharing (GNN.py:131-141): x_all is
  * [(L+1),N,C] with x_all[0] = encoder output on entry; layer l reads x_all[l],
  * writes x_all[l+1].  a/p0/layer_params advance by *_stride floats per layer
- * (0 = shared).  alpha_all (nullable) [L,E]. */
-int gadapt_block_forward(const gadapt_graph* g, float* x_all, int n_layers,
+ * (0 = shared).  alpha_all (nullable) [L,E].
+ * x0_cols = 0: slot 0 holds the dense [N,C] encoder output.  x0_cols = 4: slot 0 holds, at its start, the COMPACT
+ * [N,4] output of the identity encoder (zero-pad to C columns, GNN.py:75-82: columns 4.. are zero by construction);
+ * layer 0 reads it without the padded matrix ever being written (needs >= 2 layers, hidden >= 8). */
+int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_cols, int n_layers,
                          const float* a, int64_t a_stride, const float* p0, int64_t p0_stride,
                          const float* layer_params, float* alpha_all, int c, void* stream);
 
 /* Backward of the block.  g_top = dL/dx_all[L] (not modified): [N,C] when g_top_cols = 0, or the compact [N,g_top_cols]
  * (1..4 columns, zero beyond: the backward of x_phys = x[:, :dim], GNN.py:299, without materialising the padded
- * matrix; not together with d_layer_params).  g_ws: 2*N*C floats,
+ * matrix; not together with d_layer_params).  x0_cols as in gadapt_block_forward (then d_x0 and d_layer_params
+ * must be NULL).  g_ws: 2*N*C floats,
  * dxd_ws: N*C, edge_ws: 2*E, slab: n_slots*gadapt_backward_slab_floats(N,c) with
  * n_slots = 1 (shared weights) or L.  d_layer_params (nullable) [L,2] accumulates.
  * d_x0 (nullable) [N,C] receives dL/dx_all[0]. */
-int gadapt_block_backward(const gadapt_graph* g, const float* x_all, const float* alpha_all,
+int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all,
                           const float* g_top, int g_top_cols, int n_layers,
                           const float* a, int64_t a_stride, const float* p0, int64_t p0_stride,
                           const float* layer_params,

@@ -69,3 +69,31 @@ def test_rollout_reuses_the_graph_and_hipgraph_replay_equals_eager(gpu_device):
     assert all(torch.equal(a, b) for a, b in zip(outs_e, outs_g))
     assert not torch.equal(outs_e[0], outs_e[-1])
     assert model.end_MLmodel is not None
+
+
+@pytest.mark.gpu
+def test_compact_encoder_output_equals_dense(gpu_device):
+    """Identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the compact [N,4] features and the top layer's backward
+    the compact [N,dim] gradient; both must give exactly what the dense [N,C] matrices give (same kernels, same order)."""
+    import copy
+    import torch.nn.functional as F
+    from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt
+    for mesh, hidden in (([24, 24], 64), ([13, 13], 16)):          # wide kernels / tiled kernels
+        opt = hot_path_opt(mesh_dims=mesh, hidden_dim=hidden, num_layers=3, device=str(gpu_device))
+        ds = MeshDataset(mesh, 5, seed=4)
+        data = collate(ds.samples).to(gpu_device)
+        torch.manual_seed(1)
+        model = GNN(ds, opt).to(gpu_device).train()
+        assert model._enc_is_zero_pad()
+        out_c = model(data)
+        F.mse_loss(out_c, data.x_phys).backward()
+        grads_c = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        model.zero_grad()
+        model._enc_is_zero_pad = lambda: False                      # dense x0 [N,C] through encode + layer 0
+        out_d = model(data)
+        F.mse_loss(out_d, data.x_phys).backward()
+        torch.cuda.synchronize()
+        assert torch.equal(out_c, out_d)
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(p.grad, grads_c[k]), k
