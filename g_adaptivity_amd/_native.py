@@ -46,7 +46,7 @@ PROTOTYPES = {
     'gadapt_backward_slab_floats': (_L, [_L, _I]),
     'gadapt_layer_backward': (_I, [_G, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     'gadapt_slab_reduce': (_I, [_P, _I, _P, _P, _P, _I, _P]),
-    'gadapt_block_forward': (_I, [_G, _P, _I, _I, _P, _L, _P, _L, _P, _P, _I, _P]),
+    'gadapt_block_forward': (_I, [_G, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _I, _P]),
     'gadapt_block_backward': (_I, [_G, _P, _I, _P, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'gadapt_mesh_loss_seed': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
     'gadapt_pad_columns': (_I, [_P, _P, _L, _I, _I, _P]),

@@ -509,12 +509,28 @@ template <int C> struct TileRows {
             v[q] = ld_row4<C>(src, min(max(node0 + r, 0), n_nodes - 1), c4);
         }
     }
+    // XC: src is the compact [N,4] matrix (see ld_row4x): one 16-byte load per row (thread t < TM takes row t, in v[0]);
+    // commit_sel writes zeros everywhere else
     template <bool XC> __device__ __forceinline__ void issue_sel(const float* __restrict__ src, int node0, int n_nodes, int tid) {
-        node0_ = node0;
+        if constexpr (XC) {
+            static_assert(K::TM <= 256, "one compact row per thread");
+            node0_ = node0;
+            v[0] = *reinterpret_cast<const float4*>(src + 4 * (size_t)min(max(node0 + min(tid, K::TM - 1), 0), n_nodes - 1));
+        } else {
+            issue(src, node0, n_nodes, tid);
+        }
+    }
+    template <bool XC> __device__ __forceinline__ void commit_sel(float* tile, int n_nodes, int tid) const {
+        if constexpr (XC) {
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) {
-            const int idx = min(q * 256 + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
-            v[q] = ld_row4x<C, XC>(src, min(max(node0 + r, 0), n_nodes - 1), c4);
+            for (int q = 0; q < XQ; ++q) {
+                const int idx = q * 256 + tid, r = idx / V, c4 = idx % V;
+                if (idx < K::TM * V && c4 != 0) *reinterpret_cast<float4*>(tile + r * K::LD + 4 * c4) = f4zero();
+            }
+            if (tid < K::TM)
+                *reinterpret_cast<float4*>(tile + tid * K::LD) = (node0_ + tid < n_nodes && node0_ + tid >= 0) ? v[0] : f4zero();
+        } else {
+            commit(tile, n_nodes, tid);
         }
     }
     // same for a compact [N,d] source (ld_row4_compact)
@@ -713,6 +729,7 @@ struct FwdArgs {
     float* alpha_out;
     int n_nodes, n_tiles, residual_only, n_edges;
     unsigned long long* stamps;
+    float* x_top4;                                              // nullable: columns 0..3 of the output rows, [N,4]
 };
 
 template <int NROWS, int NV> struct RowBuf {
@@ -778,7 +795,8 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
             }
             o.v[q] = r;
         }
-        st_vec<C>(p.x_out, i, sub, o);
+        if (p.x_out) st_vec<C>(p.x_out, i, sub, o);
+        if (p.x_top4 && sub == 0) *reinterpret_cast<float4*>(p.x_top4 + 4 * (size_t)i) = o.v[0];
     };
 
     // Fast path, row length bounded by the compile-time DM: every lane issues exactly DM gathers (slots past
@@ -888,8 +906,8 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, p.p0);   // B fragments stay in registers for the whole launch
     csr.load_metas(ch.t0, 1, p.n_tiles, tid);
     if constexpr (K::RING == 3) {
-        xrA.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
-        xrA.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xrA.commit(slab_ptr(ch.t0), p.n_nodes, tid);
+        xrA.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xrA.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
+        xrA.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xrA.template commit_sel<XC>(slab_ptr(ch.t0), p.n_nodes, tid);
     }
     __syncthreads();                                             // tile metadata visible
     xrA.template issue_sel<XC>(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);   // rows past N come back as zeros
@@ -914,12 +932,12 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
             if constexpr (K::MFMA) gemm.run(xs, ps);
             GADAPT_STAMP(p.stamps, tslot + 1);
             win = sr.meta.w != 0;
-            xr.commit(slab_ptr(t + 1), p.n_nodes, tid);
+            xr.template commit_sel<XC>(slab_ptr(t + 1), p.n_nodes, tid);
             dmax = csr.commit(sr, tid, node0, win ? t : -1);
             __syncthreads();                                    // P tile, slab t+1 and the CSR slice are complete
         } else {                                                // no window: the tile itself is staged first, then projected
             win = false;
-            xr.commit(xs, p.n_nodes, tid);
+            xr.template commit_sel<XC>(xs, p.n_nodes, tid);
             dmax = csr.commit(sr, tid, node0, -1);
             if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, p.p0);
             __syncthreads();
@@ -1170,8 +1188,8 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
         csr.load_metas(ch.t0, 1, p.n_tiles, tid);
         if constexpr (K::RING == 3) {
-            xr.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
-            xr.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xr.commit(slab_ptr(ch.t0), p.n_nodes, tid);
+            xr.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xr.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
+            xr.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xr.template commit_sel<XC>(slab_ptr(ch.t0), p.n_nodes, tid);
         }
         __syncthreads();                                        // tile metadata visible
         // C = 128 has no registers to hold a tile across the edge walk: it stages at the top of the tile instead
@@ -1196,7 +1214,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             GADAPT_STAMP(p.stamps, tslot + 0);
             xs = slab_ptr(t);
             const bool win = K::RING == 3 && sr.meta.w != 0;
-            xr.commit(slab_ptr(t + K::LEAD), p.n_nodes, tid);
+            xr.template commit_sel<XC>(slab_ptr(t + K::LEAD), p.n_nodes, tid);
             gr.commit(ds, p.n_nodes, tid);
             const int dmax = csr.commit(sr, tid, node0, win ? t : -1);
             GADAPT_STAMP(p.stamps, tslot + 1);
@@ -1896,10 +1914,10 @@ static inline int wide_grid(int n_steps) {
     return g;
 }
 static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
-                           const float* lp, float* alpha_out, int residual_only, int x_cols, hipStream_t st) {
+                           const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st) {
     const int n_steps = (g->n_nodes + wide::STEP - 1) / wide::STEP;
     (void)0;
-    wide::FwdArgs p{x_in, x_out, a, p0, lp, g->ell_t, g->rowptr_t, alpha_out, g->n_nodes, n_steps, residual_only, g->wide_deg_t, nullptr};
+    wide::FwdArgs p{x_in, x_out, a, p0, lp, g->ell_t, g->rowptr_t, alpha_out, g->n_nodes, n_steps, residual_only, g->wide_deg_t, nullptr, x_top4};
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
 #endif
@@ -1940,14 +1958,14 @@ static int launch_wide_bwd_t(const gadapt_graph* g, const float* x_in, const flo
 }
 
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
-                                       const float* lp, float* alpha_out, int residual_only, int x_cols, hipStream_t st) {
+                                       const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st) {
     using K = Cfg<C>;
     if (x_cols != 0 && x_cols != 4) return fail(GADAPT_E_BADARG, "compact layer input: 4 columns");
     if constexpr (C == 64) {
-        if (g->ell_t && g->wide_deg_t > 0 && wide_enabled()) return launch_wide_fwd(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, x_cols, st);
+        if (g->ell_t && g->wide_deg_t > 0 && wide_enabled()) return launch_wide_fwd(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, x_cols, x_top4, st);
     }
     FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t), alpha_out, g->n_nodes,
-              (g->n_nodes + K::TM - 1) / K::TM, residual_only, g->n_edges, nullptr};
+              (g->n_nodes + K::TM - 1) / K::TM, residual_only, g->n_edges, nullptr, x_top4};
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
 #endif
@@ -2054,7 +2072,7 @@ extern "C" int gadapt_layer_forward(const gadapt_graph* g, const float* x_in, fl
     if (int rc = check_graph(g, c)) return rc;
     if (!x_in || !x_out || !a || !p0 || !layer_params || x_in == x_out) return fail(GADAPT_E_BADARG, "layer_forward: null or aliased pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    GADAPT_DISPATCH_C(c, launch_fwd<CC>(g, x_in, x_out, a, p0, layer_params, alpha_out, residual_only, 0, st));
+    GADAPT_DISPATCH_C(c, launch_fwd<CC>(g, x_in, x_out, a, p0, layer_params, alpha_out, residual_only, 0, nullptr, st));
 }
 
 template <int C> static int tiles_for(int64_t n_nodes) { return (int)((n_nodes + Cfg<C>::TM - 1) / Cfg<C>::TM); }
@@ -2176,22 +2194,27 @@ extern "C" int gadapt_adam_step(float* param, const float* grad, float* exp_avg,
 // L-step Euler block (GNN.py:273-291)
 // ------------------------------------------------------------------------------------------------
 static int layer_forward_cols(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0, const float* layer_params,
-                              float* alpha_out, int x_cols, int c, hipStream_t st) {
-    GADAPT_DISPATCH_C(c, launch_fwd<CC>(g, x_in, x_out, a, p0, layer_params, alpha_out, 0, x_cols, st));
+                              float* alpha_out, int x_cols, float* x_top4, int c, hipStream_t st) {
+    GADAPT_DISPATCH_C(c, launch_fwd<CC>(g, x_in, x_out, a, p0, layer_params, alpha_out, 0, x_cols, x_top4, st));
 }
 extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_cols, int n_layers, const float* a, int64_t a_stride,
-                                    const float* p0, int64_t p0_stride, const float* layer_params, float* alpha_all, int c, void* stream) {
+                                    const float* p0, int64_t p0_stride, const float* layer_params, float* alpha_all, float* x_top4,
+                                    int c, void* stream) {
     if (int rc = check_graph(g, c)) return rc;
     if (!x_all || n_layers <= 0 || !a || !p0 || !layer_params) return fail(GADAPT_E_BADARG, "block_forward: bad argument");
     if (x0_cols != 0 && (x0_cols != 4 || n_layers < 2 || c < 8)) return fail(GADAPT_E_BADARG, "block_forward: compact x0 needs 4 columns, >= 2 layers, hidden >= 8");
     const size_t nc = (size_t)g->n_nodes * c;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     for (int l = 0; l < n_layers; ++l) {
+        const bool last = (l == n_layers - 1);
+        float* alpha_l = alpha_all ? alpha_all + (size_t)l * g->n_edges : nullptr;
         int rc;
-        if (l == 0 && x0_cols)
-            rc = layer_forward_cols(g, x_all, x_all + nc, a, p0, layer_params, alpha_all, x0_cols, c, static_cast<hipStream_t>(stream));
+        if ((l == 0 && x0_cols) || (last && x_top4))             // compact input and/or compact-only output
+            rc = layer_forward_cols(g, x_all + l * nc, (last && x_top4) ? nullptr : x_all + (l + 1) * nc, a + l * a_stride, p0 + l * p0_stride,
+                                    layer_params + 2 * l, alpha_l, l == 0 ? x0_cols : 0, last ? x_top4 : nullptr, c, st);
         else
             rc = gadapt_layer_forward(g, x_all + l * nc, x_all + (l + 1) * nc, a + l * a_stride, p0 + l * p0_stride,
-                                      layer_params + 2 * l, alpha_all ? alpha_all + (size_t)l * g->n_edges : nullptr, 0, c, stream);
+                                      layer_params + 2 * l, alpha_l, 0, c, stream);
         if (rc) return rc;
     }
     return GADAPT_OK;

@@ -73,13 +73,18 @@ class _GrandEulerBlock(torch.autograd.Function):
             assert x_all.shape == (L + 1, n, c) and x_all.is_contiguous() and x_all.data_ptr() == x0.data_ptr()
         keep_alpha = need_grad or want_alpha
         alpha = torch.empty(L, max(graph.num_edges, 1), device=dev, dtype=torch.float32) if keep_alpha else None
+        # out_cols <= 4: the last layer writes only the [N,4] head of its rows (x_phys = x[:, :dim], GNN.py:299)
+        x_top4 = torch.empty(n, 4, device=dev, dtype=torch.float32) if (out_cols is not None and out_cols <= 4) else None
         check(lib().gadapt_block_forward(graph.c_ref, ptr(x_all), int(x0_cols), L, ptr(a), c * c if S > 1 else 0,
-                                         ptr(p0), c if S > 1 else 0, ptr(layer_params), ptr(alpha), c, st),
+                                         ptr(p0), c if S > 1 else 0, ptr(layer_params), ptr(alpha), ptr(x_top4), c, st),
               'gadapt_block_forward')
         ctx.graph, ctx.L, ctx.S, ctx.c = graph, L, S, c
         ctx.out_cols, ctx.x0_cols = out_cols, int(x0_cols)
         ctx.save_for_backward(x_all, alpha if need_grad else None, a, p0, wq, bq, wk, layer_params)
-        out = x_all[L] if out_cols is None else x_all[L][:, :out_cols]    # x[:, :dim] (GNN.py:299)
+        if x_top4 is not None:
+            out = x_top4[:, :out_cols]
+        else:
+            out = x_all[L] if out_cols is None else x_all[L][:, :out_cols]    # x[:, :dim] (GNN.py:299)
         if want_alpha:
             ctx.mark_non_differentiable(alpha)
             return out, alpha

@@ -151,7 +151,9 @@ int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch, float* d_a
  * layer 0 reads it without the padded matrix ever being written (needs >= 2 layers, hidden >= 8). */
 int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_cols, int n_layers,
                          const float* a, int64_t a_stride, const float* p0, int64_t p0_stride,
-                         const float* layer_params, float* alpha_all, int c, void* stream);
+                         const float* layer_params, float* alpha_all, float* x_top4, int c, void* stream);
+/* x_top4 (nullable) [N,4]: when given, the last layer writes ONLY columns 0..3 of its output rows, to x_top4, and slot L
+ * of x_all is left unwritten: the caller wants x_phys = x[:, :dim] (GNN.py:299) and nothing downstream reads the rest. */
 
 /* Backward of the block.  g_top = dL/dx_all[L] (not modified): [N,C] when g_top_cols = 0, or the compact [N,g_top_cols]
  * (1..4 columns, zero beyond: the backward of x_phys = x[:, :dim], GNN.py:299, without materialising the padded
