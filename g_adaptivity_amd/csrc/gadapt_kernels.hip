@@ -681,11 +681,27 @@ template <int NV> struct Vec {
         for (int i = 0; i < NV; ++i) v[i] = f4zero();
     }
 };
+#ifndef GADAPT_PK_DOT
+#define GADAPT_PK_DOT 1
+#endif
+typedef float pk2f __attribute__((ext_vector_type(2)));
 template <int NV> __device__ __forceinline__ float vdot(const Vec<NV>& a, const Vec<NV>& b) {
+#if GADAPT_PK_DOT
+    // two interleaved partial sums on v_pk_fma_f32 (a scalar fma chain is one instruction per element)
+    pk2f s = pk2f{a.v[0].x, a.v[0].y} * pk2f{b.v[0].x, b.v[0].y};
+    s += pk2f{a.v[0].z, a.v[0].w} * pk2f{b.v[0].z, b.v[0].w};
+#pragma unroll
+    for (int i = 1; i < NV; ++i) {
+        s += pk2f{a.v[i].x, a.v[i].y} * pk2f{b.v[i].x, b.v[i].y};
+        s += pk2f{a.v[i].z, a.v[i].w} * pk2f{b.v[i].z, b.v[i].w};
+    }
+    return s.x + s.y;
+#else
     float s = dot4(a.v[0], b.v[0]);
 #pragma unroll
     for (int i = 1; i < NV; ++i) s += dot4(a.v[i], b.v[i]);
     return s;
+#endif
 }
 template <int NV> __device__ __forceinline__ void vaxpy(Vec<NV>& y, float a, const Vec<NV>& x) {
 #pragma unroll
@@ -1005,7 +1021,8 @@ template <int NROWS, int NV> struct TBuf {
 // so on mesh-ordered graphs the x_j gathers are LDS reads.  Per tile the fourth LDS tile holds g (staged with the
 // ring slab), then dP (written over g row by row by the lanes that read it), then dP A (in place).
 // GC: the upstream gradient is compact, [N,g_cols] (top layer: backward of the x[:, :dim] slice) - only its staging differs.
-// XC: x_in is the compact [N,4] encoder output (layer 0): see ld_row4x.
+// XC: x_in is the compact [N,4] encoder output (layer 0): see ld_row4x.  No source pass follows such a launch (d x0 is
+// not wanted), so it skips what only the source pass reads: the per-edge scratch, dP A and dxd.
 template <int C, bool SUMS, bool GC = false, bool XC = false>
 __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kernel(BwdTArgs p) {
     using K = Cfg<C>;
@@ -1126,7 +1143,8 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
                 if (a[k] > 0.f) sum_dsc = fmaf(dsp, __logf(a[k]), sum_dsc);
             }
         }
-        if constexpr (K::LPN >= DM) {
+        if constexpr (XC) {
+        } else if constexpr (K::LPN >= DM) {
             const float am = pick(a, sub), dm_ = pick(da, sub);
             if (sub < deg) p.edge_ws[csr.ext[e0 + sub]] = make_float2(am * dt, dm_);
         } else {
@@ -1162,7 +1180,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
                     vaxpy(m, ak, v);
                     if (ak > 0.f) sum_dsc = fmaf(dsp, __logf(ak), sum_dsc);
                 }
-                if ((k % K::LPN) == sub) p.edge_ws[p.tpos[e0 + k]] = make_float2(ak * dt, dss);
+                if (!XC && (k % K::LPN) == sub) p.edge_ws[p.tpos[e0 + k]] = make_float2(ak * dt, dss);
             }
         }
         finish(li, i, it, gi, m, dP);
@@ -1185,7 +1203,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
         typename CsrT::Regs sr;
         TileRows<C> xr, gr;
         constexpr bool RESIDENT_B = TileGemm<C, true>::SPLIT;  // C = 128: fp32 fragments, re-read per tile (registers)
-        if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
+        if constexpr (K::MFMA && RESIDENT_B && !XC) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
         csr.load_metas(ch.t0, 1, p.n_tiles, tid);
         if constexpr (K::RING == 3) {
             xr.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xr.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
@@ -1219,7 +1237,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             const int dmax = csr.commit(sr, tid, node0, win ? t : -1);
             GADAPT_STAMP(p.stamps, tslot + 1);
             __syncthreads();
-            if (t > ch.t0) store_dxd(node0 - K::TM);            // previous tile's result: see store_dxd
+            if constexpr (!XC) { if (t > ch.t0) store_dxd(node0 - K::TM); }   // previous tile's result: see store_dxd
             GADAPT_STAMP(p.stamps, tslot + 2);
             // ---- edge phase: dP_i per node -> LDS
             if (dmax >= 0) {
@@ -1310,6 +1328,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
             }
             GADAPT_STAMP(p.stamps, tslot + 5);
             // ---- dxd = (base-dt) g + dP A
+            if constexpr (!XC) {
             if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, nullptr);
             if constexpr (K::MFMA) {
                 gemm.run_in_place(ds);                          // reads dP (like the dA pass), barrier, writes dP A
@@ -1337,10 +1356,11 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kern
                     gk[it].v[q].x += r.v[q].x; gk[it].v[q].y += r.v[q].y; gk[it].v[q].z += r.v[q].z; gk[it].v[q].w += r.v[q].w;
                 }
             }
+            }
             __syncthreads();
             GADAPT_STAMP(p.stamps, tslot + 7);
         }
-        store_dxd((ch.t1 - 1) * K::TM);
+        if constexpr (!XC) store_dxd((ch.t1 - 1) * K::TM);
     }
     xs = ring;                                                  // scratch for the flush below
 
