@@ -89,7 +89,9 @@ def main():
     torch.manual_seed(0)                                              # identical replicas
     model = GNN(ds, opt).to(dev)
     model.train()
-    optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'])
+    # one GPU: the optimizer step is captured with forward and backward (step count on the device); N > 1: the RCCL
+    # all-reduce of the gradient bucket runs eagerly between the replayed graph and the Adam launch
+    optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=(world == 1))
 
     def fwd_bwd():
         out = model(data)
@@ -115,12 +117,16 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 optim.zero_grad(); fwd_bwd()
+                if world == 1:
+                    optim.step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             optim.zero_grad()
             with torch.cuda.graph(g, stream=side):
                 static_loss = fwd_bwd()
+                if world == 1:
+                    optim.step()
             graph = g
         except Exception as e:                                        # stay correct: fall back to eager launches
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
@@ -129,8 +135,9 @@ def main():
 
     def step():
         if graph is not None:
-            graph.replay()                                            # forward + loss + backward as one hipGraph
-            optim.step()
+            graph.replay()                                            # forward + loss + backward (+ Adam at N = 1) as one hipGraph
+            if world > 1:
+                optim.step()                                          # all-reduce + fused Adam
         else:
             eager_step()
 
@@ -262,7 +269,7 @@ def main():
             'config': {'workload': args.workload, 'mesh': f"{w['n']}x{w['n']}", 'meshes_per_gpu': w['batch'],
                        'global_batch': w['batch'] * world, 'mp_layers': w['layers'], 'hidden': w['hidden'],
                        'conv_type': w['conv'], 'parallelism': f'dp{world}',
-                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'launch': 'hipgraph' if graph is not None else 'eager'},
+                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'launch': ('hipgraph' if world > 1 else 'hipgraph+adam') if graph is not None else 'eager'},
             'roofline': roofline, 'roofline_mfma': roofline_mfma, 'kernels': kernels, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))

@@ -1889,6 +1889,37 @@ __global__ void adam_step_kernel(float* param, const float* grad, float* m, floa
 
 #include "gadapt_wide.inc"
 
+// Same update with the step count kept on the device (state[0] = steps taken, state[1] = exit ticket), so that the
+// launch carries no host-side value that changes from step to step and can sit inside a captured hipGraph.  Every
+// workgroup reads the count when it starts; the workgroup that exits last (all others have read by then) advances it.
+__global__ __launch_bounds__(256) void adam_step_dev_kernel(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float b1,
+                                                            float b2, float eps, float wd, int* state, float gscale) {
+    __shared__ int s_step;
+    if (threadIdx.x == 0) s_step = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    __syncthreads();
+    const float stepf = (float)s_step;
+    const float bc1 = 1.0f - powf(b1, stepf), bc2_sqrt = sqrtf(1.0f - powf(b2, stepf));
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) {
+        float g = grad[e] * gscale;
+        const float pv = param[e];
+        if (wd != 0.f) g = fmaf(wd, pv, g);
+        const float mn = fmaf(b1, m[e], (1.f - b1) * g);
+        const float vn = fmaf(b2, v[e], (1.f - b2) * g * g);
+        m[e] = mn; v[e] = vn;
+        const float denom = sqrtf(vn) / bc2_sqrt + eps;
+        param[e] = pv - (lr / bc1) * (mn / denom);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(state + 1, 1) == (int)gridDim.x - 1) {
+            __hip_atomic_store(state + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(state, s_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -1936,7 +1967,6 @@ static inline int wide_grid(int n_steps) {
 static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                            const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st) {
     const int n_steps = (g->n_nodes + wide::STEP - 1) / wide::STEP;
-    (void)0;
     wide::FwdArgs p{x_in, x_out, a, p0, lp, g->ell_t, g->rowptr_t, alpha_out, g->n_nodes, n_steps, residual_only, g->wide_deg_t, nullptr, x_top4};
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
@@ -1951,30 +1981,6 @@ static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_ou
         hipLaunchKernelGGL(wide::fwd_kernel<false>, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
     }
     return check_launch("wide::fwd_kernel");
-}
-static bool wide_bwd_t_enabled() {
-    static const bool on = [] { const char* e = getenv("GADAPT_WIDE_BWD_T"); return e && e[0] == '1'; }();   // opt-in: slower than the tiled pass (register spills)
-    return on;
-}
-extern "C" int gadapt_backward_slab_rows(int64_t n_nodes, int c);
-static int launch_wide_bwd_t(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha, const float* a,
-                             const float* lp, float* edge_ws, float* dxd, float* slab, int accumulate, int residual_only, bool with_g, hipStream_t st) {
-    const int n_steps = (g->n_nodes + wide::STEP - 1) / wide::STEP;
-    wide::BwdTArgs p{x_in, g_in, alpha, a, lp, g->ell_t, g->rowptr_t, g->tpos_s, reinterpret_cast<float2*>(edge_ws), dxd, slab,
-                     g->n_nodes, n_steps, g->n_edges, accumulate, residual_only, g->wide_deg_t, gadapt_backward_slab_rows(g->n_nodes, 64), nullptr};
-#ifdef GADAPT_STAMPS
-    p.stamps = g_stamp_buf ? g_stamp_buf + 1024 * 32 : nullptr;
-#endif
-    ProfScope prof(1, st);
-    constexpr int lds = wide::bwd_t_lds_bytes();
-    if (with_g) {
-        allow_lds(wide::bwd_target_kernel<true>, lds);
-        hipLaunchKernelGGL(wide::bwd_target_kernel<true>, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
-    } else {
-        allow_lds(wide::bwd_target_kernel<false>, lds);
-        hipLaunchKernelGGL(wide::bwd_target_kernel<false>, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
-    }
-    return check_launch("wide::bwd_target_kernel");
 }
 
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
@@ -2015,11 +2021,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
 #endif
     constexpr int lds_t = K::lds_bytes(1, K::RING + 1, 1), lds_s = K::lds_bytes(2);
     int rc;
-    bool wide_t = false;
-    if constexpr (C == 64) wide_t = g->ell_t && g->wide_deg_t > 0 && !sums_out && !g_cols && !x_cols && g->n_edges > 0 && wide_enabled() && wide_bwd_t_enabled();
-    if (wide_t) {
-        rc = launch_wide_bwd_t(g, x_in, g_in, alpha, a, lp, edge_ws, dxd, slab, accumulate, residual_only, /*with_g=*/true, st);
-    } else {
+    {
         ProfScope prof(1, st);
         if (x_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, false, true>, lds_t);
@@ -2208,6 +2210,14 @@ extern "C" int gadapt_adam_step(float* param, const float* grad, float* exp_avg,
     hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad,
                        exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
     return check_launch("adam_step_kernel");
+}
+
+extern "C" int gadapt_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int32_t* state, float grad_scale, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || !state) return fail(GADAPT_E_BADARG, "adam_step_dev: bad argument");
+    hipLaunchKernelGGL(adam_step_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad,
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, state, grad_scale);
+    return check_launch("adam_step_dev_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -38,7 +38,7 @@ class FlatAdam:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, process_group=None, reduce_op: str = 'mean'):
+                 weight_decay: float = 0.0, process_group=None, reduce_op: str = 'mean', capturable: bool = False):
         seen, self.params = set(), []
         for p in params:                                   # shared convs repeat the same Parameter
             if p.requires_grad and id(p) not in seen:
@@ -47,6 +47,10 @@ class FlatAdam:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.group, self.reduce_op = process_group, reduce_op
         self.step_count = 0
+        # capturable: the step count lives on the device (gadapt_adam_step_dev), so step() can be captured in a hipGraph
+        # with forward and backward and replayed (torch.optim.Adam(capturable=True) does the same)
+        self.capturable = bool(capturable)
+        self._dev_state: Optional[torch.Tensor] = None
         self.bucket: Optional[torch.Tensor] = None
         self.grad_bucket: Optional[torch.Tensor] = None    # the flat gradient the last step()/_build() used
         self._own_grad: Optional[torch.Tensor] = None
@@ -144,6 +148,13 @@ class FlatAdam:
         scale = 1.0 / world if self.reduce_op == 'mean' else 1.0       # 'sum' for the modular pseudo-loss (run_GNN.py:118)
         self.step_count += 1
         b = self.bucket
+        if self.capturable:
+            if self._dev_state is None:
+                self._dev_state = torch.zeros(2, device=b.device, dtype=torch.int32)
+            check(lib().gadapt_adam_step_dev(ptr(b), ptr(self.grad_bucket), ptr(self.exp_avg), ptr(self.exp_avg_sq), b.numel(),
+                                             self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                             ptr(self._dev_state), scale, current_stream(b.device)), 'gadapt_adam_step_dev')
+            return
         check(lib().gadapt_adam_step(ptr(b), ptr(self.grad_bucket), ptr(self.exp_avg), ptr(self.exp_avg_sq), b.numel(),
                                      self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                      self.step_count, scale, current_stream(b.device)), 'gadapt_adam_step')

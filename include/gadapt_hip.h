@@ -198,6 +198,13 @@ int gadapt_adam_step(float* param, const float* grad, float* exp_avg, float* exp
                      int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int step, float grad_scale, void* stream);
 
+/* Same step with the step count on the device: state = int32[2] {steps taken so far, 0}, zero-filled once by the
+ * caller and advanced by the launch itself - nothing in the argument list changes from step to step, so the launch can be
+ * part of a captured hipGraph together with forward and backward. */
+int gadapt_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                         int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int32_t* state, float grad_scale, void* stream);
+
 /* ------------------------------------------------------------------ timing (bench only)
  * When enabled, every launch of the three hot kernels is bracketed by hipEvents on its
  * stream; kernel_id 0 = forward, 1 = backward target pass, 2 = backward source pass.

@@ -150,12 +150,13 @@ def test_golden_fixtures(gpu_device, path):
 
 
 @pytest.mark.gpu
-def test_flat_adam_matches_torch_adam(gpu_device):
+@pytest.mark.parametrize("capturable", [False, True], ids=['host-step', 'device-step'])
+def test_flat_adam_matches_torch_adam(gpu_device, capturable):
     torch.manual_seed(0)
     ps = [torch.nn.Parameter(torch.randn(64, 64, device=gpu_device)), torch.nn.Parameter(torch.randn(64, device=gpu_device)),
           torch.nn.Parameter(torch.randn(3, device=gpu_device))]           # the last one never gets a gradient
     qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
-    ours, ref = FlatAdam(ps, lr=1e-2, weight_decay=0.01), torch.optim.Adam(qs, lr=1e-2, weight_decay=0.01)
+    ours, ref = FlatAdam(ps, lr=1e-2, weight_decay=0.01, capturable=capturable), torch.optim.Adam(qs, lr=1e-2, weight_decay=0.01)
     for step in range(5):
         gs = [torch.randn_like(ps[0]), torch.randn_like(ps[1])]
         ours.zero_grad(); ref.zero_grad()
