@@ -41,6 +41,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_STAGGER_T
 #define GADAPT_STAGGER_T 0
 #endif
+// Hidden sizes from here on give the backward kernels one wave per SIMD (512 registers): at C = 128 the dA accumulators
+// (64) + projection blocks (32) + row buffers do not fit 256 registers and the spill traffic costs more than the second
+// resident workgroup brings.
+#ifndef GADAPT_ONE_WAVE_C
+#define GADAPT_ONE_WAVE_C 128
+#endif
+#ifndef GADAPT_FWD_ONE_WAVE
+#define GADAPT_FWD_ONE_WAVE 0
+#endif
 #define GADAPT_SLAB_CHUNKS 32   // second-level partials of the slab reduction
 
 // ------------------------------------------------------------------------------------------------
@@ -235,6 +244,9 @@ __device__ __forceinline__ TileChunk tile_chunk(int n_tiles) {
 #ifndef GADAPT_GEMM_SPLIT
 #define GADAPT_GEMM_SPLIT 1
 #endif
+#ifndef GADAPT_SPLIT_MAX_C
+#define GADAPT_SPLIT_MAX_C 128
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // fp32 values on the bf16 matrix cores without losing fp32 accuracy: x = h + m + l exactly, three bf16 pieces of 8
@@ -266,7 +278,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 template <int C, bool TRANS> struct TileGemm {
     using K = Cfg<C>;
     static constexpr int BPW = (K::CB * K::RB) / 4;    // 32x32 output blocks per wave
-    static constexpr bool SPLIT = GADAPT_GEMM_SPLIT && C <= 64;   // wider C: the split B fragments do not fit the registers
+    static constexpr bool SPLIT = GADAPT_GEMM_SPLIT && C <= GADAPT_SPLIT_MAX_C;
     static constexpr int KS = C / 16;                  // k-steps of the bf16 form
     float bf[SPLIT ? 1 : C / 2];
     Split3 bs[SPLIT ? KS : 1];
@@ -756,7 +768,7 @@ template <int NROWS, int NV> struct RowBuf {
 
 // XC: x_in is the compact [N,4] encoder output (layer 0, identity encoder): see ld_row4x
 template <int C, bool XC = false>
-__global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArgs p) {
+__global__ __launch_bounds__(256, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_ONE_WAVE) ? 1 : GADAPT_WAVES_FWD)) void grand_fwd_kernel(FwdArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
@@ -916,7 +928,7 @@ __global__ __launch_bounds__(256, GADAPT_WAVES_FWD) void grand_fwd_kernel(FwdArg
     // its next slab at the same moment, so one tile of compute does not cover that burst.
     // C = 128 does not have the registers for that (nor for resident B fragments): one set, one tile ahead.
     constexpr int AHEAD = (C <= 64) ? 2 : 1;
-    constexpr bool RESIDENT_B = (C <= 64);
+    constexpr bool RESIDENT_B = (C <= 64) || (C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_ONE_WAVE);
     typename TileCsr<C, 0>::Regs srA, srB;
     TileRows<C> xrA, xrB;
     if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, p.p0);   // B fragments stay in registers for the whole launch
@@ -1024,7 +1036,7 @@ template <int NROWS, int NV> struct TBuf {
 // XC: x_in is the compact [N,4] encoder output (layer 0): see ld_row4x.  No source pass follows such a launch (d x0 is
 // not wanted), so it skips what only the source pass reads: the per-edge scratch, dP A and dxd.
 template <int C, bool SUMS, bool GC = false, bool XC = false>
-__global__ __launch_bounds__(256, GADAPT_WAVES_BWD_T) void grand_bwd_target_kernel(BwdTArgs p) {
+__global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD_T)) void grand_bwd_target_kernel(BwdTArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
@@ -1454,7 +1466,7 @@ template <int HN_, int NV> struct SBuf {
 };
 
 template <int C, bool GC = false>
-__global__ __launch_bounds__(256, GADAPT_WAVES_BWD_S) void grand_bwd_source_kernel(BwdSArgs p) {
+__global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD_S)) void grand_bwd_source_kernel(BwdSArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];

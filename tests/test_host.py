@@ -181,3 +181,35 @@ def test_device_loader_batches_equal_cpu_collation():
     g = torch.Generator().manual_seed(0)
     shuffled = list(DeviceMeshLoader(ds, batch_size=7, shuffle=True, device='cpu', generator=g))[0]
     assert sorted(shuffled.idx.tolist()) == list(range(7)) and shuffled.idx.tolist() != list(range(7))
+
+
+def test_ell_copy_and_wide_eligibility():
+    """gadapt_ell_build_host: ELL-8 copy of a CSR orientation (-1 padding, rows padded to 256) and the rule that
+    sends a graph to the wide kernels: rows of at most 8 entries, every neighbour of node i inside rows
+    [256*(i/256) - 64, 256*(i/256) + 320)."""
+    from oracle.pyg_restatement import masked_edge_index
+    for n_side, batch, want in ((64, 3, 6), (23, 7, 6), (128, 1, 0)):     # 128-wide rows: neighbours 128 apart -> tiled kernels
+        ds = MeshDataset([n_side, n_side], batch, seed=1)
+        ei = masked_edge_index(collate(ds.samples), 2, n_side)
+        n = batch * n_side * n_side
+        g = MeshGraph(ei, n, 'cpu')
+        assert g.wide_deg == {'t': want, 's': want}
+        if want:
+            ell = g._ells['t'].view(-1, 8)
+            assert ell.shape[0] == (n + 255) // 256 * 256 and (ell[n:] == -1).all()
+            rt = g.rowptr_t.long()
+            for i in (0, 1, n_side, n // 2, n - 1):
+                d = int(rt[i + 1] - rt[i])
+                assert torch.equal(ell[i, :d], g.col_t[rt[i]:rt[i + 1]]) and (ell[i, d:] == -1).all()
+    gen = torch.Generator().manual_seed(0)
+    rnd = torch.stack([torch.randint(0, 1000, (3000,), generator=gen), torch.randint(0, 1000, (3000,), generator=gen)])
+    assert MeshGraph(rnd, 1000, 'cpu').wide_deg == {'t': 0, 's': 0}       # random graph: far neighbours
+    star = torch.stack([torch.arange(1, 12), torch.zeros(11, dtype=torch.int64)])
+    assert MeshGraph(star, 12, 'cpu').wide_deg['t'] == 0                   # a row of 11 in-edges
+    from g_adaptivity_amd import graph as graph_mod
+    graph_mod.WIDE_KERNELS = False
+    try:
+        ds = MeshDataset([16, 16], 2, seed=1)
+        assert MeshGraph(masked_edge_index(collate(ds.samples), 2, 16), 512, 'cpu').wide_deg == {'t': 0, 's': 0}
+    finally:
+        graph_mod.WIDE_KERNELS = True

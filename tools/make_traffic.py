@@ -9,7 +9,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 root, workload = sys.argv[1], sys.argv[2]
 out = sys.argv[3] if len(sys.argv) > 3 else 'profiles/traffic.json'
-name = lambda n: 'forward' if 'grand_fwd' in n else 'backward_target' if 'bwd_target' in n else 'backward_source' if 'bwd_source' in n else None
+name = lambda n: 'forward' if ('grand_fwd' in n or 'wide::fwd' in n) else 'backward_target' if 'bwd_target' in n else 'backward_source' if 'bwd_source' in n else None
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, 'pmc*', '**', '*counter_collection.csv'), recursive=True):
     for row in csv.DictReader(open(f)):

@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-short = lambda n: ('fwd' if 'grand_fwd' in n else 'bwd_target' if 'bwd_target' in n else 'bwd_source' if 'bwd_source' in n else n[:40])
+short = lambda n: ('fwd' if ('grand_fwd' in n or 'wide::fwd' in n) else 'bwd_target' if 'bwd_target' in n else 'bwd_source' if 'bwd_source' in n else n[:40])
 
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for f in glob.glob(os.path.join(root, 'stats', '**', '*kernel_stats.csv'), recursive=True):
@@ -18,7 +18,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, 'pmc*', '**', '*counter_collection.csv'), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get('Kernel_Name', '')
-        if 'grand_' not in k:
+        if 'grand_' not in k and 'wide::' not in k:
             continue
         acc[short(k)][row['Counter_Name']].append(float(row['Counter_Value']))
 for k in sorted(acc):
