@@ -54,6 +54,7 @@ def main():
         runner = GraphedForward(model, data) if mode == 'hipgraph' else None
         mesh_time, outs = 0.0, []
         with torch.no_grad():
+            (runner(data) if runner is not None else model(data))                        # first call: graph build, kernel load
             for k in range(args.steps):
                 data.uu_tensor = pulse(coords, k / args.steps).to(data.uu_tensor.dtype)   # the "PDE step"
                 torch.cuda.synchronize()

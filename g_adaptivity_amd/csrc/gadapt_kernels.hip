@@ -10,7 +10,8 @@
 // node range.  The forward and the target pass keep the x rows of tiles t-1..t+1 in an LDS ring and
 // gather from it when the tile's neighbours all lie there (per-tile metadata built with the graph);
 // the [TM,C]x[C,C] projections run on the bf16 matrix cores with a three-piece split of both operands
-// (fp32 accuracy, C <= 64), on v_mfma_f32_32x32x2_f32 for C = 128 and on the VALU for C < 32.
+// (fp32 accuracy, C >= 32) and on the VALU for C < 32.  Hidden 64 on row-major mesh batches runs the wide forward
+// kernel of gadapt_wide.inc instead of grand_fwd_kernel.
 //
 // Arithmetic follows /root/reference/src/GRAND_plus.py:225-343 and src/GNN.py:273-291 in the
 // (A, p0) formulation described in include/gadapt_hip.h.
@@ -1214,7 +1215,7 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
         auto slab_ptr = [&](int s_) __attribute__((always_inline)) { return ring + ((s_ + K::RING) % K::RING) * K::TILE_FLOATS; };
         typename CsrT::Regs sr;
         TileRows<C> xr, gr;
-        constexpr bool RESIDENT_B = TileGemm<C, true>::SPLIT;  // C = 128: fp32 fragments, re-read per tile (registers)
+        constexpr bool RESIDENT_B = TileGemm<C, true>::SPLIT;  // split fragments are built once per launch
         if constexpr (K::MFMA && RESIDENT_B && !XC) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
         csr.load_metas(ch.t0, 1, p.n_tiles, tid);
         if constexpr (K::RING == 3) {

@@ -426,6 +426,37 @@ def test_wide_kernels_match_tiled_kernels(gpu_device, mesh_n, batch):
 
 
 @pytest.mark.gpu
+def test_wide_kernels_ragged_rows(gpu_device):
+    """Rows of 0, 1, 7 and 8 in-edges inside the window (the ELL-8 limit), next to the mesh's 2..6: a node without
+    in-edges gets res = -x (empty aggregation, GRAND_plus.py:338-343), unused ELL slots carry weight 0."""
+    from oracle.pyg_restatement import masked_edge_index
+    from g_adaptivity_amd.graph import MeshGraph as MG
+    C, mesh_n, batch = 64, 20, 4
+    ds = MeshDataset([mesh_n, mesh_n], batch, seed=6)
+    ei = masked_edge_index(collate(ds.samples), 2, mesh_n)
+    n = batch * mesh_n * mesh_n
+    keep = ~((ei[1] == 37) | (ei[1] == 611))                          # two nodes lose every in-edge
+    keep &= ~((ei[1] == 90) & (ei[0] != 89))                          # one keeps a single in-edge
+    ei = ei[:, keep]
+    extra = torch.tensor([[204, 208, 300, 302, 299, 104], [206, 206, 301, 301, 301, 106]])   # interior rows of 6 -> 8, 8+, 7 entries
+    ei = torch.cat([ei, extra, torch.tensor([[301], [301]])], dim=1)  # plus a self-loop: node 301 has 8+... in-edges
+    ei = ei[:, ~((ei[1] == 301) & (torch.cumsum((ei[1] == 301).long(), 0) > 8))]    # cap node 301 at 8
+    deg = torch.bincount(ei[1], minlength=n)
+    assert deg.max().item() == 8 and deg.min().item() == 0 and (deg == 1).any() and (deg == 7).any()
+    assert MG(ei, n, gpu_device).wide_deg['t'] == 8
+    layer = _random_layer(C, 31)
+    x = torch.randn(n, C, generator=torch.Generator().manual_seed(32))
+    up = torch.randn(n, C, generator=torch.Generator().manual_seed(33))
+    wide = _conv_run(gpu_device, ei, x, up, layer, True)
+    tiled = _conv_run(gpu_device, ei, x, up, layer, False)
+    ref = grand_residual(x.double(), ei, *[w.double() for w in layer])
+    assert rel_err(wide[0], ref)[0] <= 1e-5
+    assert torch.allclose(wide[0][37], -x[37], rtol=0, atol=1e-6)
+    for name, a, b, tol in zip(('residual', 'alpha', 'dx'), wide, tiled, (2e-6, 2e-6, 1e-5)):
+        assert rel_err(a, b)[0] <= tol, (name, rel_err(a, b))
+
+
+@pytest.mark.gpu
 def test_wide_kernels_rebase_large_scores(gpu_device):
     """The wide forward takes softmax weights relative to the first score of a row and re-bases when a later score
     exceeds it by more than 16: scores spread over +-60 must still give the max-shifted softmax of the reference."""
