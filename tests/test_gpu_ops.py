@@ -426,6 +426,34 @@ def test_wide_kernels_match_tiled_kernels(gpu_device, mesh_n, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mesh_n,batch", [(5, 1), (9, 3), (16, 1), (17, 2), (31, 1), (33, 9), (50, 11), (63, 17), (64, 1), (64, 5)],
+                         ids=lambda v: str(v))
+def test_wide_kernels_size_sweep(gpu_device, mesh_n, batch):
+    """Node counts around the wave (32) and step (256) granularity of the wide kernels: 25 nodes, one node past a step,
+    a single partial step, batches that end mid-wave.  Full model, forward + backward, against the tiled kernels."""
+    from g_adaptivity_amd import graph as graph_mod
+    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=64, num_layers=3, device=str(gpu_device))
+    ds = MeshDataset([mesh_n, mesh_n], batch, seed=7)
+    data = collate(ds.samples).to(gpu_device)
+    res = {}
+    for wide in (True, False):
+        graph_mod.WIDE_KERNELS = wide
+        try:
+            torch.manual_seed(3)
+            model = GNN(ds, opt).to(gpu_device).train()
+            out = model(data)
+            F.mse_loss(out, data.x_phys).backward()
+            torch.cuda.synchronize()
+            g = next(iter(model._graphs.values()))
+            assert (g.wide_deg['t'] > 0) == wide
+            res[wide] = (out.detach().clone(), model.conv_layers[0].lin_query.weight.grad.clone(), model.conv_layers[0].lin_key.weight.grad.clone())
+        finally:
+            graph_mod.WIDE_KERNELS = True
+    for a, b, tol in zip(res[True], res[False], (2e-6, 2e-5, 2e-5)):
+        assert rel_err(a, b)[0] <= tol, rel_err(a, b)
+
+
+@pytest.mark.gpu
 def test_wide_kernels_ragged_rows(gpu_device):
     """Rows of 0, 1, 7 and 8 in-edges inside the window (the ELL-8 limit), next to the mesh's 2..6: a node without
     in-edges gets res = -x (empty aggregation, GRAND_plus.py:338-343), unused ELL slots carry weight 0."""
