@@ -37,16 +37,24 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X fp32 matrix (= vector) peak, SURVEY.md §8(d)
 
 
-def algorithmic_bytes(kernel, n_nodes, n_edges, c):
-    """compulsory traffic of one layer launch over the whole batch (fp32, int32 CSR)."""
+def algorithmic_bytes(kernel, n_nodes, n_edges, c, variant=0, dim=2):
+    """compulsory traffic of one layer launch over the whole batch (fp32, int32 CSR).
+
+    variant (gadapt_profile_variants): bit 0 = compact upstream gradient [N,dim], bit 1 = compact layer input [N,4],
+    bit 2 = head-only output [N,4] - the matrices such a launch really reads / writes are what is counted."""
     csr = 4 * (n_edges + n_nodes + 1)
+    dense = 4 * n_nodes * c
+    x_in = 16 * n_nodes if variant & 2 else dense
     if kernel == 'forward':            # read x, write x'
-        return 8 * n_nodes * c + csr
+        return x_in + (16 * n_nodes if variant & 4 else dense) + csr
     if kernel == 'backward_target':    # read g, read saved x  (+ CSR by target)
-        return 8 * n_nodes * c + csr
+        return (4 * n_nodes * dim if variant & 1 else dense) + x_in + csr
     if kernel == 'backward_source':    # write dx               (+ CSR by source)
-        return 4 * n_nodes * c + csr
+        return dense + csr
     raise KeyError(kernel)
+
+
+VARIANT_NAMES = {0: 'dense', 1: 'compact_g', 2: 'compact_x', 4: 'head_only_out', 6: 'compact_x+head_only_out'}
 
 
 def main():
@@ -188,35 +196,45 @@ def main():
         n_nodes, n_edges = graph_obj.num_nodes, graph_obj.num_edges
         for kid, name in enumerate(('forward', 'backward_target', 'backward_source')):
             cap = 4 * args.steps * w['layers'] + 16
-            buf = (C.c_double * cap)()
+            buf, vbuf = (C.c_double * cap)(), (C.c_int * cap)()
             cnt = lib.gadapt_profile_samples(kid, buf, cap)
+            vcnt = lib.gadapt_profile_variants(kid, vbuf, cap)
             xs = [buf[i] for i in range(max(cnt, 0))]
-            if not xs:
+            if not xs or vcnt != cnt:
                 continue
-            # launches differ by layer (the top layer's gradient is sparse, layer 0 skips work): median over the steps for
-            # each position within a step (drops launches that waited on the host), then the mean over the positions
+            # launches differ by layer (compact top gradient, compact layer-0 input, head-only last output): median over
+            # the steps for each position within a step (drops launches that waited on the host); positions of the
+            # same variant are averaged, and every variant is priced with the bytes IT moves
             per_step = max(1, cnt // (args.steps + 4))
-            pos = []
+            groups = {}
             for k in range(per_step):
                 col = sorted(xs[k::per_step])
-                pos.append(col[len(col) // 2])
-            avg_ms = max(sum(pos) / len(pos) - event_overhead_ms, 1e-6)     # minus the dispatch share of the event pair
-            by = algorithmic_bytes(name, n_nodes, n_edges, w['hidden'])
-            kernels[name] = {'launches_per_step': per_step, 'avg_us': round(avg_ms * 1e3, 2),
-                             'alg_bytes_per_launch': by, 'achieved_GBs': round(by / (avg_ms * 1e-3) / 1e9, 1)}
+                groups.setdefault(vbuf[k], []).append(col[len(col) // 2])
+            variants = {}
+            for v, meds in sorted(groups.items()):
+                avg_ms = max(sum(meds) / len(meds) - event_overhead_ms, 1e-6)   # minus the dispatch share of the event pair
+                by = algorithmic_bytes(name, n_nodes, n_edges, w['hidden'], v)
+                variants[VARIANT_NAMES.get(v, str(v))] = {'launches_per_step': len(meds), 'avg_us': round(avg_ms * 1e3, 2),
+                                                          'alg_bytes_per_launch': by, 'achieved_GBs': round(by / (avg_ms * 1e-3) / 1e9, 1)}
+            tot = sum(v['avg_us'] * v['launches_per_step'] for v in variants.values())
+            kernels[name] = {'launches_per_step': per_step, 'avg_us': round(tot / per_step, 2), 'variants': variants}
         lib.gadapt_profile_reset()
         if kernels:
-            dom = max(kernels, key=lambda k: kernels[k]['avg_us'] * kernels[k]['launches_per_step'])
-            kd = kernels[dom]
+            # dominant kernel = the (kernel, variant) group with the largest share of the step
+            dom, dvar = max(((k, v) for k in kernels for v in kernels[k]['variants']),
+                            key=lambda kv: kernels[kv[0]]['variants'][kv[1]]['avg_us'] * kernels[kv[0]]['variants'][kv[1]]['launches_per_step'])
+            kd = kernels[dom]['variants'][dvar]
             traffic = None
             tpath = os.path.join(ROOT, 'profiles', 'traffic.json')   # filled from separate rocprofv3 --pmc passes
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+                    tj = json.load(open(tpath)).get(args.workload, {})
+                    traffic = tj.get(f'{dom}:{dvar}', tj.get(dom))
                 except Exception:
                     traffic = None
-            roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': kd['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            roofline = {'kernel': dom, 'variant': dvar, 'bound': 'hbm', 'achieved': kd['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(kd['achieved_GBs'] / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                        'traffic_note': 'HBM-side bytes per launch of this kernel variant, (2 FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes',
                         'avg_launch_us': kd['avg_us'], 'alg_bytes_per_launch': kd['alg_bytes_per_launch'],
                         'event_pair_overhead_us': round(event_overhead_ms * 1e3, 2)}
 

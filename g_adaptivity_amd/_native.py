@@ -55,6 +55,7 @@ PROTOTYPES = {
     'gadapt_profile_enable': (_I, [_I]),
     'gadapt_profile_read': (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'gadapt_profile_samples': (_I, [_I, C.POINTER(C.c_double), _I]),
+    'gadapt_profile_variants': (_I, [_I, C.POINTER(C.c_int), _I]),
     'gadapt_profile_reset': (_I, []),
     'gadapt_profile_calibrate': (_I, [_I, _P]),
     'gadapt_debug_occupancy': (_I, [_I, C.POINTER(C.c_int)]),

@@ -75,14 +75,15 @@ extern "C" int gadapt_supported_hidden_dim(int c) {
 // ------------------------------------------------------------------------------------------------
 #include <type_traits>
 #include <vector>
-struct ProfRec { int id; hipEvent_t a, b; };
+struct ProfRec { int id, variant; hipEvent_t a, b; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 struct ProfScope {
     hipStream_t st; int idx = -1;
-    ProfScope(int id, hipStream_t s) : st(s) {
+    // variant: bit 0 = compact upstream gradient, bit 1 = compact layer input, bit 2 = head-only output (launchers below)
+    ProfScope(int id, hipStream_t s, int variant = 0) : st(s) {
         if (!g_prof_on) return;
-        ProfRec r{id, nullptr, nullptr};
+        ProfRec r{id, variant, nullptr, nullptr};
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
         (void)hipEventRecord(r.a, st);
         g_prof.push_back(r);
@@ -109,6 +110,16 @@ extern "C" int gadapt_profile_samples(int kernel_id, double* out_ms, int cap) {
         if (r.id != kernel_id) continue;
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && n < cap) out_ms[n++] = ms;
+    }
+    return n;
+}
+extern "C" int gadapt_profile_variants(int kernel_id, int* out, int cap) {
+    if (!out || cap < 0) return fail(GADAPT_E_BADARG, "profile_variants: bad argument");
+    int n = 0;
+    for (auto& r : g_prof) {
+        if (r.id != kernel_id) continue;
+        float ms = 0.f;                                         // same filter as gadapt_profile_samples: entries stay aligned
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && n < cap) out[n++] = r.variant;
     }
     return n;
 }
@@ -1984,7 +1995,7 @@ static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_ou
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
 #endif
-    ProfScope prof(0, st);
+    ProfScope prof(0, st, (x_cols ? 2 : 0) | (x_out ? 0 : 4));
     constexpr int lds = wide::fwd_lds_bytes();
     if (x_cols) {
         allow_lds(wide::fwd_kernel<true>, lds);
@@ -2008,7 +2019,7 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
 #endif
-    ProfScope prof(0, st);
+    ProfScope prof(0, st, (x_cols ? 2 : 0) | (x_out ? 0 : 4));
     constexpr int lds = K::lds_bytes(0, K::RING + 1);
     if (x_cols) {
         allow_lds(grand_fwd_kernel<C, true>, lds);
@@ -2035,7 +2046,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     constexpr int lds_t = K::lds_bytes(1, K::RING + 1, 1), lds_s = K::lds_bytes(2);
     int rc;
     {
-        ProfScope prof(1, st);
+        ProfScope prof(1, st, (g_cols ? 1 : 0) | (x_cols ? 2 : 0));
         if (x_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, false, true>, lds_t);
             hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, true>), dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
@@ -2056,7 +2067,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
 #ifdef GADAPT_STAMPS
     ps.stamps = g_stamp_buf ? g_stamp_buf + 2 * 1024 * 32 : nullptr;
 #endif
-    ProfScope prof(2, st);
+    ProfScope prof(2, st, g_cols ? 1 : 0);
     if (g_cols) {
         allow_lds(grand_bwd_source_kernel<C, true>, lds_s);
         hipLaunchKernelGGL((grand_bwd_source_kernel<C, true>), dim3(grid_for(n_tiles, GADAPT_BWD_S_MAX_BLOCKS)), dim3(256), lds_s, st, ps);

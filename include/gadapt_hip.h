@@ -212,6 +212,9 @@ int gadapt_adam_step_dev(float* param, const float* grad, float* exp_avg, float*
 int gadapt_profile_enable(int on);
 int gadapt_profile_read(int kernel_id, double* total_ms, int* count);
 int gadapt_profile_samples(int kernel_id, double* out_ms, int cap);   /* returns the number written */
+/* Variant of each recorded launch, aligned with gadapt_profile_samples: bit 0 = compact upstream gradient (g_top_cols),
+ * bit 1 = compact layer input (x0_cols), bit 2 = head-only output (x_top4). */
+int gadapt_profile_variants(int kernel_id, int* out, int cap);
 int gadapt_profile_reset(void);
 /* Dispatch share D of an event pair: n x one empty launch (kernel id 3, p1) and n x two empty launches (id 4, p2),
  * bracketed like the hot kernels; D = 2 p1 - p2. */
