@@ -1829,11 +1829,13 @@ __global__ void mesh_loss_seed_kernel(const float* x_top, const float* target, f
 // loss = mean((pred - target)^2) or mean(|pred - target|) and seed = d loss / d pred in one launch.  Deterministic:
 // per-block partials, then the block that takes the last ticket adds them in index order.  scratch[0] is the ticket
 // counter (left at zero), scratch[1..] the partials.
-#define GADAPT_LOSS_BLOCKS 256
+#ifndef GADAPT_LOSS_BLOCKS
+#define GADAPT_LOSS_BLOCKS 128      /* every block costs one ticket atomic: 64 / 128 / 256 / 512 blocks measured 10.1 / 8.9 / 10.5 / 15.3 us */
+#endif
 __global__ __launch_bounds__(256) void loss_forward_kernel(const float* __restrict__ pred, int64_t pred_stride,
                                                            const float* __restrict__ target, int64_t n_rows, int d, int l1,
                                                            float* __restrict__ seed, float* __restrict__ loss_out, float* scratch) {
-    __shared__ float red[256];
+    __shared__ float red[4];
     __shared__ unsigned ticket;
     const int64_t total = n_rows * d;
     const float inv = 1.0f / (float)total;
@@ -1874,11 +1876,18 @@ __global__ __launch_bounds__(256) void loss_forward_kernel(const float* __restri
             }
         }
     }
-    red[threadIdx.x] = lv;
-    __syncthreads();
-    for (int s_ = 128; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_]; __syncthreads(); }
+    // fixed-shape tree: butterfly inside each wave, then the four wave sums in order (one barrier instead of eight)
+    auto block_sum = [&](float v) __attribute__((always_inline)) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        __syncthreads();                                         // red[] of an earlier call has been read
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    const float bsum = block_sum(lv);
     if (threadIdx.x == 0) {
-        __hip_atomic_store(scratch + 1 + blockIdx.x, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(scratch + 1 + blockIdx.x, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         ticket = atomicAdd(reinterpret_cast<unsigned*>(scratch), 1u);
     }
@@ -1886,13 +1895,11 @@ __global__ __launch_bounds__(256) void loss_forward_kernel(const float* __restri
     if (ticket != gridDim.x - 1) return;
     __threadfence();
     float v = 0.f;
-    for (unsigned k = threadIdx.x; k < gridDim.x; k += 256)      // fixed order per thread, then the fixed tree below
+    for (unsigned k = threadIdx.x; k < gridDim.x; k += 256)      // fixed order per thread, then the fixed tree
         v += __hip_atomic_load(scratch + 1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int s_ = 128; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_]; __syncthreads(); }
+    const float total_sum = block_sum(v);
     if (threadIdx.x == 0) {
-        loss_out[0] = red[0] * inv;
+        loss_out[0] = total_sum * inv;
         *reinterpret_cast<unsigned*>(scratch) = 0u;            // ready for the next launch
     }
 }
