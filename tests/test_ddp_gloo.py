@@ -45,17 +45,32 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_flat_bucket_allreduce_equals_full_batch_gradient():
+def _run_two_ranks():
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    reduced = q.get(timeout=120)
+    try:
+        reduced = q.get(timeout=120)
+    except Exception:
+        reduced = None
+    ok = reduced is not None
     for p in procs:
         p.join(timeout=120)
-        assert p.exitcode == 0
+        if p.is_alive():
+            p.kill()                                       # this process object only: never by pattern
+            ok = False
+        ok = ok and p.exitcode == 0
+    return reduced if ok else None
+
+
+def test_two_rank_flat_bucket_allreduce_equals_full_batch_gradient():
+    reduced = _run_two_ranks()
+    if reduced is None:                                    # the rendezvous port is picked, released and re-bound: one retry
+        reduced = _run_two_ranks()
+    assert reduced is not None, "two-rank gloo run failed twice"
     opt = hot_path_opt(mesh_dims=[9, 9], hidden_dim=8, num_layers=2)
     ds = MeshDataset([9, 9], 8, seed=0)
     torch.manual_seed(0)
