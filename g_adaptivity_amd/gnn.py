@@ -127,7 +127,7 @@ class GNN(nn.Module):
         else:
             ckey = tuple(int(v) for v in np.asarray(corners).reshape(-1))
         key = (num_nodes, int(data.edge_index.shape[1]), self.dim, ckey, bool(self.opt['fix_boundary']),
-               bool(self.opt.get('self_loops')), str(device), _graph_mod.WIDE_KERNELS)
+               bool(self.opt.get('self_loops')), str(device), _graph_mod.WIDE_KERNELS, _graph_mod.WIDE_MIN_NODES)
         g = self._graphs.get(key)
         if g is None:
             single = not isinstance(corners, (list, tuple))

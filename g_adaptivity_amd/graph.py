@@ -48,6 +48,10 @@ def prepare_edge_index(data, dim: int, mesh_n: int, fix_boundary: bool, self_loo
 # The wide (hidden 64) kernels run on graphs that qualify (gadapt_ell_build_host); False keeps the tiled kernels
 # everywhere (tests compare the two).  Read when a MeshGraph is built; part of the cache key.
 WIDE_KERNELS = True
+# ... and only from this many nodes on: a wide workgroup loads a 384-row window before it computes anything, which a
+# batch too small to fill the 256 CUs does not earn back (forward of 64x64 meshes, hidden 64, 4 layers as one hipGraph:
+# batch 1 / 4 / 8 / 16 = 78.6 / 80.7 / 85.7 / 93.2 us wide against 74.5 / 74.1 / 87.1 / 110.1 us tiled).
+WIDE_MIN_NODES = 24576
 
 
 class MeshGraph:
@@ -83,7 +87,7 @@ class MeshGraph:
             md = C.c_int32(0)
             if _native.lib().gadapt_ell_build_host(rp.data_ptr(), cl.data_ptr(), n, ell.data_ptr(), C.addressof(md)) != 0:
                 raise _native.NativeError("gadapt_ell_build_host failed")
-            ells[tag], wide_deg[tag] = ell.to(self.device), (int(md.value) if WIDE_KERNELS else 0)
+            ells[tag], wide_deg[tag] = ell.to(self.device), (int(md.value) if (WIDE_KERNELS and n >= WIDE_MIN_NODES) else 0)
         self._ells, self.wide_deg = ells, wide_deg
         self.edge_index = edge_index                        # as given (original order/device)
         self.rowptr_t, self.col_t, self.eid_t = (t.to(self.device) for t in (rowptr_t, col_t, eid_t))
@@ -118,8 +122,8 @@ class GraphCache:
             # device-side fingerprint without a full D2H copy: three order-sensitive checksums
             w = torch.arange(1, ei.shape[1] + 1, device=ei.device, dtype=torch.int64)
             fp = torch.stack([(ei[0] * w).sum(), (ei[1] * w).sum(), (ei[0] ^ (ei[1] << 1)).sum()]).tolist()
-            return (int(ei.shape[1]), int(num_nodes), str(device), tuple(fp), WIDE_KERNELS)
-        return (int(ei.shape[1]), int(num_nodes), str(device), hash(ei.numpy().tobytes()), WIDE_KERNELS)
+            return (int(ei.shape[1]), int(num_nodes), str(device), tuple(fp), WIDE_KERNELS, WIDE_MIN_NODES)
+        return (int(ei.shape[1]), int(num_nodes), str(device), hash(ei.numpy().tobytes()), WIDE_KERNELS, WIDE_MIN_NODES)
 
     def get(self, edge_index: torch.Tensor, num_nodes: int, device) -> MeshGraph:
         key = self._key(edge_index, num_nodes, device)

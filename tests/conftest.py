@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the tests put graphs of every size through the wide kernels (production keeps them for batches that fill the GPU)
+from g_adaptivity_amd import graph as _graph_mod   # noqa: E402
+_graph_mod.WIDE_MIN_NODES = 0
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

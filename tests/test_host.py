@@ -207,9 +207,15 @@ def test_ell_copy_and_wide_eligibility():
     star = torch.stack([torch.arange(1, 12), torch.zeros(11, dtype=torch.int64)])
     assert MeshGraph(star, 12, 'cpu').wide_deg['t'] == 0                   # a row of 11 in-edges
     from g_adaptivity_amd import graph as graph_mod
+    ds = MeshDataset([16, 16], 2, seed=1)
+    small = masked_edge_index(collate(ds.samples), 2, 16)
     graph_mod.WIDE_KERNELS = False
     try:
-        ds = MeshDataset([16, 16], 2, seed=1)
-        assert MeshGraph(masked_edge_index(collate(ds.samples), 2, 16), 512, 'cpu').wide_deg == {'t': 0, 's': 0}
+        assert MeshGraph(small, 512, 'cpu').wide_deg == {'t': 0, 's': 0}
     finally:
         graph_mod.WIDE_KERNELS = True
+    graph_mod.WIDE_MIN_NODES = 24576                                        # the production default: small batches stay tiled
+    try:
+        assert MeshGraph(small, 512, 'cpu').wide_deg == {'t': 0, 's': 0}
+    finally:
+        graph_mod.WIDE_MIN_NODES = 0
