@@ -1,7 +1,7 @@
 """Attention-diffusion conv operators with the reference's constructor / forward surface.
 
-Drop-in for `GRAND_plusConv` (`src/GRAND_plus.py:40-347`) and `GRAND_conv`
-(`src/GRAND_plus.py:366-382`) in the configuration `get_conv` builds
+Drop-in for `GRAND_plusConv` (`src/GRAND_plus.py:40-347`), `GRAND_conv`
+(`src/GRAND_plus.py:366-382`) and the stock `TransformerConv` that `get_conv(opt, 'TRANS', ...)` builds (`src/GNN.py:112-113`) in the configuration `get_conv` builds
 (`src/GNN.py:115-119`): heads=1, root_weight=False, edge_dim=None, dropout=0,
 identity value map.  Parameters and `state_dict` keys are the reference's
 (`lin_key.{weight,bias}`, `lin_query.{weight,bias}`, `lin_skip.weight`, optional
@@ -149,3 +149,50 @@ class GRAND_conv(_AttentionDiffusionBase):
         res, alpha_t, graph = self._residual(x, edge_index, graph, True)
         self.stored_ei, self._stored = edge_index, (graph, alpha_t)
         return res
+
+
+class TRANS_conv(nn.Module):
+    """`get_conv(opt, 'TRANS', in, out)` = PyG `TransformerConv(in, out, heads=1)` with its defaults (`src/GNN.py:112-113`):
+    concat=True, beta=False, dropout=0, edge_dim=None, bias=True, root_weight=True, i.e.
+
+        out_i = sum_j alpha_ij (W_v x_j + b_v) + W_s x_i + b_s,   alpha = softmax_j(<W_q x_i + b_q, W_k x_j + b_k> / sqrt(C)).
+
+    The aggregation is linear in the values, so  sum_j alpha_ij (W_v x_j + b_v) = W_v m_i + (sum_j alpha_ij) b_v  with
+    m = A(x) x: the graph part is exactly the GRAND residual op of the HIP kernels (m = residual + x), the value and skip
+    projections are plain dense GEMMs (torch on the GPU: rocBLAS / hipBLASLt).  sum_j alpha_ij is 1 for a node with in-edges
+    (up to the 1e-16 of PyG's softmax, below fp32 resolution) and 0 for a node without.  Parameters carry PyG's names
+    (`lin_key`, `lin_query`, `lin_value`, `lin_skip`); hidden sizes are those of the fused kernels, in == out."""
+
+    def __init__(self, opt, in_channels, out_channels, heads: int = 1):
+        super().__init__()
+        if heads != 1 or in_channels != out_channels:
+            raise NotImplementedError("TRANS: get_conv builds heads=1 with in_dim == out_dim == hidden_dim (src/GNN.py:112-113,127-141)")
+        self.opt = opt
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, 1
+        self.lin_key = nn.Linear(in_channels, out_channels)
+        self.lin_query = nn.Linear(in_channels, out_channels)
+        self.lin_value = nn.Linear(in_channels, out_channels)
+        self.lin_skip = nn.Linear(in_channels, out_channels, bias=True)
+        self._has_in = {}
+
+    def reset_parameters(self):
+        for lin in (self.lin_key, self.lin_query, self.lin_value, self.lin_skip):
+            lin.reset_parameters()
+
+    def forward(self, x, edge_index, graph: Optional[MeshGraph] = None):
+        if graph is None:
+            graph = graph_for(edge_index, x.shape[0], x.device)
+        scale = torch.full((), 1.0 / math.sqrt(self.out_channels), device=x.device, dtype=torch.float32)
+        res, _ = Fn.grand_residual(x, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
+                                   self.lin_key.bias, scale, graph, False)
+        m = res + x                                                    # A(x) x
+        has_in = self._has_in.get(id(graph))
+        if has_in is None:
+            if len(self._has_in) > 8:
+                self._has_in.clear()
+            has_in = self._has_in[id(graph)] = (graph.rowptr_t[1:] > graph.rowptr_t[:-1]).to(torch.float32).unsqueeze(-1)
+        out = torch.nn.functional.linear(m, self.lin_value.weight) + has_in * self.lin_value.bias
+        return out + torch.nn.functional.linear(x, self.lin_skip.weight, self.lin_skip.bias)
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads=1)'

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as Fn
-from .conv import GRAND_conv, GRAND_plusConv
+from .conv import GRAND_conv, GRAND_plusConv, TRANS_conv
 from .features import GlobalFeatureExtractorCNN, expand_to_nodes, field_to_grid
 from . import graph as _graph_mod
 from .graph import MeshGraph, prepare_edge_index
@@ -66,9 +66,11 @@ def get_conv(opt, conv_type, in_dim, out_dim, feat_dim=None):
     if conv_type == 'GRAND_plus':
         return GRAND_plusConv(opt, in_dim, out_dim, global_feat_dim=feat_dim, heads=1, concat=False, beta=False,
                               dropout=0.0, edge_dim=None, bias=False, root_weight=False)
-    if conv_type in ('GCN', 'GAT', 'TRANS', 'GAT_plus'):
-        raise NotImplementedError(f"conv_type={conv_type!r}: stock-PyG variants are a later scope row "
-                                  "(SURVEY.md §8(f) rank 3); GRAND and GRAND_plus are built")
+    if conv_type == 'TRANS':
+        return TRANS_conv(opt, in_dim, out_dim, heads=1)                 # GNN.py:112-113
+    if conv_type in ('GCN', 'GAT', 'GAT_plus'):
+        raise NotImplementedError(f"conv_type={conv_type!r}: a later scope row (SURVEY.md §8(f) rank 3: different edge "
+                                  "scores); GRAND, GRAND_plus and TRANS are built")
     raise NotImplementedError                                            # GNN.py:124
 
 
@@ -171,7 +173,7 @@ class GNN(nn.Module):
 
     def _fusable(self) -> bool:
         o = self.opt
-        plain = o['conv_type'] == 'GRAND_plus' or (o['non_lin'] == 'identity')     # GNN.py:284-286 only for non-GRAND_plus
+        plain = o['conv_type'] == 'GRAND_plus' or (o['conv_type'] == 'GRAND' and o['non_lin'] == 'identity')   # GNN.py:284-286
         return bool(o['residual']) and plain and not (self.training and o.get('dropout', 0.0) > 0)
 
     # ------------------------------------------------------------------ forward

@@ -26,9 +26,11 @@ What each function follows (paths under /root/reference):
 * `masked_edge_index`      - `GNN.forward` edge surgery (`src/GNN.py:206-218`).
 * `node_features`          - feature concat (`src/GNN.py:225-239`).
 * `identity_encoder_weight`- `get_enc` identity branch (`src/GNN.py:75-90`).
+* `transformer_conv`       - PyG `TransformerConv(in, out, heads=1)` defaults, the
+                             'TRANS' branch of `get_conv` (`src/GNN.py:112-113`).
 * `OracleGNN`              - `GNN.__init__/forward` (`src/GNN.py:144-306`) for
                              loss_type in {mesh_loss, modular}, enc='identity',
-                             conv_type in {GRAND_plus, GRAND}.
+                             conv_type in {GRAND_plus, GRAND, TRANS}.
 """
 from __future__ import annotations
 
@@ -77,6 +79,23 @@ def grand_residual(x, edge_index, w_query, b_query, w_key, b_key,
     if return_attention:
         return res, (alpha, query, key)
     return res
+
+
+def transformer_conv(x, edge_index, w_query, b_query, w_key, b_key, w_value, b_value, w_skip, b_skip):
+    """PyG 2.4.0 `TransformerConv(in, out, heads=1)` with its defaults (concat=True, beta=False, dropout=0, edge_dim=None,
+    bias=True, root_weight=True) - what `get_conv(opt, 'TRANS', ...)` builds (`src/GNN.py:112-113`); same op sequence as
+    `grand_residual` with a Linear value map and the root/skip term added (`out += lin_skip(x)`), no `- x`."""
+    n, c = x.shape
+    src, dst = edge_index[0], edge_index[1]
+    query = F.linear(x, w_query, b_query).view(-1, 1, c)
+    key = F.linear(x, w_key, b_key).view(-1, 1, c)
+    value = F.linear(x, w_value, b_value).view(-1, 1, c)
+    alpha = (query.index_select(0, dst) * key.index_select(0, src)).sum(dim=-1) / math.sqrt(c)
+    alpha = pyg_softmax(alpha, dst, n)
+    msg = value.index_select(0, src) * alpha.view(-1, 1, 1)
+    out = torch.zeros(n, 1, c, dtype=x.dtype, device=x.device).index_add_(0, dst, msg)
+    out = out.view(-1, c)                                       # concat=True, heads=1
+    return out + F.linear(x, w_skip, b_skip)                    # root_weight=True
 
 
 def with_self_loops(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
@@ -139,6 +158,17 @@ _NONLIN = {'relu': F.relu, 'elu': F.elu, 'selu': F.selu, 'tanh': torch.tanh, 'si
            'leaky_relu': F.leaky_relu, 'identity': lambda t: t}                           # get_nonlin, GNN.py:48-64
 
 
+class _QKVS(nn.Module):
+    """Parameter holder with PyG TransformerConv's state_dict names (heads=1, bias=True, root_weight=True)."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.lin_key = nn.Linear(c, c)
+        self.lin_query = nn.Linear(c, c)
+        self.lin_value = nn.Linear(c, c)
+        self.lin_skip = nn.Linear(c, c, bias=True)
+
+
 class _QK(nn.Module):
     """Parameter holder with the reference's state_dict names (`src/GRAND_plus.py:146-147,178`)."""
 
@@ -193,15 +223,16 @@ class OracleGNN(nn.Module):
             if opt.get(flag):
                 in_dim += opt['global_feat_dim']
                 setattr(self, name, _GlobalCNN(1, c, opt['global_feat_dim'], dim=self.dim))
-        assert opt['enc'] == 'identity' and opt['conv_type'] in ('GRAND', 'GRAND_plus')
+        assert opt['enc'] == 'identity' and opt['conv_type'] in ('GRAND', 'GRAND_plus', 'TRANS')
+        _QK_ = _QKVS if opt['conv_type'] == 'TRANS' else _QK
         self.enc = nn.Linear(in_dim, c, bias=False)
         self.enc.weight.data = identity_encoder_weight(in_dim, c)
         self.enc.weight.requires_grad = False
         if opt['share_conv']:
-            shared = _QK(c)
+            shared = _QK_(c)
             self.conv_layers = nn.ModuleList([shared for _ in range(opt['num_layers'])])     # :131-141
         else:
-            self.conv_layers = nn.ModuleList([_QK(c) for _ in range(opt['num_layers'])])
+            self.conv_layers = nn.ModuleList([_QK_(c) for _ in range(opt['num_layers'])])
         if opt.get('learn_step'):
             self.steps = nn.ParameterList([nn.Parameter(torch.tensor([opt['time_step']]))
                                            for _ in range(opt['num_layers'])])              # :179-180
@@ -231,9 +262,15 @@ class OracleGNN(nn.Module):
         x = self.enc(feats.to(self.enc.weight.dtype))                                      # :270
         alphas = []
         for i, layer in enumerate(self.conv_layers):                                       # :273
-            res, (alpha, _, _) = grand_residual(x, edge_index, layer.lin_query.weight, layer.lin_query.bias,
-                                                layer.lin_key.weight, layer.lin_key.bias,
-                                                self.temperature(), return_attention=True)
+            if opt['conv_type'] == 'TRANS':                                                # GNN.py:284, stock TransformerConv
+                res = transformer_conv(x, edge_index, layer.lin_query.weight, layer.lin_query.bias, layer.lin_key.weight,
+                                       layer.lin_key.bias, layer.lin_value.weight, layer.lin_value.bias,
+                                       layer.lin_skip.weight, layer.lin_skip.bias)
+                alpha = None
+            else:
+                res, (alpha, _, _) = grand_residual(x, edge_index, layer.lin_query.weight, layer.lin_query.bias,
+                                                    layer.lin_key.weight, layer.lin_key.bias,
+                                                    self.temperature(), return_attention=True)
             if not (opt['residual'] and opt['conv_type'] == 'GRAND_plus'):
                 res = F.dropout(res, opt.get('dropout', 0.0), training=self.training)      # :285 / :295
                 res = _NONLIN[opt['non_lin']](res)                                         # :286 / :296

@@ -28,6 +28,7 @@ CASES = [
     ((10, 10), 2, 64, 2, 'GRAND_plus', {'fix_boundary': False, 'self_loops': True}),   # in-degree 7 rows
     ((21,), 3, 8, 3, 'GRAND', {'gnn_inc_feat_f': False}),                               # Burgers features (params.py:148,155)
 ]
+TRANS_CASES = [((11, 11), 2, 8, 3, 'relu'), ((14, 14), 3, 64, 2, 'tanh'), ((12, 12), 2, 32, 2, 'identity')]
 IDS = [f"{'x'.join(map(str, c[0]))}-b{c[1]}-C{c[2]}-L{c[3]}-{c[4]}" + ('-' + ','.join(c[5]) if c[5] else '') for c in CASES]
 
 
@@ -89,3 +90,29 @@ def test_global_cnn_features_parity(gpu_device, mesh_dims, hidden):
         assert e64 <= max(GRAD_TOL, 1.5 * noise), f"{name}.grad vs fp64 oracle: {e64:.2e} (fp32 oracle: {noise:.2e})"
         checked += name.startswith('global_feature_extractor')
     assert checked == 16                                        # 2 extractors x 4 convs x (weight, bias)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh_dims,batch,hidden,layers,non_lin", TRANS_CASES, ids=[f"{c[0][0]}x{c[0][1]}-C{c[2]}-{c[4]}" for c in TRANS_CASES])
+def test_trans_conv_parity(gpu_device, mesh_dims, batch, hidden, layers, non_lin):
+    """conv_type='TRANS' (stock TransformerConv, GNN.py:112-113): graph part on the HIP kernels, value / skip projections as
+    dense GEMMs; layer by layer with non_lin and the residual update (GNN.py:284-291).  Coordinates and every
+    parameter gradient against the oracle."""
+    oracle, o64, model, ref, ref64, out = _run(gpu_device, mesh_dims, batch, hidden, layers, 'TRANS', {'non_lin': non_lin})
+    norm, elem = rel_err(out, ref64)
+    _, noise_elem = rel_err(ref, ref64)                             # the fp32 oracle's own elementwise error (small coordinates
+    assert norm <= COORD_TOL                                        #  after cancellation: x + dt * (value + skip terms))
+    assert elem <= max(COORD_TOL, 2.0 * noise_elem), f"x_phys elementwise {elem:.2e} (fp32 oracle vs fp64: {noise_elem:.2e})"
+    assert rel_err(out, ref)[0] <= COORD_TOL
+    d32, d64 = dict(oracle.named_parameters()), dict(o64.named_parameters())
+    checked = 0
+    for name, ph in model.named_parameters():
+        if name not in d64 or d64[name].grad is None:
+            continue
+        if name.endswith('lin_key.bias'):
+            assert ph.grad.abs().max().item() == 0.0                # vanishes analytically (softmax shift invariance)
+            continue
+        e64, noise = rel_err(ph.grad, d64[name].grad)[0], rel_err(d32[name].grad, d64[name].grad)[0]
+        assert e64 <= max(GRAD_TOL, 1.5 * noise), f"{name}.grad vs fp64 oracle: {e64:.2e} (fp32 oracle: {noise:.2e})"
+        checked += 1
+    assert checked == 7                                             # query w/b, key w, value w/b, skip w/b (shared conv)

@@ -137,3 +137,25 @@ def test_oracle_reproduces_golden(path):
     assert np.abs(out.detach().numpy() - g['x_phys_f64']).max() <= 1e-6
     scale = np.abs(g['d_wq_f64']).max()
     assert np.abs(lay.lin_query.weight.grad.numpy() - g['d_wq_f64']).max() <= 1e-3 * scale
+
+
+def test_transformer_conv_matches_dense_fp64():
+    """The 'TRANS' branch of get_conv (stock TransformerConv, GNN.py:112-113): gather/softmax/scatter restatement against
+    the dense masked-softmax formulation, fp64, including a node without in-edges (its aggregation is empty, the root term stays)."""
+    import math
+    from oracle.pyg_restatement import transformer_conv
+    torch.manual_seed(0)
+    n, c = 30, 8
+    ei = torch.unique(torch.stack([torch.randint(0, n, (120,)), torch.randint(0, n, (120,))]), dim=1)
+    ei = ei[:, ei[1] != 7]                                           # node 7: no in-edge
+    x = torch.randn(n, c, dtype=torch.float64)
+    W = [torch.randn(c, c, dtype=torch.float64) * 0.3 for _ in range(4)]
+    b = [torch.randn(c, dtype=torch.float64) * 0.3 for _ in range(4)]
+    out = transformer_conv(x, ei, W[0], b[0], W[1], b[1], W[2], b[2], W[3], b[3])
+    Q, K, V = x @ W[0].T + b[0], x @ W[1].T + b[1], x @ W[2].T + b[2]
+    mask = torch.zeros(n, n, dtype=torch.bool)
+    mask[ei[1], ei[0]] = True
+    A = torch.nan_to_num(torch.softmax(((Q @ K.T) / math.sqrt(c)).masked_fill(~mask, float('-inf')), dim=1), nan=0.0)
+    ref = A @ V + x @ W[3].T + b[3]
+    assert (out - ref).abs().max().item() <= 1e-13
+    assert torch.allclose(out[7], x[7] @ W[3].T + b[3], rtol=0, atol=1e-14)
