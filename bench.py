@@ -66,6 +66,9 @@ def main():
     ap.add_argument('--torch-loss', action='store_true', help='torch F.mse_loss instead of the one-launch native loss')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dense-slots', action='store_true',
+                    help='materialise the zero-padded encoder output, the full last-layer output and the padded top gradient '
+                         '(DESIGN.md §4) instead of their compact forms')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     args = ap.parse_args()
 
@@ -90,7 +93,7 @@ def main():
     w = WORKLOADS[args.workload]
     opt = hot_path_opt(mesh_dims=[w['n'], w['n']], hidden_dim=w['hidden'], num_layers=w['layers'], conv_type=w['conv'],
                        gnn_inc_feat_f=w['f'], gnn_inc_feat_uu=w['uu'], device=str(dev), loss_type='mesh_loss',
-                       show_mesh_evol_plots='False')
+                       show_mesh_evol_plots='False', compact_slots=not args.dense_slots)
     ds = MeshDataset([w['n'], w['n']], w['batch'], seed=rank)        # every rank owns its own shard of meshes
     data = collate(ds.samples).to(dev)
     target = data.x_phys
@@ -287,7 +290,7 @@ def main():
             'config': {'workload': args.workload, 'mesh': f"{w['n']}x{w['n']}", 'meshes_per_gpu': w['batch'],
                        'global_batch': w['batch'] * world, 'mp_layers': w['layers'], 'hidden': w['hidden'],
                        'conv_type': w['conv'], 'parallelism': f'dp{world}',
-                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'launch': ('hipgraph' if world > 1 else 'hipgraph+adam') if graph is not None else 'eager'},
+                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'slots': 'dense' if args.dense_slots else 'compact', 'launch': ('hipgraph' if world > 1 else 'hipgraph+adam') if graph is not None else 'eager'},
             'roofline': roofline, 'roofline_mfma': roofline_mfma, 'kernels': kernels, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))

@@ -225,7 +225,7 @@ class GNN(nn.Module):
             else:
                 out0 = None
             learnable = o.get('learn_step') or o.get('softmax_temp_type') == 'learnable_a'
-            if (native_in and x_all is not None and not learnable and o['num_layers'] >= 2 and o['hidden_dim'] >= 8
+            if (o.get('compact_slots', True) and native_in and x_all is not None and not learnable and o['num_layers'] >= 2 and o['hidden_dim'] >= 8
                     and self.enc.weight.shape[1] <= 4 and self._enc_is_zero_pad()):
                 # identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the compact [N,4] features, the padded
                 # [N,C] matrix is never written (nor read back by the layer-0 backward)
@@ -255,8 +255,9 @@ class GNN(nn.Module):
             store = o['conv_type'] == 'GRAND' or isinstance(o.get('show_mesh_evol_plots'), bool)
             x, alpha = Fn.grand_euler_block(x, wq, bq, wk, bk, self._layer_params(dev), graph,
                                             o['num_layers'], want_alpha=store, x_all=x_all,
-                                            out_cols=self.dim if isinstance(self.dec, nn.Identity) else None, x0_cols=x0_cols)
-            sliced = isinstance(self.dec, nn.Identity)
+                                            out_cols=self.dim if (isinstance(self.dec, nn.Identity) and o.get('compact_slots', True)) else None,
+                                            x0_cols=x0_cols)
+            sliced = isinstance(self.dec, nn.Identity) and o.get('compact_slots', True)
             if store:                                                      # GRAND_plus.py:253-256, :381
                 for l, layer in enumerate(self.conv_layers):
                     layer.stored_ei, layer._stored = graph.edge_index, (graph, alpha[l])

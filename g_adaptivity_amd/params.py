@@ -46,6 +46,9 @@ def hot_path_opt(**overrides) -> dict:
         'lr': 0.001, 'decay': 0.0,
         'device': 'cpu',
         'show_mesh_evol_plots': False,      # bool => conv stores stored_ei/stored_alpha (GRAND_plus.py:253)
+        # not a reference key: False materialises the zero-padded encoder output, the full last-layer output and the padded
+        # top gradient (the literal GNN.py:270,299 data flow) instead of their compact forms
+        'compact_slots': True,
     }
     opt.update(overrides)
     return opt
