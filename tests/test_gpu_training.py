@@ -97,3 +97,14 @@ def test_compact_encoder_output_equals_dense(gpu_device):
         for k, p in model.named_parameters():
             if p.grad is not None:
                 assert torch.equal(p.grad, grads_c[k]), k
+        # ... and the fully dense data flow (opt['compact_slots'] = False: padded x0, full x_L, padded top gradient)
+        torch.manual_seed(1)
+        dense = GNN(ds, dict(opt, compact_slots=False)).to(gpu_device).train()
+        dense.load_state_dict(model.state_dict())
+        out_f = dense(data)
+        F.mse_loss(out_f, data.x_phys).backward()
+        torch.cuda.synchronize()
+        assert torch.equal(out_c, out_f)
+        for k, p in dense.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(p.grad, grads_c[k]), k
