@@ -69,6 +69,14 @@ def test_rollout_reuses_the_graph_and_hipgraph_replay_equals_eager(gpu_device):
     assert all(torch.equal(a, b) for a, b in zip(outs_e, outs_g))
     assert not torch.equal(outs_e[0], outs_e[-1])
     assert model.end_MLmodel is not None
+    # unchanged fields are not copied again (same tensor object, same version); an in-place update must be seen
+    with torch.no_grad():
+        before = runner(data).clone()
+        data.uu_tensor.mul_(0.5)                                    # in place: same object, new version
+        after_g, after_e = runner(data).clone(), model(data).clone()
+        data.x_comp = data.x_comp.clone()                           # new object, same values
+        again = runner(data).clone()
+    assert torch.equal(after_g, after_e) and not torch.equal(before, after_g) and torch.equal(again, after_g)
 
 
 @pytest.mark.gpu
