@@ -1980,8 +1980,16 @@ template <int TM> static const int32_t* meta_for(const int32_t* const (&m)[3]) {
     static_assert(TM == 64 || TM == 128 || TM == 256, "tile heights with metadata");
     return m[TM == 64 ? 0 : (TM == 128 ? 1 : 2)];
 }
+// More than 48 KB of dynamic LDS needs the attribute set once per (device, kernel); the call costs several microseconds
+// of host time, which is most of an eager small-graph forward, so it is remembered.
 template <typename KernelT> static void allow_lds(KernelT k, int bytes) {
-    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (bytes <= 48 * 1024) return;
+    static std::vector<std::pair<int, const void*>> done;        // launches come from one host thread per process
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void* f = reinterpret_cast<const void*>(k);
+    for (auto& d : done) if (d.first == dev && d.second == f) return;
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) done.emplace_back(dev, f);
 }
 
 // The wide kernels (gadapt_wide.inc) take over for hidden size 64 when the graph qualifies; GADAPT_WIDE=0 in the
