@@ -295,6 +295,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()                                                # rank 0 was still measuring: leave together
         dist.destroy_process_group()
 
 
