@@ -79,11 +79,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     import torch.distributed as dist
+    # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (never used by the driver): GADAPT_BENCH_SHARE_GPU=1
+    # maps the ranks onto the GPUs that exist, GADAPT_BENCH_BACKEND=gloo moves the collectives off RCCL (which needs one GPU per rank)
+    if os.environ.get('GADAPT_BENCH_SHARE_GPU') == '1':
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    backend = os.environ.get('GADAPT_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt, _native
     from g_adaptivity_amd.optim import FlatAdam
