@@ -116,3 +116,26 @@ def test_compact_encoder_output_equals_dense(gpu_device):
         for k, p in dense.named_parameters():
             if p.grad is not None:
                 assert torch.equal(p.grad, grads_c[k]), k
+
+
+@pytest.mark.gpu
+def test_bench_line_contract(gpu_device):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline object of the dominant kernel group and a
+    bounded CPU baseline (run as the driver runs it: a child process, small K / W)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '2', '--cpu-seconds', '2'],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 2 and d['unit'] == 'meshes/s' and d['scaling'] == 'weak'
+    assert d['vs_baseline'] is None and d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config']
+    rf, cb = d['roofline'], d['cpu_baseline']
+    assert rf['bound'] == 'hbm' and rf['peak'] == 8000.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3 and rf['unit'] == 'GB/s'
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and 'sample' in cb
+    assert abs(d['value'] - 32 * 1000.0 / d['ms_per_step']) / d['value'] < 0.01
