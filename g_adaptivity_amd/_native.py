@@ -39,6 +39,8 @@ PROTOTYPES = {
     'gadapt_coeffs_backward': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'gadapt_encode_linear': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
     'gadapt_encode_features': (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _P]),
+    'gadapt_encode_features_coeffs': (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _P]),
+    'gadapt_slab_reduce_coeffs_backward': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'gadapt_loss_forward': (_I, [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P]),
     'gadapt_loss_scratch_floats': (_I, []),
     'gadapt_layer_forward': (_I, [_G, _P, _P, _P, _P, _P, _P, _I, _I, _P]),

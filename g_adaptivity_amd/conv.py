@@ -173,7 +173,6 @@ class TRANS_conv(nn.Module):
         self.lin_query = nn.Linear(in_channels, out_channels)
         self.lin_value = nn.Linear(in_channels, out_channels)
         self.lin_skip = nn.Linear(in_channels, out_channels, bias=True)
-        self._has_in = {}
 
     def reset_parameters(self):
         for lin in (self.lin_key, self.lin_query, self.lin_value, self.lin_skip):
@@ -186,12 +185,7 @@ class TRANS_conv(nn.Module):
         res, _ = Fn.grand_residual(x, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
                                    self.lin_key.bias, scale, graph, False)
         m = res + x                                                    # A(x) x
-        has_in = self._has_in.get(id(graph))
-        if has_in is None:
-            if len(self._has_in) > 8:
-                self._has_in.clear()
-            has_in = self._has_in[id(graph)] = (graph.rowptr_t[1:] > graph.rowptr_t[:-1]).to(torch.float32).unsqueeze(-1)
-        out = torch.nn.functional.linear(m, self.lin_value.weight) + has_in * self.lin_value.bias
+        out = torch.nn.functional.linear(m, self.lin_value.weight) + graph.has_in * self.lin_value.bias
         return out + torch.nn.functional.linear(x, self.lin_skip.weight, self.lin_skip.bias)
 
     def __repr__(self):

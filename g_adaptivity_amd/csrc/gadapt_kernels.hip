@@ -64,7 +64,7 @@ static int check_launch(const char* what) {
     return GADAPT_OK;
 }
 extern "C" const char* gadapt_last_error(void) { return g_err; }
-extern "C" int gadapt_abi_version(void) { return 2; }
+extern "C" int gadapt_abi_version(void) { return 3; }
 extern "C" int gadapt_supported_hidden_dim(int c) {
     return c == 4 || c == 8 || c == 16 || c == 32 || c == 64 || c == 128;
 }
@@ -73,28 +73,37 @@ extern "C" int gadapt_supported_hidden_dim(int c) {
 // optional per-kernel timing (bench/roofline only): HIP events on the launch stream around every
 // hot-kernel launch.  Off by default; when off the launch path touches none of this.
 // ------------------------------------------------------------------------------------------------
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 struct ProfRec { int id, variant; hipEvent_t a, b; };
-static bool g_prof_on = false;
+// Launches come from more than one host thread (forward: the Python thread, backward: autograd's worker thread), so the
+// record list is guarded; the flag is read on every launch and stays a relaxed atomic.
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 struct ProfScope {
     hipStream_t st; int idx = -1;
     // variant: bit 0 = compact upstream gradient, bit 1 = compact layer input, bit 2 = head-only output (launchers below)
+    hipEvent_t eb = nullptr;
     ProfScope(int id, hipStream_t s, int variant = 0) : st(s) {
-        if (!g_prof_on) return;
+        if (!g_prof_on.load(std::memory_order_relaxed)) return;
         ProfRec r{id, variant, nullptr, nullptr};
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
         (void)hipEventRecord(r.a, st);
+        eb = r.b;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         g_prof.push_back(r);
         idx = (int)g_prof.size() - 1;
     }
-    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, st); }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(eb, st); }
 };
-extern "C" int gadapt_profile_enable(int on) { g_prof_on = (on != 0); return GADAPT_OK; }
+extern "C" int gadapt_profile_enable(int on) { g_prof_on.store(on != 0, std::memory_order_relaxed); return GADAPT_OK; }
 extern "C" int gadapt_profile_read(int kernel_id, double* total_ms, int* count) {
     if (!total_ms || !count) return fail(GADAPT_E_BADARG, "profile_read: null pointer");
     double tot = 0.0; int n = 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) {
         if (r.id != kernel_id) continue;
         float ms = 0.f;
@@ -106,6 +115,7 @@ extern "C" int gadapt_profile_read(int kernel_id, double* total_ms, int* count) 
 extern "C" int gadapt_profile_samples(int kernel_id, double* out_ms, int cap) {
     if (!out_ms || cap < 0) return fail(GADAPT_E_BADARG, "profile_samples: bad argument");
     int n = 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) {
         if (r.id != kernel_id) continue;
         float ms = 0.f;
@@ -116,6 +126,7 @@ extern "C" int gadapt_profile_samples(int kernel_id, double* out_ms, int cap) {
 extern "C" int gadapt_profile_variants(int kernel_id, int* out, int cap) {
     if (!out || cap < 0) return fail(GADAPT_E_BADARG, "profile_variants: bad argument");
     int n = 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) {
         if (r.id != kernel_id) continue;
         float ms = 0.f;                                         // same filter as gadapt_profile_samples: entries stay aligned
@@ -143,6 +154,7 @@ extern "C" int gadapt_profile_calibrate(int n, void* stream) {
     return check_launch("profile_empty_kernel");
 }
 extern "C" int gadapt_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
     return GADAPT_OK;
@@ -1652,9 +1664,8 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
 // C is a compile-time trip count so that every load of a dot product is in flight at once (a runtime-length loop
 // pays one L2 round trip per unrolled group).
 template <int C>
-__global__ void coeffs_fwd_kernel(const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wk,
-                                  float* __restrict__ a, float* __restrict__ p0) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void coeffs_fwd_body(const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wk,
+                                                float* __restrict__ a, float* __restrict__ p0, int e) {
     if (e < C * C) {                    // A[o][cc] = sum_r wk[r][o] wq[r][cc]
         const int o = e / C, cc = e % C;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1668,6 +1679,11 @@ __global__ void coeffs_fwd_kernel(const float* __restrict__ wq, const float* __r
         for (int r = 0; r < C; ++r) v = fmaf(wk[r * C + o], bq[r], v);
         p0[o] = v;
     }
+}
+template <int C>
+__global__ void coeffs_fwd_kernel(const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wk,
+                                  float* __restrict__ a, float* __restrict__ p0) {
+    coeffs_fwd_body<C>(wq, bq, wk, a, p0, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 template <int C>
@@ -1702,11 +1718,15 @@ __global__ void coeffs_bwd_kernel(const float* __restrict__ wq, const float* __r
 // x0[i][4q..4q+3] = sum_k feats[i][k] w[4q+t][k] (+ b).  W^T sits in LDS as float4 per (k, q); C/4 consecutive
 // threads write one 4*C-byte row, and a thread keeps its q while it strides over nodes.
 #define GADAPT_ENC_MAX_WORDS 4096      /* C * F floats of LDS */
-__global__ __launch_bounds__(256) void encode_linear_kernel(const float* __restrict__ feats, int f0, const float* __restrict__ e1,
-                                                            const float* __restrict__ e2, const float* __restrict__ w,
-                                                            const float* __restrict__ b, float* __restrict__ x0,
-                                                            int64_t n_nodes, int f, int c) {
-    __shared__ float4 wl[GADAPT_ENC_MAX_WORDS / 4];
+struct EncArgs {
+    const float* feats; int f0; const float* e1; const float* e2; const float* w; const float* b; float* x0;
+    int64_t n_nodes; int f, c;
+};
+// block `bid` of `nblocks` encoder blocks (the merged encoder + coefficient launch runs more blocks than that)
+__device__ __forceinline__ void encode_body(const EncArgs& p, float4* wl, int bid, int nblocks) {
+    const float* __restrict__ feats = p.feats; const float* __restrict__ e1 = p.e1; const float* __restrict__ e2 = p.e2;
+    const float* __restrict__ w = p.w; const float* __restrict__ b = p.b; float* __restrict__ x0 = p.x0;
+    const int f0 = p.f0, f = p.f, c = p.c; const int64_t n_nodes = p.n_nodes;
     const int c4 = c >> 2;
     for (int idx = threadIdx.x; idx < f * c4; idx += blockDim.x) {
         const int k = idx / c4, q = idx % c4;
@@ -1720,8 +1740,8 @@ __global__ __launch_bounds__(256) void encode_linear_kernel(const float* __restr
     // Four rows per thread and iteration, every load of the four issued before the first use (the kernel is a pure
     // HBM write stream: what limits it is how many stores a wave keeps in flight).
     constexpr int R = 4;
-    const int64_t stride = (int64_t)gridDim.x * rows_per_block;
-    for (int64_t i0 = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / c4; i0 < n_nodes; i0 += R * stride) {
+    const int64_t stride = (int64_t)nblocks * rows_per_block;
+    for (int64_t i0 = (int64_t)bid * rows_per_block + threadIdx.x / c4; i0 < n_nodes; i0 += R * stride) {
         float xv[R][4], x1[R], x2[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -1763,6 +1783,19 @@ __global__ __launch_bounds__(256) void encode_linear_kernel(const float* __restr
         }
     }
 }
+__global__ __launch_bounds__(256) void encode_linear_kernel(EncArgs p) {
+    __shared__ float4 wl[GADAPT_ENC_MAX_WORDS / 4];
+    encode_body(p, wl, blockIdx.x, gridDim.x);
+}
+// The encoder and the composite coefficients (A, p0) of the shared conv are independent and both precede layer 0: one
+// launch, the first `enc_blocks` workgroups encode, the rest compute coefficients (a dependent dispatch costs ~4.5 us).
+template <int C>
+__global__ __launch_bounds__(256) void encode_coeffs_kernel(EncArgs p, int enc_blocks, const float* __restrict__ wq, const float* __restrict__ bq,
+                                                            const float* __restrict__ wk, float* __restrict__ a, float* __restrict__ p0) {
+    __shared__ float4 wl[GADAPT_ENC_MAX_WORDS / 4];
+    if ((int)blockIdx.x < enc_blocks) { encode_body(p, wl, blockIdx.x, enc_blocks); return; }
+    coeffs_fwd_body<C>(wq, bq, wk, a, p0, ((int)blockIdx.x - enc_blocks) * 256 + threadIdx.x);
+}
 
 // g_top[i][:] = {g_phys[i][0..d), 0, ...}: backward of the x[:, :dim] slice (GNN.py:299) in one pass
 __global__ void pad_columns_kernel(const float* __restrict__ g_phys, float* __restrict__ g_top, int64_t n_nodes, int d, int c) {
@@ -1799,6 +1832,51 @@ __global__ void slab_reduce2_kernel(const float* part, float* d_a, float* d_p0, 
     float v = 0.f;
     for (int k = 0; k < GADAPT_SLAB_CHUNKS; ++k) v += part[(size_t)k * row_len + e];
     if (e < c * c) d_a[e] = v; else d_p0[e - c * c] = v;
+}
+
+// part [CHUNKS][C*C+C] -> (dA, dp0) in LDS -> dWq | dbq | dWk | dbk: the second level of the slab reduction and the chain
+// rule of coeffs_bwd_kernel in ONE launch.  Every workgroup adds the CHUNKS partial rows itself (fixed order, so all
+// workgroups hold bit-identical sums; 0.5 MB of L2-resident reads per workgroup at C = 64) and then produces its share
+// of the 2 C^2 + 2 C outputs.  dA rows are padded by one float: the dWk sum walks a column of dA^T.
+template <int C>
+__global__ __launch_bounds__(256) void reduce2_coeffs_bwd_kernel(const float* __restrict__ part, const float* __restrict__ wq,
+                                                                 const float* __restrict__ bq, const float* __restrict__ wk,
+                                                                 float* __restrict__ d_wq, float* __restrict__ d_bq,
+                                                                 float* __restrict__ d_wk, float* __restrict__ d_bk) {
+    extern __shared__ float4 smem4[];
+    float* da = reinterpret_cast<float*>(smem4);                 // [C][C+1]
+    float* dp = da + C * (C + 1);                                // [C]
+    constexpr int ROW = C * C + C, c2 = C * C;
+    for (int e = threadIdx.x; e < ROW; e += 256) {
+        float v = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < GADAPT_SLAB_CHUNKS; ++k) v += part[(size_t)k * ROW + e];
+        if (e < c2) da[(e / C) * (C + 1) + (e % C)] = v; else dp[e - c2] = v;
+    }
+    __syncthreads();
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * c2 + 2 * C; e += gridDim.x * 256) {
+        if (e < c2) {                       // d_wq[r][cc] = sum_o wk[r][o] dA[o][cc]
+            const int r = e / C, cc = e % C;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < C; ++o) v[o & 3] = fmaf(wk[r * C + o], da[o * (C + 1) + cc], v[o & 3]);
+            d_wq[e] = (v[0] + v[1]) + (v[2] + v[3]);
+        } else if (e < 2 * c2) {            // d_wk[r][o] = sum_cc wq[r][cc] dA[o][cc] + bq[r] dp0[o]
+            const int f = e - c2, r = f / C, o = f % C;
+            float v[4] = {bq[r] * dp[o], 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) v[cc & 3] = fmaf(wq[r * C + cc], da[o * (C + 1) + cc], v[cc & 3]);
+            d_wk[f] = (v[0] + v[1]) + (v[2] + v[3]);
+        } else if (e < 2 * c2 + C) {        // d_bq[r] = sum_o wk[r][o] dp0[o]
+            const int r = e - 2 * c2;
+            float v = 0.f;
+#pragma unroll
+            for (int o = 0; o < C; ++o) v = fmaf(wk[r * C + o], dp[o], v);
+            d_bq[r] = v;
+        } else {
+            d_bk[e - 2 * c2 - C] = 0.f;     // softmax shift invariance: d/d lin_key.bias vanishes identically
+        }
+    }
 }
 
 __global__ void mesh_loss_seed_kernel(const float* x_top, const float* target, float* x_phys, float* g_top, float* loss_out,
@@ -1984,10 +2062,13 @@ template <int TM> static const int32_t* meta_for(const int32_t* const (&m)[3]) {
 // of host time, which is most of an eager small-graph forward, so it is remembered.
 template <typename KernelT> static void allow_lds(KernelT k, int bytes) {
     if (bytes <= 48 * 1024) return;
-    static std::vector<std::pair<int, const void*>> done;        // launches come from one host thread per process
+    // forward launches come from the Python thread, backward launches from autograd's worker thread: the table is guarded
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void*>> done;
     int dev = 0;
     (void)hipGetDevice(&dev);
     const void* f = reinterpret_cast<const void*>(k);
+    std::lock_guard<std::mutex> lk(mu);
     for (auto& d : done) if (d.first == dev && d.second == f) return;
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) done.emplace_back(dev, f);
 }
@@ -2168,6 +2249,24 @@ extern "C" int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch,
     return check_launch("slab_reduce");
 }
 
+// slab -> d_wq | d_bq | d_wk | d_bk in two launches (first-level partial sums, then second level + chain rule together)
+extern "C" int gadapt_slab_reduce_coeffs_backward(const float* slab, int n_rows, float* scratch, const float* wq, const float* bq,
+                                                  const float* wk, float* d_wq, float* d_bq, float* d_wk, float* d_bk, int c, void* stream) {
+    if (!slab || n_rows <= 0 || !scratch || !wq || !bq || !wk || !d_wq || !d_bq || !d_wk || !d_bk || !gadapt_supported_hidden_dim(c))
+        return fail(GADAPT_E_BADARG, "slab_reduce_coeffs_backward: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int row_len = c * c + c;
+    hipLaunchKernelGGL(slab_reduce1_kernel, dim3((row_len + 255) / 256, GADAPT_SLAB_CHUNKS), dim3(256), 0, st, slab, scratch, n_rows, row_len);
+    const int lds = (c * (c + 1) + c) * 4;
+    int blocks = (2 * c * c + 2 * c + 255) / 256;
+    if (blocks > 32) blocks = 32;                               // every workgroup repeats the second-level sums
+#define GADAPT_R2CB(CC) case CC: allow_lds(reduce2_coeffs_bwd_kernel<CC>, lds); \
+        hipLaunchKernelGGL(reduce2_coeffs_bwd_kernel<CC>, dim3(blocks), dim3(256), lds, st, scratch, wq, bq, wk, d_wq, d_bq, d_wk, d_bk); break;
+    switch (c) { GADAPT_R2CB(4) GADAPT_R2CB(8) GADAPT_R2CB(16) GADAPT_R2CB(32) GADAPT_R2CB(64) GADAPT_R2CB(128) default: break; }
+#undef GADAPT_R2CB
+    return check_launch("slab_reduce_coeffs_backward");
+}
+
 extern "C" int gadapt_coeffs_forward(const float* wq, const float* bq, const float* wk, float* a_out, float* p0_out, int c, void* stream) {
     if (!wq || !bq || !wk || !a_out || !p0_out || c <= 0) return fail(GADAPT_E_BADARG, "coeffs_forward: bad argument");
     if (!gadapt_supported_hidden_dim(c)) return fail(GADAPT_E_BADARG, "coeffs_forward: unsupported hidden_dim");
@@ -2190,8 +2289,9 @@ extern "C" int gadapt_coeffs_backward(const float* wq, const float* bq, const fl
     return check_launch("coeffs_bwd_kernel");
 }
 
+struct wq_t { const float* wq; const float* bq; const float* wk; float* a; float* p0; int c; };
 static int launch_encode(const float* feats, int f0, const float* e1, const float* e2, const float* w, const float* b, float* x0,
-                         int64_t n_nodes, int c, void* stream) {
+                         int64_t n_nodes, int c, void* stream, const void* coeffs = nullptr) {
     const int f = f0 + (e1 ? 1 : 0) + (e2 ? 1 : 0);
     if (c % 4 || c > 256 || 256 % (c / 4) || (int64_t)c * f > GADAPT_ENC_MAX_WORDS)
         return fail(GADAPT_E_BADARG, "encode: need hidden_dim in {4,8,...,256} dividing 1024 and hidden_dim*in_dim <= 4096");
@@ -2199,9 +2299,19 @@ static int launch_encode(const float* feats, int f0, const float* e1, const floa
     int64_t blocks = (n_nodes + 4 * rows_per_block - 1) / (4 * rows_per_block);    // four rows per thread and iteration
     if (blocks > 1024) blocks = 1024;                                              // resident set: the W^T table is staged once per block
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(encode_linear_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), feats, f0, e1, e2, w, b,
-                       x0, n_nodes, f, c);
-    return check_launch("encode_linear_kernel");
+    const wq_t* cf = static_cast<const wq_t*>(coeffs);
+    EncArgs p{feats, f0, e1, e2, w, b, x0, n_nodes, f, c};
+    if (!cf) {
+        hipLaunchKernelGGL(encode_linear_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+        return check_launch("encode_linear_kernel");
+    }
+    const int cblocks = (cf->c * cf->c + cf->c + 255) / 256;
+#define GADAPT_ENC_CF(CC) case CC: hipLaunchKernelGGL(encode_coeffs_kernel<CC>, dim3((unsigned)blocks + cblocks), dim3(256), 0, static_cast<hipStream_t>(stream), \
+                                                      p, (int)blocks, cf->wq, cf->bq, cf->wk, cf->a, cf->p0); break;
+    switch (cf->c) { GADAPT_ENC_CF(4) GADAPT_ENC_CF(8) GADAPT_ENC_CF(16) GADAPT_ENC_CF(32) GADAPT_ENC_CF(64) GADAPT_ENC_CF(128)
+                     default: return fail(GADAPT_E_BADARG, "encode_features_coeffs: unsupported hidden_dim"); }
+#undef GADAPT_ENC_CF
+    return check_launch("encode_coeffs_kernel");
 }
 extern "C" int gadapt_encode_linear(const float* feats, const float* w, const float* b, float* x0, int64_t n_nodes, int f, int c, void* stream) {
     if (!feats || !w || !x0 || n_nodes <= 0 || f <= 0 || c <= 0) return fail(GADAPT_E_BADARG, "encode_linear: bad argument");
@@ -2212,6 +2322,15 @@ extern "C" int gadapt_encode_features(const float* x_comp, int dim, const float*
     if (!x_comp || !w || !x0 || n_nodes <= 0 || dim <= 0 || c <= 0) return fail(GADAPT_E_BADARG, "encode_features: bad argument");
     // the kernel reads "first extra" then "second extra": with only uu present it is the first one
     return launch_encode(x_comp, dim, f_tensor ? f_tensor : uu_tensor, f_tensor ? uu_tensor : nullptr, w, b, x0, n_nodes, c, stream);
+}
+extern "C" int gadapt_encode_features_coeffs(const float* x_comp, int dim, const float* f_tensor, const float* uu_tensor, const float* w,
+                                             const float* b, float* x0, int64_t n_nodes, int c, const float* wq, const float* bq,
+                                             const float* wk, float* a_out, float* p0_out, int c_conv, void* stream) {
+    if (!x_comp || !w || !x0 || n_nodes <= 0 || dim <= 0 || c <= 0 || !wq || !bq || !wk || !a_out || !p0_out)
+        return fail(GADAPT_E_BADARG, "encode_features_coeffs: bad argument");
+    if (!gadapt_supported_hidden_dim(c_conv)) return fail(GADAPT_E_BADARG, "encode_features_coeffs: unsupported hidden_dim");
+    const wq_t cf{wq, bq, wk, a_out, p0_out, c_conv};
+    return launch_encode(x_comp, dim, f_tensor ? f_tensor : uu_tensor, f_tensor ? uu_tensor : nullptr, w, b, x0, n_nodes, c, stream, &cf);
 }
 extern "C" int gadapt_loss_forward(const float* pred, int64_t pred_stride, const float* target, int64_t n_rows, int d, int l1,
                                    float* seed, float* loss_out, float* scratch, void* stream) {

@@ -42,7 +42,7 @@ class _GrandEulerBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, wq, bq, wk, bk, layer_params, graph: MeshGraph, num_layers: int, want_alpha: bool, x_all=None,
-                out_cols=None, x0_cols=0):
+                out_cols=None, x0_cols=0, coeffs=None):
         for t, n in ((x0, 'x'), (wq, 'lin_query.weight'), (bq, 'lin_query.bias'), (wk, 'lin_key.weight'),
                      (layer_params, 'layer_params')):
             _require_gpu(t, n)
@@ -59,11 +59,15 @@ class _GrandEulerBlock(torch.autograd.Function):
         dev, st = x0.device, current_stream(x0.device)
         wq, bq, wk = wq.contiguous(), bq.contiguous(), wk.contiguous()
         layer_params = layer_params.contiguous()
-        a = torch.empty(S, c, c, device=dev, dtype=torch.float32)
-        p0 = torch.empty(S, c, device=dev, dtype=torch.float32)
-        for s in range(S):
-            check(lib().gadapt_coeffs_forward(ptr(wq[s]), ptr(bq[s]), ptr(wk[s]), ptr(a[s]), ptr(p0[s]), c, st),
-                  'gadapt_coeffs_forward')
+        if coeffs is not None:                 # (A, p0) of these very weights, already computed (merged encoder launch)
+            a, p0 = coeffs[0]
+            assert a.shape == (S, c, c) and p0.shape == (S, c) and a.is_contiguous() and p0.is_contiguous()
+        else:
+            a = torch.empty(S, c, c, device=dev, dtype=torch.float32)
+            p0 = torch.empty(S, c, device=dev, dtype=torch.float32)
+            for s in range(S):
+                check(lib().gadapt_coeffs_forward(ptr(wq[s]), ptr(bq[s]), ptr(wk[s]), ptr(a[s]), ptr(p0[s]), c, st),
+                      'gadapt_coeffs_forward')
         need_grad = any(ctx.needs_input_grad[:6])
         if x_all is None:                      # else: caller's [(L+1),N,C] buffer whose slot 0 already holds x0
             x_all = torch.empty(L + 1, n, c, device=dev, dtype=torch.float32)
@@ -118,21 +122,17 @@ class _GrandEulerBlock(torch.autograd.Function):
                                           ptr(g_ws), ptr(dxd_ws), ptr(edge_ws), ptr(slab), ptr(d_lp), ptr(d_x0), c, st),
               'gadapt_block_backward')
         scratch = torch.empty(32 * (c * c + c), device=dev, dtype=torch.float32)
-        d_a = torch.empty(c, c, device=dev, dtype=torch.float32)
-        d_p0 = torch.empty(c, device=dev, dtype=torch.float32)
         # one flat tensor [dWq | dbq | dWk | dbk]: installed as the parameters' .grad without a copy, it is the
         # gradient bucket of optim.FlatAdam (one Adam launch, one all-reduce)
         flat = torch.empty(S * (2 * c * c + 2 * c), device=dev, dtype=torch.float32)
         cuts = [0, S * c * c, S * (c * c + c), S * (2 * c * c + c), S * (2 * c * c + 2 * c)]
         d_wq, d_wk = flat[cuts[0]:cuts[1]].view(S, c, c), flat[cuts[2]:cuts[3]].view(S, c, c)
         d_bq, d_bk = flat[cuts[1]:cuts[2]].view(S, c), flat[cuts[3]:cuts[4]].view(S, c)
-        for s in range(S):
-            check(lib().gadapt_slab_reduce(ptr(slab[s]), slab_rows, ptr(scratch), ptr(d_a), ptr(d_p0), c, st),
-                  'gadapt_slab_reduce')
-            check(lib().gadapt_coeffs_backward(ptr(wq[s]), ptr(bq[s]), ptr(wk[s]), ptr(d_a), ptr(d_p0),
-                                               ptr(d_wq[s]), ptr(d_bq[s]), ptr(d_wk[s]), ptr(d_bk[s]), c, st),
-                  'gadapt_coeffs_backward')
-        return d_x0, d_wq, d_bq, d_wk, d_bk, d_lp, None, None, None, None, None, None
+        for s in range(S):                      # slab -> second-level sums + chain rule to the Linear parameters: 2 launches
+            check(lib().gadapt_slab_reduce_coeffs_backward(ptr(slab[s]), slab_rows, ptr(scratch), ptr(wq[s]), ptr(bq[s]), ptr(wk[s]),
+                                                           ptr(d_wq[s]), ptr(d_bq[s]), ptr(d_wk[s]), ptr(d_bk[s]), c, st),
+                  'gadapt_slab_reduce_coeffs_backward')
+        return d_x0, d_wq, d_bq, d_wk, d_bk, d_lp, None, None, None, None, None, None, None
 
 
 class _GrandResidual(torch.autograd.Function):
@@ -194,16 +194,18 @@ def grand_residual(x, wq, bq, wk, bk, scale: torch.Tensor, graph: MeshGraph, wan
 
 def grand_euler_block(x0: torch.Tensor, wq, bq, wk, bk, layer_params: torch.Tensor, graph: MeshGraph,
                       num_layers: int, want_alpha: bool = False, x_all: Optional[torch.Tensor] = None,
-                      out_cols: Optional[int] = None, x0_cols: int = 0):
+                      out_cols: Optional[int] = None, x0_cols: int = 0, coeffs=None):
     """Returns (x_L [N,C], alpha [L,E] in target-CSR order or None).
 
     `x_all` (optional): a contiguous [(L+1),N,C] buffer whose slot 0 IS `x0` (same memory); the
     layers then write straight into it and no copy of x0 is made.  `out_cols`: return only the first
     columns of x_L (the `x[:, :dim]` slice of `src/GNN.py:299`) with a single-pass backward.
     `x0_cols=4`: `x0` is the compact [N,4] output of the identity encoder (zero-pad, `src/GNN.py:75-82`) stored at the
-    start of `x_all`'s slot 0; layer 0 reads it directly and the padded [N,C] matrix is never written."""
+    start of `x_all`'s slot 0; layer 0 reads it directly and the padded [N,C] matrix is never written.
+    `coeffs=(a [S,C,C], p0 [S,C])`: the composite coefficients of exactly these weights when the caller has them already
+    (`encode_features(..., conv=...)` computes them in the encoder's launch)."""
     return _GrandEulerBlock.apply(x0.contiguous(), wq, bq, wk, bk, layer_params, graph, num_layers, want_alpha,
-                                  None if x_all is None else [x_all], out_cols, x0_cols)
+                                  None if x_all is None else [x_all], out_cols, x0_cols, None if coeffs is None else [coeffs])
 
 
 def score_scale(hidden_dim: int, temperature=None):
@@ -227,8 +229,10 @@ def encode_linear(feats: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
 
 
 def encode_features(x_comp: torch.Tensor, f_tensor: Optional[torch.Tensor], uu_tensor: Optional[torch.Tensor],
-                    weight: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x0 = enc([x_comp | f | uu]) (`src/GNN.py:225-239,270`) without materialising the concatenated feature matrix."""
+                    weight: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, conv=None):
+    """x0 = enc([x_comp | f | uu]) (`src/GNN.py:225-239,270`) without materialising the concatenated feature matrix.
+    `conv=(wq, bq, wk)` (weights of ONE conv, [C,C] / [C]): the same launch also computes that conv's composite
+    coefficients; returns (x0, (a [1,C,C], p0 [1,C])) instead of x0."""
     _require_gpu(x_comp, 'x_comp')
     n, dim = x_comp.shape
     c = weight.shape[0]
@@ -241,6 +245,16 @@ def encode_features(x_comp: torch.Tensor, f_tensor: Optional[torch.Tensor], uu_t
         raise ValueError(f"encoder weight has {weight.shape[1]} input columns for {dim} coordinates + extras")
     x0 = torch.empty(n, c, device=x_comp.device, dtype=torch.float32) if out is None else out
     assert x0.shape == (n, c) and x0.is_contiguous()
+    if conv is not None:
+        wq, bq, wk = (t.detach().contiguous() for t in conv)
+        cc = wq.shape[0]
+        a = torch.empty(1, cc, cc, device=x_comp.device, dtype=torch.float32)
+        p0 = torch.empty(1, cc, device=x_comp.device, dtype=torch.float32)
+        check(lib().gadapt_encode_features_coeffs(ptr(x_comp.contiguous()), dim, ptr(f_tensor), ptr(uu_tensor), ptr(weight.contiguous()),
+                                                  ptr(bias.contiguous()) if bias is not None else None, ptr(x0), n, c,
+                                                  ptr(wq), ptr(bq), ptr(wk), ptr(a), ptr(p0), cc, current_stream(x_comp.device)),
+              'gadapt_encode_features_coeffs')
+        return x0, (a, p0)
     check(lib().gadapt_encode_features(ptr(x_comp.contiguous()), dim, ptr(f_tensor), ptr(uu_tensor), ptr(weight.contiguous()),
                                        ptr(bias.contiguous()) if bias is not None else None, ptr(x0), n, c,
                                        current_stream(x_comp.device)), 'gadapt_encode_features')

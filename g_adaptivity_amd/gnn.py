@@ -121,22 +121,29 @@ class GNN(nn.Module):
 
     # ------------------------------------------------------------------ graph cache
     def _graph(self, data, num_nodes: int, device) -> MeshGraph:
+        """CSR of the edge list the conv layers see (`src/GNN.py:206-223`), built once per batch topology.  The cache key
+        holds a content fingerprint of `edge_index` and of the three masks (`graph.content_fingerprint`): batches with
+        equal node / edge counts but another connectivity, edge order or boundary marking get their own graph, as in the
+        reference, which redoes the surgery on every forward."""
         corners = getattr(data, 'corner_nodes', None)
         if corners is None:
-            ckey = ()
+            clist = None
         elif isinstance(corners, (list, tuple)):
-            ckey = tuple(int(v) for a in corners for v in np.asarray(a).reshape(-1))
+            clist = list(corners)
         else:
-            ckey = tuple(int(v) for v in np.asarray(corners).reshape(-1))
-        key = (num_nodes, int(data.edge_index.shape[1]), self.dim, ckey, bool(self.opt['fix_boundary']),
-               bool(self.opt.get('self_loops')), str(device), _graph_mod.WIDE_KERNELS, _graph_mod.WIDE_MIN_NODES)
+            clist = [np.asarray(corners)]                               # a single un-collated sample (data is not modified)
+        ckey = () if clist is None else tuple(int(v) for a in clist for v in np.asarray(a).reshape(-1))
+        fix = bool(self.opt['fix_boundary'])
+        tensors = [data.edge_index]
+        if fix:
+            # the loop nodes appended by GNN.py:209-218 come from `batch` (mesh count / per-mesh node counts)
+            tensors += [data.to_boundary_edge_mask, data.to_corner_nodes_mask, data.diff_boundary_edges_mask, data.batch]
+        key = (num_nodes, self.dim, ckey, fix, bool(self.opt.get('self_loops')), str(device),
+               _graph_mod.content_fingerprint(tensors), _graph_mod.WIDE_KERNELS, _graph_mod.WIDE_MIN_NODES)
         g = self._graphs.get(key)
         if g is None:
-            single = not isinstance(corners, (list, tuple))
-            if single and self.dim == 2 and corners is not None:
-                data.corner_nodes = [np.asarray(corners)]
-            ei = prepare_edge_index(data, self.dim, self.mesh_dims[0], self.opt['fix_boundary'],
-                                    bool(self.opt.get('self_loops')), num_nodes)
+            ei = prepare_edge_index(data, self.dim, self.mesh_dims[0], fix, bool(self.opt.get('self_loops')), num_nodes,
+                                    corner_nodes=clist if self.dim == 2 else None)
             g = MeshGraph(ei.to(device), num_nodes, device)
             if len(self._graphs) >= 32:
                 self._graphs.pop(next(iter(self._graphs)))
@@ -212,7 +219,11 @@ class GNN(nn.Module):
 
         fusable = self._fusable()
         x_all, sliced, x0_cols = None, False, 0
-        feats = None
+        feats, coeffs = None, None
+        first = self.conv_layers[0]
+        # weight-shared conv (GNN.py:131-140): its composite coefficients ride in the encoder's launch
+        conv_w = (first.lin_query.weight, first.lin_query.bias, first.lin_key.weight) \
+            if (fusable and o['share_conv'] and o['hidden_dim'] in Fn._native.SUPPORTED_HIDDEN) else None
         if glob:                                                           # differentiable wrt the CNN parameters
             feats = features()
             x = F.linear(feats, self.enc.weight, self.enc.bias) if isinstance(self.enc, nn.Linear) else self.enc(feats)
@@ -230,9 +241,13 @@ class GNN(nn.Module):
                 # identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the compact [N,4] features, the padded
                 # [N,C] matrix is never written (nor read back by the layer-0 backward)
                 x0_cols = 4
-                x = Fn.encode_features(x_comp, f, uu, self.enc.weight[:4], out=x_all[0].view(-1)[:4 * n].view(n, 4))
+                x = Fn.encode_features(x_comp, f, uu, self.enc.weight[:4], out=x_all[0].view(-1)[:4 * n].view(n, 4), conv=conv_w)
+                if conv_w is not None:
+                    x, coeffs = x
             elif native_in:                                                # GNN.py:225-239 + :270 in one launch
-                x = Fn.encode_features(x_comp, f, uu, self.enc.weight, out=out0)
+                x = Fn.encode_features(x_comp, f, uu, self.enc.weight, out=out0, conv=conv_w if x_all is not None else None)
+                if conv_w is not None and x_all is not None:
+                    x, coeffs = x
             else:
                 feats = features()
                 x = Fn.encode_linear(feats, self.enc.weight, out=out0)
@@ -243,7 +258,6 @@ class GNN(nn.Module):
             x = F.dropout(x, o.get('dropout', 0.0), training=self.training)               # GNN.py:271
 
         if fusable:
-            first = self.conv_layers[0]
             if o['share_conv']:
                 wq, bq = first.lin_query.weight.unsqueeze(0), first.lin_query.bias.unsqueeze(0)
                 wk, bk = first.lin_key.weight.unsqueeze(0), first.lin_key.bias.unsqueeze(0)
@@ -256,7 +270,7 @@ class GNN(nn.Module):
             x, alpha = Fn.grand_euler_block(x, wq, bq, wk, bk, self._layer_params(dev), graph,
                                             o['num_layers'], want_alpha=store, x_all=x_all,
                                             out_cols=self.dim if (isinstance(self.dec, nn.Identity) and o.get('compact_slots', True)) else None,
-                                            x0_cols=x0_cols)
+                                            x0_cols=x0_cols, coeffs=coeffs)
             sliced = isinstance(self.dec, nn.Identity) and o.get('compact_slots', True)
             if store:                                                      # GRAND_plus.py:253-256, :381
                 for l, layer in enumerate(self.conv_layers):

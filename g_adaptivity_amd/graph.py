@@ -10,6 +10,7 @@ of once per forward.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -20,8 +21,9 @@ from ._native import GadaptGraph
 
 
 def prepare_edge_index(data, dim: int, mesh_n: int, fix_boundary: bool, self_loops: bool,
-                       num_nodes: int) -> torch.Tensor:
-    """CPU int64 [2,E] edge list the conv layers see (`src/GNN.py:206-223`)."""
+                       num_nodes: int, corner_nodes=None) -> torch.Tensor:
+    """CPU int64 [2,E] edge list the conv layers see (`src/GNN.py:206-223`).  `corner_nodes` overrides
+    `data.corner_nodes` (a single un-collated sample carries one array instead of a list of arrays)."""
     edge_index = data.edge_index.detach().cpu()
     if fix_boundary:
         keep = ~(data.to_boundary_edge_mask.cpu() | data.to_corner_nodes_mask.cpu()
@@ -33,7 +35,8 @@ def prepare_edge_index(data, dim: int, mesh_n: int, fix_boundary: bool, self_loo
             ends = torch.stack([b * mesh_n, (b + 1) * mesh_n - 1], dim=1).reshape(-1)     # GNN.py:210
             loops = ends.repeat(2, 1)
         else:
-            corner = torch.stack([torch.as_tensor(np.asarray(a), dtype=torch.int64) for a in data.corner_nodes])
+            corners = data.corner_nodes if corner_nodes is None else corner_nodes
+            corner = torch.stack([torch.as_tensor(np.asarray(a), dtype=torch.int64) for a in corners])
             counts = torch.bincount(data.batch.cpu(), minlength=num_in_batch)
             offsets = torch.cumsum(counts, 0) - counts                                     # GNN.py:214-216
             loops = (corner + offsets.unsqueeze(-1)).reshape(-1).repeat(2, 1)
@@ -43,6 +46,69 @@ def prepare_edge_index(data, dim: int, mesh_n: int, fix_boundary: bool, self_loo
         ar = torch.arange(num_nodes, dtype=torch.int64)
         edge_index = torch.cat([edge_index, ar.repeat(2, 1)], dim=1)
     return edge_index.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Content fingerprint of index / mask tensors: what a graph cache may key on.  The reference rebuilds `edge_index` from
+# `data` on every forward (`src/GNN.py:206-218`), so a cache must notice ANY change of the edge list or of the masks -
+# equal sizes are not enough (two triangulations of one point set have equal node and edge counts).
+# ---------------------------------------------------------------------------------------------------------------
+_fp_memo: Dict[int, Tuple] = {}
+_fp_weights: Dict[Tuple, torch.Tensor] = {}
+
+
+def _fp_weight(n: int, device) -> torch.Tensor:
+    key = (str(device), n)
+    w = _fp_weights.get(key)
+    if w is None:
+        if len(_fp_weights) > 16:
+            _fp_weights.clear()
+        w = _fp_weights[key] = torch.arange(1, n + 1, device=device, dtype=torch.int64)
+    return w
+
+
+def content_fingerprint(tensors) -> Tuple:
+    """Order-sensitive checksums (int64 wrap-around arithmetic) of integer / bool tensors, on the device they live on.
+
+    Memoised per tensor OBJECT (weak reference + version counter + data pointer): a batch object fed again - every step
+    of a hipGraph-free training loop over `DeviceMeshLoader`, every call of a rollout - costs a dictionary lookup; a new
+    tensor (even at a recycled address) is hashed again.  One host synchronisation per set of new tensors."""
+    out, todo = [None] * len(tensors), []
+    for k, t in enumerate(tensors):
+        m = _fp_memo.get(id(t))
+        if m is not None and m[0]() is t and m[1] == t._version and m[2] == t.data_ptr() and m[3] == tuple(t.shape):
+            out[k] = m[4]
+        else:
+            todo.append(k)
+    if todo:
+        sums = []
+        for k in todo:
+            v = tensors[k].detach().reshape(-1).to(torch.int64)
+            n = int(v.numel())
+            if n == 0:
+                sums.append(torch.zeros(2, dtype=torch.int64, device=v.device))
+                continue
+            w = _fp_weight(n, v.device)
+            sums.append(torch.stack([(v * w).sum(), ((v + 1) * (w * w + 7)).sum()]))
+        by_dev = {}
+        for k, s_ in zip(todo, sums):
+            by_dev.setdefault(str(s_.device), []).append((k, s_))
+        for items in by_dev.values():                                   # one D2H copy per device
+            vals = torch.stack([s_ for _, s_ in items]).tolist()
+            for (k, _), v in zip(items, vals):
+                t = tensors[k]
+                fp = (tuple(t.shape), str(t.dtype), int(v[0]), int(v[1]))
+                out[k] = fp
+                if len(_fp_memo) > 256:
+                    for dead in [i for i, m in _fp_memo.items() if m[0]() is None]:
+                        _fp_memo.pop(dead, None)
+                    if len(_fp_memo) > 256:
+                        _fp_memo.clear()
+                try:
+                    _fp_memo[id(t)] = (weakref.ref(t), t._version, t.data_ptr(), tuple(t.shape), fp)
+                except TypeError:
+                    pass
+    return tuple(out)
 
 
 # The wide (hidden 64) kernels run on graphs that qualify (gadapt_ell_build_host); False keeps the tiled kernels
@@ -101,6 +167,14 @@ class MeshGraph:
                                     ells['t'].data_ptr(), ells['s'].data_ptr(), wide_deg['t'], wide_deg['s'])
         self.c_ref = C.byref(self.c_struct)
 
+    @property
+    def has_in(self) -> torch.Tensor:
+        """[N,1] float mask: 1 where a node has at least one in-edge (kept on the graph it belongs to)."""
+        m = getattr(self, '_has_in', None)
+        if m is None:
+            m = self._has_in = (self.rowptr_t[1:] > self.rowptr_t[:-1]).to(torch.float32).unsqueeze(-1)
+        return m
+
     def alpha_to_edge_order(self, alpha_t: torch.Tensor) -> torch.Tensor:
         """[.., E] attention in target-CSR order -> the caller's edge order."""
         out = torch.empty_like(alpha_t)
@@ -117,13 +191,7 @@ class GraphCache:
 
     @staticmethod
     def _key(edge_index: torch.Tensor, num_nodes: int, device) -> Tuple:
-        ei = edge_index.detach()
-        if ei.device.type != 'cpu':
-            # device-side fingerprint without a full D2H copy: three order-sensitive checksums
-            w = torch.arange(1, ei.shape[1] + 1, device=ei.device, dtype=torch.int64)
-            fp = torch.stack([(ei[0] * w).sum(), (ei[1] * w).sum(), (ei[0] ^ (ei[1] << 1)).sum()]).tolist()
-            return (int(ei.shape[1]), int(num_nodes), str(device), tuple(fp), WIDE_KERNELS, WIDE_MIN_NODES)
-        return (int(ei.shape[1]), int(num_nodes), str(device), hash(ei.numpy().tobytes()), WIDE_KERNELS, WIDE_MIN_NODES)
+        return (int(num_nodes), str(device), content_fingerprint([edge_index]), WIDE_KERNELS, WIDE_MIN_NODES)
 
     def get(self, edge_index: torch.Tensor, num_nodes: int, device) -> MeshGraph:
         key = self._key(edge_index, num_nodes, device)

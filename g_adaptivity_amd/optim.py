@@ -38,14 +38,18 @@ class FlatAdam:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, process_group=None, reduce_op: str = 'mean', capturable: bool = False):
+                 weight_decay: float = 0.0, process_group=None, reduce_op: str = 'mean', capturable: bool = False,
+                 data_parallel: bool = True):
         seen, self.params = set(), []
         for p in params:                                   # shared convs repeat the same Parameter
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p))
                 self.params.append(p)
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        # torch.optim-style view of the hyper-parameters: LR schedulers and user code read / write `param_groups[0]['lr']`
+        self.param_groups = [{'params': self.params, 'lr': lr, 'betas': tuple(betas), 'eps': eps, 'weight_decay': weight_decay}]
+        self.defaults = {'lr': lr, 'betas': tuple(betas), 'eps': eps, 'weight_decay': weight_decay}
         self.group, self.reduce_op = process_group, reduce_op
+        self.data_parallel = bool(data_parallel)        # False: never all-reduce, even inside an initialised process group
         self.step_count = 0
         # capturable: the step count lives on the device (gadapt_adam_step_dev), so step() can be captured in a hipGraph
         # with forward and backward and replayed (torch.optim.Adam(capturable=True) does the same)
@@ -56,6 +60,14 @@ class FlatAdam:
         self._own_grad: Optional[torch.Tensor] = None
         self.active: List[torch.nn.Parameter] = []
         self.offsets: List[int] = []
+        self._active_ids = frozenset()
+
+    # hyper-parameters live in param_groups[0] (one group: the reference builds Adam(model.parameters(), lr, weight_decay))
+    lr = property(lambda self: self.param_groups[0]['lr'], lambda self, v: self.param_groups[0].__setitem__('lr', v))
+    betas = property(lambda self: self.param_groups[0]['betas'], lambda self, v: self.param_groups[0].__setitem__('betas', tuple(v)))
+    eps = property(lambda self: self.param_groups[0]['eps'], lambda self, v: self.param_groups[0].__setitem__('eps', v))
+    weight_decay = property(lambda self: self.param_groups[0]['weight_decay'],
+                            lambda self, v: self.param_groups[0].__setitem__('weight_decay', v))
 
     @staticmethod
     def _shared_offsets(params) -> Optional[List[int]]:
@@ -79,7 +91,9 @@ class FlatAdam:
             pos += params[i].numel()
         return offs
 
-    def _build(self):
+    def _build(self, carry=None):
+        """Lay the parameters that have gradients out in one bucket.  `carry`: (old active list, old offsets, exp_avg,
+        exp_avg_sq) of a previous layout whose moments are kept for the parameters that stay."""
         self.active = [p for p in self.params if p.grad is not None]
         if not self.active:
             raise RuntimeError("FlatAdam.step() before any backward()")
@@ -102,6 +116,17 @@ class FlatAdam:
             p.data = self.bucket[off:off + k].view_as(p)
         self.exp_avg = torch.zeros_like(self.bucket)
         self.exp_avg_sq = torch.zeros_like(self.bucket)
+        if carry is not None:
+            old_active, old_offsets, old_m, old_v = carry
+            where = {id(p): off for p, off in zip(old_active, old_offsets)}
+            for p, off in zip(self.active, self.offsets):
+                o = where.get(id(p))
+                if o is not None:
+                    k = p.numel()
+                    self.exp_avg[off:off + k].copy_(old_m[o:o + k])
+                    self.exp_avg_sq[off:off + k].copy_(old_v[o:o + k])
+        self._own_grad = None
+        self._active_ids = frozenset(id(p) for p in self.active)
         self.grad_bucket = self._flat_grad()
 
     def _flat_grad(self) -> torch.Tensor:
@@ -118,11 +143,42 @@ class FlatAdam:
             self._own_grad = torch.zeros_like(self.bucket)
         for p, off in zip(self.active, self.offsets):
             dst = self._own_grad[off:off + p.numel()]
-            if p.grad is None:
-                dst.zero_()
-            else:
-                dst.copy_(p.grad.reshape(-1))
+            dst.copy_(p.grad.reshape(-1))
         return self._own_grad
+
+    def state_dict(self) -> dict:
+        """Checkpointable state (the reference keeps none: `src/run_GNN.py:140-152` tracks the model only): step count,
+        both moments and the bucket layout by position in the constructor's parameter list."""
+        if self.capturable and self._dev_state is not None:
+            self.step_count = int(self._dev_state[0].item())
+        index = {id(p): k for k, p in enumerate(self.params)}
+        return {'step': self.step_count,
+                'param_groups': [{k: v for k, v in self.param_groups[0].items() if k != 'params'}],
+                'active': [index[id(p)] for p in self.active], 'offsets': list(self.offsets),
+                'exp_avg': None if self.bucket is None else self.exp_avg.detach().clone(),
+                'exp_avg_sq': None if self.bucket is None else self.exp_avg_sq.detach().clone()}
+
+    def load_state_dict(self, state: dict):
+        self.param_groups[0].update(state['param_groups'][0])
+        self.step_count = int(state['step'])
+        if state['exp_avg'] is None:
+            return
+        want = [self.params[k] for k in state['active']]
+        dev = want[0].device
+        # lay the bucket out exactly as it was saved; the parameters' current values move into it
+        self.active, self.offsets = want, list(state['offsets'])
+        n = sum(p.numel() for p in want)
+        self.bucket = torch.empty(n, device=dev, dtype=torch.float32)
+        for p, off in zip(self.active, self.offsets):
+            k = p.numel()
+            self.bucket[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.bucket[off:off + k].view_as(p)
+        self.exp_avg = state['exp_avg'].to(dev, torch.float32).clone()
+        self.exp_avg_sq = state['exp_avg_sq'].to(dev, torch.float32).clone()
+        self._own_grad, self.grad_bucket = None, None
+        self._active_ids = frozenset(id(p) for p in self.active)
+        if self.capturable:
+            self._dev_state = torch.tensor([self.step_count, 0], device=dev, dtype=torch.int32)
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -134,6 +190,8 @@ class FlatAdam:
     def all_reduce(self):
         """SUM over ranks on the flat bucket (one RCCL collective over xGMI)."""
         import torch.distributed as dist
+        if not self.data_parallel:
+            return 1
         if self.group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             dist.all_reduce(self.grad_bucket, op=dist.ReduceOp.SUM, group=self.group)
             return dist.get_world_size(self.group)
@@ -142,8 +200,28 @@ class FlatAdam:
     def step(self):
         if self.bucket is None:
             self._build()
+        elif torch.cuda.is_current_stream_capturing() if torch.cuda.is_available() else False:
+            self.grad_bucket = self._flat_grad()           # a captured step replays one fixed layout
         else:
-            self.grad_bucket = self._flat_grad()
+            have = frozenset(id(p) for p in self.params if p.grad is not None)
+            if have != self._active_ids:
+                # The set of parameters with gradients changed (a module unfrozen later, `steps` / temperature switched on,
+                # a parameter that got no gradient this time).  torch.optim.Adam updates exactly the parameters whose
+                # .grad is not None, each with its own step count; one flat bucket has ONE step count, so the layout is
+                # rebuilt for the new set (moments of the parameters that stay are kept) - loudly if that would give a
+                # newcomer the bias correction of an older step.
+                if not have:
+                    raise RuntimeError("FlatAdam.step(): no parameter has a gradient")
+                if self.capturable:
+                    raise RuntimeError("FlatAdam(capturable=True): the set of parameters with gradients changed after the "
+                                       "bucket was laid out; a captured step cannot follow it")
+                if self.step_count > 0 and not have <= self._active_ids:
+                    raise RuntimeError("FlatAdam: a parameter received its first gradient after step %d; one flat bucket "
+                                       "shares one step count (bias correction), so build a new optimizer for the new "
+                                       "parameter set" % self.step_count)
+                self._build(carry=(self.active, self.offsets, self.exp_avg, self.exp_avg_sq))
+            else:
+                self.grad_bucket = self._flat_grad()
         world = self.all_reduce()
         scale = 1.0 / world if self.reduce_op == 'mean' else 1.0       # 'sum' for the modular pseudo-loss (run_GNN.py:118)
         self.step_count += 1

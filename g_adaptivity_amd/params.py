@@ -45,7 +45,10 @@ def hot_path_opt(**overrides) -> dict:
         'loss_fn': 'mse',
         'lr': 0.001, 'decay': 0.0,
         'device': 'cpu',
-        'show_mesh_evol_plots': False,      # bool => conv stores stored_ei/stored_alpha (GRAND_plus.py:253)
+        # params.py:298 declares the string "True"; the pipeline's tf_sweep_args (params.py:172-177, run_pipeline.py:96-100)
+        # turns it into the bool True before any model is built, and a bool makes GRAND_plusConv keep
+        # stored_ei / stored_alpha (GRAND_plus.py:253).  Pass the string 'False' (or any non-bool) to skip that.
+        'show_mesh_evol_plots': True,
         # not a reference key: False materialises the zero-padded encoder output, the full last-layer output and the padded
         # top gradient (the literal GNN.py:270,299 data flow) instead of their compact forms
         'compact_slots': True,

@@ -108,6 +108,14 @@ int gadapt_encode_features(const float* x_comp, int dim, const float* f_tensor /
                            const float* uu_tensor /*nullable*/, const float* w, const float* b /*nullable*/,
                            float* x0, int64_t n_nodes, int c, void* stream);
 
+/* gadapt_encode_features and gadapt_coeffs_forward (of ONE conv: the weight-shared layer of GNN.py:131-140) in a single
+ * launch: both precede layer 0 and are independent of each other.  c = encoder output width, c_conv = conv width. */
+int gadapt_encode_features_coeffs(const float* x_comp, int dim, const float* f_tensor /*nullable*/,
+                                  const float* uu_tensor /*nullable*/, const float* w, const float* b /*nullable*/,
+                                  float* x0, int64_t n_nodes, int c,
+                                  const float* wq, const float* bq, const float* wk, float* a_out, float* p0_out, int c_conv,
+                                  void* stream);
+
 /* ------------------------------------------------------------------ one layer
  * layer_params (device, 2 floats): {dt, score_scale} with score_scale = 1/(sqrt(C)*T).
  * alpha_out (nullable) [E] in target order.  x_out must not alias x_in.
@@ -140,6 +148,12 @@ int gadapt_layer_backward(const gadapt_graph* g, const float* x_in, const float*
 
 /* slab [n_rows][C*C+C] -> d_a [C*C], d_p0 [C].  scratch: 32*(C*C+C) floats. */
 int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch, float* d_a, float* d_p0, int c, void* stream);
+
+/* gadapt_slab_reduce followed by gadapt_coeffs_backward in two launches instead of three: the second-level sums and the
+ * chain rule share a kernel (d_a / d_p0 only ever exist in LDS).  Same results bit for bit. */
+int gadapt_slab_reduce_coeffs_backward(const float* slab, int n_rows, float* scratch,
+                                       const float* wq, const float* bq, const float* wk,
+                                       float* d_wq, float* d_bq, float* d_wk, float* d_bk, int c, void* stream);
 
 /* ------------------------------------------------------------------ L-step Euler block
  * The loop of GNN.py:273-291 with weight sharing (GNN.py:131-141): x_all is

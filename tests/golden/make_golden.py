@@ -5,7 +5,8 @@ The reference has no fixtures for this path and cannot be imported here (SURVEY.
 vectors pin the oracle against regressions and give the GPU tests a reference that does not need the
 oracle at run time; they do not pin the oracle to the reference (parity unpinned).
 
-    python tests/golden/make_golden.py        # rewrites G1/G2/G3 .npz (fp32 run + fp64 twin)
+    python tests/golden/make_golden.py            # rewrites every G*.npz (fp32 run + fp64 twin)
+    python tests/golden/make_golden.py G4 G5      # only the named cases
 """
 import os
 import sys
@@ -20,11 +21,15 @@ from g_adaptivity_amd import MeshDataset, collate, hot_path_opt          # noqa:
 from oracle.pyg_restatement import OracleGNN, masked_edge_index           # noqa: E402
 
 CASES = {
-    # name: mesh_dims, batch, hidden, layers, conv_type   
-    'G1_1d_n32_b8_GRAND_L1_C8': ((32,), 8, 8, 1, 'GRAND'),
-    'G2_2d_n11_b2_GRANDplus_L4_C8': ((11, 11), 2, 8, 4, 'GRAND_plus'),
-    'G3_2d_n32_b2_GRANDplus_L4_C64': ((32, 32), 2, 64, 4, 'GRAND_plus'),
+    # name: mesh_dims, batch, hidden, layers, conv_type, opt overrides   (G4/G5 = the shapes of
+    # BASELINE.json configs 4 and 5 at one mesh per batch)
+    'G1_1d_n32_b8_GRAND_L1_C8': ((32,), 8, 8, 1, 'GRAND', {}),
+    'G2_2d_n11_b2_GRANDplus_L4_C8': ((11, 11), 2, 8, 4, 'GRAND_plus', {}),
+    'G3_2d_n32_b2_GRANDplus_L4_C64': ((32, 32), 2, 64, 4, 'GRAND_plus', {}),
+    'G4_2d_n64_b1_GRAND_L6_C128_xyuu': ((64, 64), 1, 128, 6, 'GRAND', {'gnn_inc_feat_f': False}),   # params.py:148,155 features
+    'G5_2d_n128_b1_GRANDplus_L20_C64': ((128, 128), 1, 64, 20, 'GRAND_plus', {}),
 }
+ONLY = [a for a in sys.argv[1:]]
 
 
 def run(dtype, ds, data, opt, state):
@@ -42,8 +47,10 @@ def run(dtype, ds, data, opt, state):
                 d_wk=lay.lin_key.weight.grad.numpy(), d_bk=lay.lin_key.bias.grad.numpy()), ei
 
 
-for name, (mesh_dims, batch, hidden, layers, conv) in CASES.items():
-    opt = hot_path_opt(mesh_dims=list(mesh_dims), hidden_dim=hidden, num_layers=layers, conv_type=conv)
+for name, (mesh_dims, batch, hidden, layers, conv, over) in CASES.items():
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        continue
+    opt = hot_path_opt(mesh_dims=list(mesh_dims), hidden_dim=hidden, num_layers=layers, conv_type=conv, **over)
     ds = MeshDataset(mesh_dims, batch, seed=0)
     data = collate(ds.samples)
     torch.manual_seed(0)
@@ -54,7 +61,8 @@ for name, (mesh_dims, batch, hidden, layers, conv) in CASES.items():
     np.savez_compressed(
         os.path.join(HERE, name + '.npz'),
         mesh_dims=np.array(mesh_dims), batch=batch, hidden=hidden, layers=layers, conv_type=conv,
-        edge_index=ei.numpy(), x_comp=data.x_comp.numpy(), f=data.f_tensor.numpy(), uu=data.uu_tensor.numpy(),
+        inc_f=int(bool(opt['gnn_inc_feat_f'])), inc_uu=int(bool(opt['gnn_inc_feat_uu'])),
+        edge_index=ei.numpy().astype(np.int32), x_comp=data.x_comp.numpy(), f=data.f_tensor.numpy(), uu=data.uu_tensor.numpy(),
         target=data.x_phys.numpy(),
         wq=state[lay + 'lin_query.weight'].numpy(), bq=state[lay + 'lin_query.bias'].numpy(),
         wk=state[lay + 'lin_key.weight'].numpy(), bk=state[lay + 'lin_key.bias'].numpy(),

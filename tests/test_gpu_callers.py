@@ -1,0 +1,178 @@
+"""GPU tests of the callers either side of the path: device-resident collation, the graph
+cache's content key, optimizer state, and the two-rank data-parallel step on real launches (pytest -m gpu)."""
+import copy
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from g_adaptivity_amd import DeviceMeshLoader, GNN, MeshDataset, MeshLoader, collate, hot_path_opt, mse_loss
+from g_adaptivity_amd.optim import FlatAdam
+from helpers import hip_model_like, make_case, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_device_mesh_loader_equals_host_collation(gpu_device):
+    """`DeviceMeshLoader` batches == `collate(...).to(device)` field by field, the model gives bit-identical output on
+    both, and every batch of the epoch hits ONE cached CSR (topology tensors are shared, `src/data.py:290`)."""
+    ds = MeshDataset([14, 14], 10, seed=3)
+    opt = hot_path_opt(mesh_dims=[14, 14], hidden_dim=64, num_layers=3, device=str(gpu_device), show_mesh_evol_plots='False')
+    torch.manual_seed(0)
+    model = GNN(ds, opt).to(gpu_device).eval()
+    host = list(MeshLoader(ds, batch_size=4, shuffle=False))
+    dev = list(DeviceMeshLoader(ds, batch_size=4, shuffle=False, device=gpu_device))
+    assert len(host) == len(dev) == 3
+    for h, d in zip(host, dev):
+        h = h.to(gpu_device)
+        for k in ('x_comp', 'x_phys', 'f_tensor', 'uu_tensor', 'u_true_tensor', 'edge_index', 'batch', 'to_boundary_edge_mask',
+                  'to_corner_nodes_mask', 'diff_boundary_edges_mask'):
+            assert torch.equal(getattr(h, k), getattr(d, k)), k
+            assert getattr(d, k).device == gpu_device
+        assert [list(map(int, c)) for c in h.corner_nodes] == [list(map(int, c)) for c in d.corner_nodes]
+        with torch.no_grad():
+            assert torch.equal(model(h), model(d))
+    # 2 topologies (batches of 4 and the ragged last batch of 2), each built once for host AND device batches alike
+    assert len(model._graphs) == 2
+    # a shuffled device epoch covers every sample once
+    seen = torch.cat([b.idx for b in DeviceMeshLoader(ds, batch_size=4, shuffle=True, device=gpu_device)]).sort().values
+    assert seen.tolist() == list(range(10))
+
+
+@pytest.mark.gpu
+def test_graph_cache_is_keyed_on_content(gpu_device):
+    """Batches with EQUAL node and edge counts but another edge order, another connectivity or other boundary masks each get
+    their own CSR and the oracle's answer, without anyone clearing the cache (the reference redoes the edge surgery every
+    forward, `src/GNN.py:206-218`); feeding a batch again reuses its graph."""
+    opt, ds, data, oracle = make_case((10, 10), 2, 16, 2)
+    model = hip_model_like(oracle, ds, opt, gpu_device).eval()
+
+    def both(d):
+        with torch.no_grad():
+            return model(d.clone().to(gpu_device)), oracle(d)
+
+    out_a, ref_a = both(data)
+    assert len(model._graphs) == 1 and rel_err(out_a, ref_a)[0] <= 1e-5
+    # (1) same edges, another order: same answer (up to fp32 reassociation), but its own cache entry
+    perm = torch.randperm(data.edge_index.shape[1], generator=torch.Generator().manual_seed(0))
+    d1 = data.clone()
+    d1.edge_index = data.edge_index[:, perm]
+    for k in ('to_boundary_edge_mask', 'to_corner_nodes_mask', 'diff_boundary_edges_mask'):
+        setattr(d1, k, getattr(data, k)[perm])
+    out_1, ref_1 = both(d1)
+    assert len(model._graphs) == 2 and rel_err(out_1, ref_1)[0] <= 1e-5 and rel_err(out_1, out_a)[0] <= 1e-5
+    # (2) same counts, another connectivity: one interior edge pair re-targeted (an "edge flip")
+    d2 = data.clone()
+    ei = d2.edge_index.clone()
+    free = (~(data.to_boundary_edge_mask | data.to_corner_nodes_mask | data.diff_boundary_edges_mask)).nonzero().flatten()
+    e = int(free[len(free) // 2])
+    old_src = int(ei[0, e])
+    ei[0, e] = old_src + 1 if old_src % 10 < 8 else old_src - 1        # another interior source for that target
+    d2.edge_index = ei
+    out_2, ref_2 = both(d2)
+    assert len(model._graphs) == 3 and rel_err(out_2, ref_2)[0] <= 1e-5
+    assert not torch.equal(out_2, out_a)                                # a stale CSR would have reproduced out_a
+    # (3) same edge list, other masks: fix one more edge (drop it from the diffusion)
+    d3 = data.clone()
+    m = d3.to_boundary_edge_mask.clone()
+    m[e] = True
+    d3.to_boundary_edge_mask = m
+    out_3, ref_3 = both(d3)
+    assert len(model._graphs) == 4 and rel_err(out_3, ref_3)[0] <= 1e-5 and not torch.equal(out_3, out_a)
+    # feeding a known batch again builds nothing
+    out_again, _ = both(data)
+    assert len(model._graphs) == 4 and torch.equal(out_again, out_a)
+    # a single un-collated sample (corner_nodes is one array, not a list) is handled without touching the caller's object
+    single = ds.samples[0].clone()
+    single.batch = torch.zeros(single.x_comp.shape[0], dtype=torch.int64)
+    kept = single.corner_nodes
+    with torch.no_grad():
+        out_s = model(single.clone().to(gpu_device))
+    one = collate([ds.samples[0]])
+    assert rel_err(out_s, oracle(one))[0] <= 1e-5 and single.corner_nodes is kept
+
+
+@pytest.mark.gpu
+def test_flat_adam_state_dict_param_groups_and_gradient_set_changes(gpu_device):
+    torch.manual_seed(0)
+
+    def make():
+        return [torch.nn.Parameter(torch.randn(32, 32, device=gpu_device)), torch.nn.Parameter(torch.randn(32, device=gpu_device)),
+                torch.nn.Parameter(torch.randn(5, device=gpu_device))]
+
+    ps = make()
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ours, ref = FlatAdam(ps, lr=1e-2, weight_decay=0.01), torch.optim.Adam(qs, lr=1e-2, weight_decay=0.01)
+    gens = torch.Generator(device=gpu_device).manual_seed(1)
+
+    def step(optim_a, params_a, optim_b, params_b, which=(0, 1)):
+        optim_a.zero_grad(); optim_b.zero_grad()
+        for k in which:
+            g = torch.randn(params_a[k].shape, device=gpu_device, generator=gens)
+            params_a[k].grad = g.clone(); params_b[k].grad = g.clone()
+        optim_a.step(); optim_b.step()
+
+    for _ in range(3):
+        step(ours, ps, ref, qs)
+    # LR schedulers write param_groups[0]['lr']
+    ours.param_groups[0]['lr'] = 5e-3; ref.param_groups[0]['lr'] = 5e-3
+    assert ours.lr == 5e-3
+    step(ours, ps, ref, qs)
+    for p, q in zip(ps, qs):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)
+    # checkpoint -> fresh optimizer over fresh parameter objects -> same trajectory as the uninterrupted pair
+    state = copy.deepcopy(ours.state_dict())
+    assert state['step'] == 4 and state['exp_avg'].numel() == 32 * 32 + 32
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    resumed = FlatAdam(ps2, lr=1.0)                                     # wrong lr on purpose: the state carries the right one
+    resumed.load_state_dict(state)
+    assert resumed.lr == 5e-3 and resumed.step_count == 4
+    for _ in range(2):
+        ours.zero_grad(); resumed.zero_grad(); ref.zero_grad()
+        for k in (0, 1):
+            g = torch.randn(ps[k].shape, device=gpu_device, generator=gens)
+            ps[k].grad = g.clone(); ps2[k].grad = g.clone(); qs[k].grad = g.clone()
+        ours.step(); resumed.step(); ref.step()
+    torch.cuda.synchronize()
+    for p, p2, q in zip(ps, ps2, qs):
+        assert torch.equal(p, p2)
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)
+    # a parameter that gets no gradient this time is skipped like torch.optim.Adam skips `grad is None` ...
+    before = ps[1].detach().clone()
+    step(ours, ps, ref, qs, which=(0,))
+    torch.cuda.synchronize()
+    assert torch.equal(ps[1], before) and torch.allclose(ps[0], qs[0], rtol=1e-5, atol=1e-6)
+    # ... and a parameter whose FIRST gradient arrives after steps were taken is refused loudly (one bucket = one step count)
+    with pytest.raises(RuntimeError, match="first gradient"):
+        step(ours, ps, ref, qs, which=(0, 2))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.gpu
+def test_two_rank_step_equals_full_batch_step(gpu_device):
+    """Two ranks (fresh child processes sharing the one GPU of the test box, gloo for the collective - RCCL needs a GPU
+    per rank) each run forward + backward on THEIR shard through the HIP kernels, all-reduce the flat gradient bucket and
+    take the fused Adam step; the result must equal the single-process step on the full batch (equal shards: the mean of
+    the shard means is the full-batch mean).  This executes `FlatAdam.step()` behind a real reduce."""
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GADAPT_DDP_CHECK_OUT=os.path.join(ROOT, 'gpurun_out'))
+    os.makedirs(env['GADAPT_DDP_CHECK_OUT'], exist_ok=True)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'tools', 'ddp_step_check.py')],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['world'] == 2 and d['bucket_floats'] == 2 * (64 * 64 + 64)
+    assert d['grad_rel_err'] <= 1e-5, d          # averaged shard gradients vs the full-batch gradient
+    assert d['param_max_abs_diff'] <= 1e-6, d    # after 3 Adam steps (lr 1e-3)
+    assert d['ranks_identical'] is True          # replicas stay bit-identical after the reduce

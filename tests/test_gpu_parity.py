@@ -27,6 +27,13 @@ CASES = [
     ((13, 13), 2, 64, 2, 'GRAND_plus', {'softmax_temp_type': 'fixed', 'softmax_temp': 2.0}),
     ((10, 10), 2, 64, 2, 'GRAND_plus', {'fix_boundary': False, 'self_loops': True}),   # in-degree 7 rows
     ((21,), 3, 8, 3, 'GRAND', {'gnn_inc_feat_f': False}),                               # Burgers features (params.py:148,155)
+    # BASELINE config 4 shape: 64x64, 6 layers, hidden 128, GRAND, features [x, y, uu] (two meshes: the oracle stays quick)
+    ((64, 64), 2, 128, 6, 'GRAND', {'gnn_inc_feat_f': False}),
+    # BASELINE config 5 shape: 128x128 mesh, 20 Euler steps, hidden 64 (one mesh): 128-node mesh rows exceed the LDS window,
+    # so this is the mesh-ordered NON-windowed tile path, and 20 layers of error growth in forward and backward
+    ((128, 128), 1, 64, 20, 'GRAND_plus', {}),
+    # BASELINE config 2 at its full batch (32 meshes 32x32, 4 layers, hidden 64)
+    ((32, 32), 32, 64, 4, 'GRAND_plus', {}),
 ]
 TRANS_CASES = [((11, 11), 2, 8, 3, 'relu'), ((14, 14), 3, 64, 2, 'tanh'), ((12, 12), 2, 32, 2, 'identity')]
 IDS = [f"{'x'.join(map(str, c[0]))}-b{c[1]}-C{c[2]}-L{c[3]}-{c[4]}" + ('-' + ','.join(c[5]) if c[5] else '') for c in CASES]
