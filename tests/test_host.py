@@ -83,7 +83,7 @@ def test_every_declared_symbol_is_exported():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/gadapt_hip.h but not exported"
     assert declared == set(_native.PROTOTYPES), declared ^ set(_native.PROTOTYPES)
-    assert _native.lib().gadapt_abi_version() == 2
+    assert _native.lib().gadapt_abi_version() == 3
     assert [c for c in (3, 4, 8, 16, 32, 64, 128, 256) if _native.lib().gadapt_supported_hidden_dim(c)] == [4, 8, 16, 32, 64, 128]
 
 
