@@ -52,6 +52,28 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GADAPT_FWD_ONE_WAVE 0
 #endif
 #define GADAPT_SLAB_CHUNKS 32   // second-level partials of the slab reduction
+// Softmax arithmetic: 1 = expf / IEEE division (<= 1 ulp each), 0 = v_exp_f32 of a rounded product and v_rcp_f32.
+// The approximate forms leave alpha with ~4x the rounding error of the reference's exp / true division; harmless for
+// the coordinates (2e-7 either way) but visible in parameter gradients that are the small remainder of large cancelling
+// sums (64x64, 6 layers, hidden 128: 3.4e-4 against the fp64 oracle with them, 1.4e-4 without, fp32 reference path 1.0e-4).
+// Cost of the exact forms: +0.6 us per forward launch (17.1 -> 17.7 us), nothing measurable elsewhere.
+#ifndef GADAPT_PRECISE_SOFTMAX
+#define GADAPT_PRECISE_SOFTMAX 1
+#endif
+__device__ __forceinline__ float sm_exp(float x) {
+#if GADAPT_PRECISE_SOFTMAX
+    return expf(x);
+#else
+    return __expf(x);
+#endif
+}
+__device__ __forceinline__ float sm_rcp(float x) {
+#if GADAPT_PRECISE_SOFTMAX
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // error reporting
@@ -895,10 +917,10 @@ __global__ __launch_bounds__(256, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_ONE_WAV
         float den = 0.f;
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
-            s[k] = __expf(s[k] - mx);                            // masked slots: exp(-inf) = 0
+            s[k] = sm_exp(s[k] - mx);                            // masked slots: exp(-inf) = 0
             den += s[k];
         }
-        const float inv = __builtin_amdgcn_rcpf(den + 1e-16f);  // PyG softmax epsilon
+        const float inv = sm_rcp(den + 1e-16f);                 // PyG softmax epsilon
         V m; m.zero();
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
@@ -930,12 +952,12 @@ __global__ __launch_bounds__(256, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_ONE_WAV
             mx = fmaxf(mx, group_sum<K::LPN>(vdot(Pi, ld_xsel<C, XC>(p.x_in, p.col[e0 + k], sub))) * sc);
         float den = 0.f;
         for (int k = 0; k < deg; ++k)
-            den += __expf(group_sum<K::LPN>(vdot(Pi, ld_xsel<C, XC>(p.x_in, p.col[e0 + k], sub))) * sc - mx);
+            den += sm_exp(group_sum<K::LPN>(vdot(Pi, ld_xsel<C, XC>(p.x_in, p.col[e0 + k], sub))) * sc - mx);
         const float inv = 1.0f / (den + 1e-16f);
         V m; m.zero();
         for (int k = 0; k < deg; ++k) {
             const V v = ld_xsel<C, XC>(p.x_in, p.col[e0 + k], sub);
-            const float a = __expf(group_sum<K::LPN>(vdot(Pi, v)) * sc - mx) * inv;
+            const float a = sm_exp(group_sum<K::LPN>(vdot(Pi, v)) * sc - mx) * inv;
             vaxpy(m, a, v);
             if (p.alpha_out && (k % K::LPN) == sub) p.alpha_out[e0 + k] = a;
         }
@@ -1839,22 +1861,27 @@ __global__ void slab_reduce2_kernel(const float* part, float* d_a, float* d_p0, 
 // workgroups hold bit-identical sums; 0.5 MB of L2-resident reads per workgroup at C = 64) and then produces its share
 // of the 2 C^2 + 2 C outputs.  dA rows are padded by one float: the dWk sum walks a column of dA^T.
 template <int C>
-__global__ __launch_bounds__(256) void reduce2_coeffs_bwd_kernel(const float* __restrict__ part, const float* __restrict__ wq,
-                                                                 const float* __restrict__ bq, const float* __restrict__ wk,
-                                                                 float* __restrict__ d_wq, float* __restrict__ d_bq,
-                                                                 float* __restrict__ d_wk, float* __restrict__ d_bk) {
+__global__ __launch_bounds__(1024) void reduce2_coeffs_bwd_kernel(const float* __restrict__ part, const float* __restrict__ wq,
+                                                                  const float* __restrict__ bq, const float* __restrict__ wk,
+                                                                  float* __restrict__ d_wq, float* __restrict__ d_bq,
+                                                                  float* __restrict__ d_wk, float* __restrict__ d_bk) {
     extern __shared__ float4 smem4[];
     float* da = reinterpret_cast<float*>(smem4);                 // [C][C+1]
     float* dp = da + C * (C + 1);                                // [C]
     constexpr int ROW = C * C + C, c2 = C * C;
-    for (int e = threadIdx.x; e < ROW; e += 256) {
+    // 1024 threads, the CHUNKS loads of an element all in flight: the sums are an L2 round trip per element and thread,
+    // not per load (a 256-thread version with an 8-wide unroll took 26.8 us at C = 64: 64 dependent round trips)
+    for (int e = threadIdx.x; e < ROW; e += 1024) {
+        float t[GADAPT_SLAB_CHUNKS];
+#pragma unroll
+        for (int k = 0; k < GADAPT_SLAB_CHUNKS; ++k) t[k] = part[(size_t)k * ROW + e];
         float v = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < GADAPT_SLAB_CHUNKS; ++k) v += part[(size_t)k * ROW + e];
+#pragma unroll
+        for (int k = 0; k < GADAPT_SLAB_CHUNKS; ++k) v += t[k];  // same order as slab_reduce2_kernel
         if (e < c2) da[(e / C) * (C + 1) + (e % C)] = v; else dp[e - c2] = v;
     }
     __syncthreads();
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * c2 + 2 * C; e += gridDim.x * 256) {
+    for (int e = blockIdx.x * 1024 + threadIdx.x; e < 2 * c2 + 2 * C; e += gridDim.x * 1024) {
         if (e < c2) {                       // d_wq[r][cc] = sum_o wk[r][o] dA[o][cc]
             const int r = e / C, cc = e % C;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -2258,10 +2285,10 @@ extern "C" int gadapt_slab_reduce_coeffs_backward(const float* slab, int n_rows,
     const int row_len = c * c + c;
     hipLaunchKernelGGL(slab_reduce1_kernel, dim3((row_len + 255) / 256, GADAPT_SLAB_CHUNKS), dim3(256), 0, st, slab, scratch, n_rows, row_len);
     const int lds = (c * (c + 1) + c) * 4;
-    int blocks = (2 * c * c + 2 * c + 255) / 256;
-    if (blocks > 32) blocks = 32;                               // every workgroup repeats the second-level sums
+    int blocks = (2 * c * c + 2 * c + 1023) / 1024;
+    if (blocks > 33) blocks = 33;                               // every workgroup repeats the second-level sums
 #define GADAPT_R2CB(CC) case CC: allow_lds(reduce2_coeffs_bwd_kernel<CC>, lds); \
-        hipLaunchKernelGGL(reduce2_coeffs_bwd_kernel<CC>, dim3(blocks), dim3(256), lds, st, scratch, wq, bq, wk, d_wq, d_bq, d_wk, d_bk); break;
+        hipLaunchKernelGGL(reduce2_coeffs_bwd_kernel<CC>, dim3(blocks), dim3(1024), lds, st, scratch, wq, bq, wk, d_wq, d_bq, d_wk, d_bk); break;
     switch (c) { GADAPT_R2CB(4) GADAPT_R2CB(8) GADAPT_R2CB(16) GADAPT_R2CB(32) GADAPT_R2CB(64) GADAPT_R2CB(128) default: break; }
 #undef GADAPT_R2CB
     return check_launch("slab_reduce_coeffs_backward");
