@@ -9,7 +9,7 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wall -Wno-u
 
 all: $(LIB)
 
-$(LIB): $(CSRC)/gadapt_kernels.hip $(CSRC)/gadapt_wide.inc $(CSRC)/csr_build.cpp include/gadapt_hip.h
+$(LIB): $(CSRC)/gadapt_kernels.hip $(CSRC)/gadapt_wide.inc $(CSRC)/gadapt_sparse.inc $(CSRC)/csr_build.cpp include/gadapt_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/gadapt_kernels.hip $(CSRC)/csr_build.cpp
 
 resources: $(CSRC)/gadapt_kernels.hip include/gadapt_hip.h

@@ -57,6 +57,16 @@ def algorithmic_bytes(kernel, n_nodes, n_edges, c, variant=0, dim=2):
 VARIANT_NAMES = {0: 'dense', 1: 'compact_g', 2: 'compact_x', 4: 'head_only_out', 6: 'compact_x+head_only_out'}
 
 
+def load_pmc(workload):
+    """Per-kernel counter summary of this workload from profiles/pmc.json (tools/profile_all.sh + tools/make_pmc_json.py:
+    separate rocprofv3 --pmc passes); {} when the file or the workload is missing."""
+    path = os.path.join(ROOT, 'profiles', 'pmc.json')
+    try:
+        return json.load(open(path)).get(workload, {})
+    except Exception:
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -236,13 +246,10 @@ def main():
                             key=lambda kv: kernels[kv[0]]['variants'][kv[1]]['avg_us'] * kernels[kv[0]]['variants'][kv[1]]['launches_per_step'])
             kd = kernels[dom]['variants'][dvar]
             traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')   # filled from separate rocprofv3 --pmc passes
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath)).get(args.workload, {})
-                    traffic = tj.get(f'{dom}:{dvar}', tj.get(dom))
-                except Exception:
-                    traffic = None
+            pmc = load_pmc(args.workload)                            # filled from separate rocprofv3 --pmc passes
+            ent = pmc.get(f'{dom}:{dvar}', pmc.get(dom))
+            if isinstance(ent, dict):
+                traffic = ent.get('traffic_bytes')
             roofline = {'kernel': dom, 'variant': dvar, 'bound': 'hbm', 'achieved': kd['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(kd['achieved_GBs'] / HBM_PEAK_GBS, 4), 'traffic': traffic,
                         'traffic_note': 'HBM-side bytes per launch of this kernel variant, (2 FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes',
@@ -256,17 +263,34 @@ def main():
         per_gpu = value / world
         gemm_flops_per_mesh = 12.0 * (w['n'] ** 2) * w['hidden'] ** 2 * w['layers']
         tf = gemm_flops_per_mesh * per_gpu / 1e12
+        # measured matrix-pipe utilisation per hot kernel (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD cycles of the launch, from the
+        # committed PMC passes) and its time-weighted mean over the hot kernels of a step
+        pmc = load_pmc(args.workload)
+        measured, wsum, tsum = {}, 0.0, 0.0
+        for kname, kd in kernels.items():
+            u = pmc.get(kname, {}).get('mfma_util') if isinstance(pmc.get(kname), dict) else None
+            if u is not None:
+                measured[kname] = u
+                t = kd['avg_us'] * kd['launches_per_step']
+                wsum, tsum = wsum + u * t, tsum + t
         roofline_mfma = {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
                          'flops_per_mesh': gemm_flops_per_mesh,
+                         'measured': {'matrix_pipe_busy_frac': measured,
+                                      'hot_kernels_time_weighted': round(wsum / tsum, 4) if tsum else None,
+                                      'source': 'profiles/pmc.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), '
+                                                'v_mfma_f32_32x32x16_bf16 = 32 busy cycles each'},
                          'note': 'algorithmic GEMM flops of the reference formulation x meshes/s per GPU; the kernels '
                                  'execute 8 N C^2 per layer (composite A = Wk^T Wq) on the bf16 matrix cores, 3-piece split'}
 
-    # ---- CPU baseline: the oracle on the host cores, same workload, bounded sample
+    # ---- CPU baseline: the oracle on the host cores, same workload, bounded sample.  A quarter of the batch per step (the
+    # cost is linear in the meshes), a short sweep over thread counts (index_add_ / scatter ops stop scaling early), then
+    # >= 10 timed steps at the best count.
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.pyg_restatement import OracleGNN
-        cdata = collate(ds.samples)
+        sub = max(1, w['batch'] // 4)
+        cdata = collate(ds.samples[:sub])
         ctarget = cdata.x_phys
         copt = dict(opt); copt['device'] = 'cpu'
         torch.manual_seed(0)
@@ -277,17 +301,34 @@ def main():
             oracle.zero_grad()
             F.mse_loss(oracle(cdata), ctarget).backward()
 
-        cpu_step()
-        t1 = time.perf_counter(); cpu_step(); one = time.perf_counter() - t1
-        iters = max(2, min(50, int(args.cpu_seconds / max(one, 1e-3))))
-        t1 = time.perf_counter()
-        for _ in range(iters):
-            cpu_step()
-        ct = time.perf_counter() - t1
-        cpu = {'value': round(w['batch'] * iters / ct, 2), 'unit': 'meshes/s', 'cores': torch.get_num_threads(),
-               'host_cpus': os.cpu_count(), 'kind': 'port',
-               'sample': f"{iters} fwd+bwd steps of the same {w['batch']}-mesh batch ({ct:.1f} s), CPU restatement of the "
-                         f"reference path (PyG-equivalent op sequence), no optimizer step"}
+        def timed(k):
+            t1 = time.perf_counter()
+            for _ in range(k):
+                cpu_step()
+            return (time.perf_counter() - t1) / k
+
+        default_threads = torch.get_num_threads()
+        cands = sorted({t for t in (8, 16, 32, 64, default_threads) if 1 <= t <= max(default_threads, 1)})
+        budget = max(args.cpu_seconds, 4.0)
+        sweep = {}
+        t_start = time.perf_counter()
+        for t in cands:
+            torch.set_num_threads(t)
+            cpu_step()                                                # warm-up at this thread count
+            sweep[t] = timed(1)
+            if time.perf_counter() - t_start > 0.45 * budget:
+                break
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        left = budget - (time.perf_counter() - t_start)
+        iters = max(10, min(60, int(left / max(sweep[best], 1e-3))))
+        per = timed(iters)
+        torch.set_num_threads(default_threads)
+        cpu = {'value': round(sub / per, 2), 'unit': 'meshes/s', 'cores': best, 'host_cpus': os.cpu_count(), 'kind': 'port',
+               'threads_sweep_meshes_per_s': {str(t): round(sub / v, 2) for t, v in sweep.items()},
+               'sample': f"{iters} fwd+bwd steps of a {sub}-mesh batch of the same workload ({iters * per:.1f} s) at {best} threads "
+                         f"(the best of {sorted(sweep)}), CPU restatement of the reference path (PyG-equivalent op sequence), "
+                         f"no optimizer step"}
 
     if rank == 0:
         line = {

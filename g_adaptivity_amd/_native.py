@@ -41,6 +41,12 @@ PROTOTYPES = {
     'gadapt_encode_features': (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _P]),
     'gadapt_encode_features_coeffs': (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _P]),
     'gadapt_slab_reduce_coeffs_backward': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'gadapt_spmm': (_I, [_G, _I, _P, _P, _P, _I, _F, _P]),
+    'gadapt_sddmm': (_I, [_G, _I, _P, _P, _P, _I, _F, _P]),
+    'gadapt_edge_softmax_forward': (_I, [_G, _P, _P, _P]),
+    'gadapt_edge_softmax_backward': (_I, [_G, _P, _P, _P, _P]),
+    'gadapt_edge_combine': (_I, [_G, _P, _P, _P, _I, _P]),
+    'gadapt_edge_rowsum': (_I, [_G, _I, _P, _P, _P]),
     'gadapt_loss_forward': (_I, [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P]),
     'gadapt_loss_scratch_floats': (_I, []),
     'gadapt_layer_forward': (_I, [_G, _P, _P, _P, _P, _P, _P, _I, _I, _P]),

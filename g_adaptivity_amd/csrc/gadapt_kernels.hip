@@ -2477,3 +2477,5 @@ extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, 
     }
     return GADAPT_OK;
 }
+
+#include "gadapt_sparse.inc"

@@ -183,6 +183,27 @@ int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols
                           float* g_ws, float* dxd_ws, float* edge_ws, float* slab,
                           float* d_layer_params, float* d_x0, int c, void* stream);
 
+/* ------------------------------------------------------------------ generic message-passing primitives
+ * What PyG's MessagePassing.propagate / utils.softmax do with index_select + scatter, per CSR row, for the conv variants
+ * besides GRAND / GRAND_plus that get_conv builds (GNN.py:108-124: GAT_plus GRAND_plus.py:386-416, GATConv, GCNConv), the
+ * reg_skew scores (GRAND_plus.py:280-324) and hidden sizes the fused kernels are not built for.  Per-edge arrays are in
+ * target-CSR order (like alpha_out).  transpose / by_source = 1 walks the source CSR (the transposed product a backward
+ * pass needs).  C must be a multiple of 4.  Rows are summed in the caller's edge order: bit-reproducible.
+ *   spmm:         out_i = sum_{e: j->i} w_e x_j (+ self_scale * x_i)      [transpose: out_j = sum_{e: j->i} w_e x_i]
+ *                 w = NULL means w_e = 1.
+ *   sddmm:        s_e = scale * <a_i, b_j> for e: j->i                    [transpose: scale * <a_j, b_i>]
+ *   edge_softmax: alpha_e = exp(s_e - max_i) / (sum_i exp(.) + 1e-16) over the in-edges of i (PyG utils.softmax);
+ *                 backward d_s_e = alpha_e (d_alpha_e - sum_i alpha d_alpha)
+ *   edge_combine: o_e = u_src[j] + v_dst[i] (op 0) or u_src[j] * v_dst[i] (op 1) for e: j->i
+ *   edge_rowsum:  r_i = sum of edge_vals over the in-edges of i           [by_source: over the out-edges of j]        */
+int gadapt_spmm(const gadapt_graph* g, int transpose, const float* w /*nullable*/, const float* x, float* out, int c,
+                float self_scale, void* stream);
+int gadapt_sddmm(const gadapt_graph* g, int transpose, const float* a, const float* b, float* out, int c, float scale, void* stream);
+int gadapt_edge_softmax_forward(const gadapt_graph* g, const float* scores, float* alpha, void* stream);
+int gadapt_edge_softmax_backward(const gadapt_graph* g, const float* alpha, const float* d_alpha, float* d_scores, void* stream);
+int gadapt_edge_combine(const gadapt_graph* g, const float* u_src, const float* v_dst, float* out, int op, void* stream);
+int gadapt_edge_rowsum(const gadapt_graph* g, int by_source, const float* edge_vals, float* out, void* stream);
+
 /* ------------------------------------------------------------------ loss seed
  * mesh_loss (run_GNN.py:80-84,106): loss = mean |x_phys - target|^p, p = 2 (mse) or 1 (l1),
  * x_phys = x_top[:, :d] (GNN.py:299).  Writes x_phys [N,d], g_top [N,C] (zero outside
