@@ -5,7 +5,7 @@ Public surface mirrors the reference modules:
     from g_adaptivity_amd import mse_loss, l1_loss          # the training loop's loss_fn, one launch each
 The arithmetic lives in `libgadapt_hip.so` (csrc/, C-ABI in include/gadapt_hip.h).
 """
-from .conv import GRAND_conv, GRAND_plusConv, TRANS_conv
+from .conv import GAT_conv, GAT_plus, GCN_conv, GRAND_conv, GRAND_plusConv, TRANS_conv
 from .functional import l1_loss, mse_loss
 from .gnn import GNN, build_conv_list, get_conv, get_dec, get_enc, get_mlp, get_nonlin
 from .graph import GraphCache, MeshGraph, prepare_edge_index
@@ -13,6 +13,6 @@ from .mesh_graph import DeviceMeshLoader, MeshData, MeshDataset, MeshLoader, col
 from .params import hot_path_opt
 
 __all__ = ['GNN', 'get_conv', 'build_conv_list', 'get_enc', 'get_dec', 'get_mlp', 'get_nonlin',
-           'GRAND_plusConv', 'GRAND_conv', 'TRANS_conv', 'MeshGraph', 'GraphCache', 'prepare_edge_index',
+           'GRAND_plusConv', 'GRAND_conv', 'TRANS_conv', 'GAT_plus', 'GAT_conv', 'GCN_conv', 'MeshGraph', 'GraphCache', 'prepare_edge_index',
            'MeshData', 'MeshDataset', 'MeshLoader', 'DeviceMeshLoader', 'collate', 'interval_mesh', 'square_mesh',
            'synthetic_batch', 'hot_path_opt', 'mse_loss', 'l1_loss']

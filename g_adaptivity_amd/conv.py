@@ -13,10 +13,13 @@ from __future__ import annotations
 import math
 from typing import Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from . import sparse_ops as Sp
+from ._native import SUPPORTED_HIDDEN
 from .graph import MeshGraph, graph_for
 
 
@@ -79,12 +82,20 @@ class _AttentionDiffusionBase(nn.Module):
         t = self._temperature()
         return s if t is None else s / t
 
-    def _residual(self, x, edge_index, graph: Optional[MeshGraph], want_alpha: bool):
+    def _residual(self, x, edge_index, graph: Optional[MeshGraph], want_alpha: bool, edge_weight: Optional[torch.Tensor] = None):
+        """A(x)x - x and the attention (target-CSR order).  The fused kernels carry the hidden sizes they are built for;
+        any other width, and scores with a per-edge factor (`reg_skew`), take the same arithmetic through the generic
+        primitives (Q/K projections as dense GEMMs, sddmm -> edge softmax -> spmm in HIP)."""
         if graph is None:
             graph = graph_for(edge_index, x.shape[0], x.device)
-        res, alpha_t = Fn.grand_residual(x, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
-                                         self.lin_key.bias, self._scale(x.device), graph, want_alpha)
-        return res, alpha_t, graph
+        if edge_weight is None and x.shape[1] in SUPPORTED_HIDDEN:
+            res, alpha_t = Fn.grand_residual(x, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
+                                             self.lin_key.bias, self._scale(x.device), graph, want_alpha)
+            return res, alpha_t, graph
+        q = torch.nn.functional.linear(x, self.lin_query.weight, self.lin_query.bias)      # GRAND_plus.py:225
+        k = torch.nn.functional.linear(x, self.lin_key.weight, self.lin_key.bias)          # GRAND_plus.py:226
+        m, alpha_t = Sp.attention_aggregate(graph, q, k, x, self._scale(x.device), edge_weight)
+        return m - x, alpha_t, graph
 
     def __repr__(self):
         return f'{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})'
@@ -106,9 +117,10 @@ class GRAND_plusConv(_AttentionDiffusionBase):
             # ones is the defined choice made here
             self.sm_temp_a = nn.Parameter(torch.ones(1, heads, 1))
         elif t == 'learnable_v':
-            raise NotImplementedError("softmax_temp_type='learnable_v' (src/GRAND_plus.py:158-160,330-331)")
-        if opt.get('reg_skew') and self.dim == 2:
-            raise NotImplementedError("reg_skew triangle-area weighting (src/GRAND_plus.py:280-324)")
+            # GRAND_plus.py:158-160: Linear(in_channels, heads, bias=False); the parameter exists (state_dict key
+            # `sm_temp_v.weight`), the forward cannot run - see forward()
+            self.sm_temp_v = nn.Linear(in_channels, heads, bias=False)
+        self._skew_cache = {}
 
     def _temperature(self):
         t = self.opt.get('softmax_temp_type')
@@ -122,9 +134,20 @@ class GRAND_plusConv(_AttentionDiffusionBase):
                 return_attention_weights=None, graph: Optional[MeshGraph] = None):
         assert edge_attr is None, "edge_attr needs lin_edge (edge_dim), which get_conv never builds"
         self.mesh_points, self.mesh = x, mesh                              # GRAND_plus.py:229-230
+        if self.opt.get('softmax_temp_type') == 'learnable_v':
+            # GRAND_plus.py:330-331 applies Linear(C, heads) to the [E, heads] score tensor and then .squeeze(2) a 2-D
+            # tensor: a shape error for every hidden size (C != 1: matmul shapes; C == 1: squeeze dim out of range).
+            # Same outcome here, said plainly.
+            raise RuntimeError(f"softmax_temp_type='learnable_v': sm_temp_v = Linear({self.in_channels}, {self.heads}) cannot be applied "
+                               f"to the [E, {self.heads}] attention scores (src/GRAND_plus.py:159,331) - the reference raises here too")
         store = isinstance(self.opt.get('show_mesh_evol_plots'), bool)     # GRAND_plus.py:253
         want_alpha = store or isinstance(return_attention_weights, bool)
-        res, alpha_t, graph = self._residual(x, edge_index, graph, want_alpha)
+        edge_weight = None
+        if self.opt.get('reg_skew') and self.dim == 2:                     # GRAND_plus.py:280-324
+            if graph is None:
+                graph = graph_for(edge_index, x.shape[0], x.device)
+            edge_weight = self._edge_area_sum(x, mesh, graph)
+        res, alpha_t, graph = self._residual(x, edge_index, graph, want_alpha, edge_weight)
         if store:
             self.stored_ei, self._stored = edge_index, (graph, alpha_t)
         if isinstance(return_attention_weights, bool):                     # GRAND_plus.py:259-262
@@ -134,6 +157,47 @@ class GRAND_plusConv(_AttentionDiffusionBase):
             key = torch.nn.functional.linear(x, self.lin_key.weight, self.lin_key.bias).view(-1, 1, c)
             return res, (edge_index, (alpha, query, key))
         return res
+
+
+    # ---- reg_skew: triangle-area weighted scores (GRAND_plus.py:280-324)
+    def _edge_area_sum(self, x, mesh, graph: MeshGraph) -> torch.Tensor:
+        """[E] in target-CSR order: for edge (a, b) the summed area of the triangles whose `cell_node_map` row [i,j,k] contains
+        it as (i,j), (j,k) or (k,i) - 1 or 2 hits, else 0 (the reference's if/elif chain, :310-322) - with the areas taken
+        from the first two columns of the layer's input (`self.mesh_points`, :229,283-288), differentiable.  The O(E*T)
+        Python matching loop of the reference (:310-322) is a one-time hash join per topology here."""
+        if mesh is None or not hasattr(mesh, 'coordinates'):
+            raise ValueError("reg_skew needs the mesh (its coordinates.cell_node_map().values), as in src/GRAND_plus.py:281")
+        cells = np.asarray(mesh.coordinates.cell_node_map().values).astype(np.int64)
+        key = (id(graph), cells.shape, int(cells.sum()), cells.tobytes()[:64])
+        ent = self._skew_cache.get(key)
+        if ent is None:
+            t = cells.shape[0]
+            table = {}
+            for col_a, col_b in ((0, 1), (1, 2), (2, 0)):              # tri_edges = [(i,j)] + [(j,k)] + [(k,i)], :295-299
+                for tri, (a, b) in enumerate(zip(cells[:, col_a].tolist(), cells[:, col_b].tolist())):
+                    table.setdefault((a, b), []).append(tri)
+            ei = graph.edge_index.detach().cpu()
+            t1 = np.full(ei.shape[1], -1, dtype=np.int64); t2 = np.full(ei.shape[1], -1, dtype=np.int64)
+            for e, (a, b) in enumerate(zip(ei[0].tolist(), ei[1].tolist())):
+                hits = table.get((a, b), ())
+                if len(hits) == 1:
+                    t1[e] = hits[0]
+                elif len(hits) == 2:
+                    t1[e], t2[e] = hits
+            order = graph.eid_t.long().cpu().numpy()                   # target-CSR slot -> caller's edge id
+            dev = x.device
+            ent = (graph, torch.from_numpy(cells).to(dev),
+                   torch.from_numpy(np.maximum(t1[order], 0)).to(dev), torch.from_numpy((t1[order] >= 0).astype(np.float32)).to(dev),
+                   torch.from_numpy(np.maximum(t2[order], 0)).to(dev), torch.from_numpy((t2[order] >= 0).astype(np.float32)).to(dev))
+            if len(self._skew_cache) > 4:
+                self._skew_cache.clear()
+            self._skew_cache[key] = ent
+        _, cells_d, i1, m1, i2, m2 = ent
+        px, py = x[:, 0], x[:, 1]
+        xa, xb, xc = px[cells_d[:, 0]], px[cells_d[:, 1]], px[cells_d[:, 2]]
+        ya, yb, yc = py[cells_d[:, 0]], py[cells_d[:, 1]], py[cells_d[:, 2]]
+        area = 0.5 * torch.abs(xa * (yb - yc) + xb * (yc - ya) + xc * (ya - yb))        # :288
+        return area[i1] * m1 + area[i2] * m2
 
 
 class GRAND_conv(_AttentionDiffusionBase):
@@ -190,3 +254,119 @@ class TRANS_conv(nn.Module):
 
     def __repr__(self):
         return f'{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads=1)'
+
+
+def _glorot_(t: torch.Tensor) -> torch.Tensor:
+    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))                 # torch_geometric.nn.inits.glorot
+    with torch.no_grad():
+        return t.uniform_(-a, a)
+
+
+class _GATBase(nn.Module):
+    """GATConv attention (PyG 2.4.0, heads=1, negative_slope=0.2, add_self_loops=True):
+    alpha_ij = softmax_j(leaky_relu(<att_src, h_j> + <att_dst, h_i>)) over the edges j->i of the self-looped graph.
+    Per-node sums and the leaky_relu are dense torch ops; gather / softmax / aggregation are the HIP primitives."""
+
+    def __init__(self, opt, in_channels, out_channels):
+        super().__init__()
+        if in_channels != out_channels:
+            raise NotImplementedError("get_conv builds in_dim == out_dim == hidden_dim (src/GNN.py:127-141)")
+        self.opt = opt
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, 1
+        self.negative_slope, self.add_self_loops = 0.2, True
+        self.att_src = nn.Parameter(_glorot_(torch.empty(1, 1, out_channels)))
+        self.att_dst = nn.Parameter(_glorot_(torch.empty(1, 1, out_channels)))
+        self.stored_ei = None
+        self._stored = None
+
+    @property
+    def stored_alpha(self):
+        if self._stored is None:
+            return None
+        graph, alpha_t = self._stored
+        return graph.alpha_to_edge_order(alpha_t).unsqueeze(-1)
+
+    @stored_alpha.setter
+    def stored_alpha(self, value):
+        self._stored = None if value is None else value
+
+    def _attention(self, h, edge_index, graph: Optional[MeshGraph]):
+        if graph is None:
+            graph = graph_for(edge_index, h.shape[0], h.device)
+        looped = graph.with_self_loops()
+        a_src = (h * self.att_src.view(1, -1)).sum(-1)
+        a_dst = (h * self.att_dst.view(1, -1)).sum(-1)
+        score = torch.nn.functional.leaky_relu(Sp.edge_add(looped, a_src, a_dst), self.negative_slope)
+        return looped, Sp.edge_softmax(looped, score)
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads=1)'
+
+
+class GAT_plus(_GATBase):
+    """`GAT_plus(opt, in, out)` (`src/GNN.py:120-121`, `src/GRAND_plus.py:386-416`): GATConv attention with identity source /
+    target maps; the conv's own output is discarded and the attention re-applied as a sparse matrix,
+    `Ax = sparse(alpha)^T x`; returns `Ax - x` (`gat_plus_type='GAT_res_lap'`) or `Ax` (`'GAT_lin'`).  Keeps
+    `stored_ei` (the self-looped edge list GATConv returns) and `stored_alpha`.  Parameters: att_src, att_dst (bias=False)."""
+
+    def __init__(self, opt, in_channels, out_channels, heads=1, concat=False, beta=False, dropout=0, edge_dim=None, bias=False,
+                 root_weight=False):
+        super().__init__(opt, in_channels, out_channels)
+        self.lin_src = nn.Identity()                                   # GRAND_plus.py:394-395
+        self.lin_dst = nn.Identity()
+
+    def forward(self, x, edge_index, graph: Optional[MeshGraph] = None):
+        kind = self.opt['gat_plus_type']
+        if kind not in ('GAT_res_lap', 'GAT_lin'):
+            # the reference's forward has no branch for the other declared choices (params.py:272) and returns None
+            raise NotImplementedError(f"gat_plus_type={kind!r}: src/GRAND_plus.py:400-416 implements 'GAT_res_lap' and 'GAT_lin' only")
+        looped, alpha_t = self._attention(x, edge_index, graph)
+        self.stored_ei, self._stored = looped.edge_index, (looped, alpha_t)
+        ax = Sp.spmm(looped, alpha_t, x)
+        return ax - x if kind == 'GAT_res_lap' else ax
+
+
+class GAT_conv(_GATBase):
+    """`get_conv(opt, 'GAT', in, out)` = PyG `GATConv(in, out, heads=1)` (`src/GNN.py:110-111`) with its defaults:
+    out_i = sum_j alpha_ij W x_j + bias.  PyG's parameter names: lin_src (= lin_dst), att_src, att_dst, bias."""
+
+    def __init__(self, opt, in_channels, out_channels, heads: int = 1):
+        if heads != 1:
+            raise NotImplementedError("get_conv builds heads=1 (src/GNN.py:111)")
+        super().__init__(opt, in_channels, out_channels)
+        self.lin_src = nn.Linear(in_channels, out_channels, bias=False)
+        _glorot_(self.lin_src.weight)
+        self.lin_dst = self.lin_src
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+    def forward(self, x, edge_index, graph: Optional[MeshGraph] = None):
+        h = self.lin_src(x)
+        looped, alpha_t = self._attention(h, edge_index, graph)
+        return Sp.spmm(looped, alpha_t, h) + self.bias
+
+
+class GCN_conv(nn.Module):
+    """`get_conv(opt, 'GCN', in, out)` = PyG `GCNConv(in, out)` (`src/GNN.py:109-110`): gcn_norm with
+    `add_remaining_self_loops`, out = D^-1/2 (A + I) D^-1/2 (x W^T) + bias, degrees by target.  Parameters `lin.weight`, `bias`."""
+
+    def __init__(self, opt, in_channels, out_channels):
+        super().__init__()
+        self.opt = opt
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        _glorot_(self.lin.weight)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+    def forward(self, x, edge_index, graph: Optional[MeshGraph] = None):
+        if graph is None:
+            graph = graph_for(edge_index, x.shape[0], x.device)
+        looped = graph.with_self_loops()
+        norm = getattr(looped, '_gcn_norm', None)
+        if norm is None:                                               # constant of the topology: once per graph
+            dis = Sp.in_degree(looped).pow(-0.5)
+            dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
+            norm = looped._gcn_norm = Sp.edge_mul(looped, dis, dis).detach()
+        return Sp.spmm(looped, norm, self.lin(x)) + self.bias
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({self.in_channels}, {self.out_channels})'

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as Fn
-from .conv import GRAND_conv, GRAND_plusConv, TRANS_conv
+from .conv import GAT_conv, GAT_plus, GCN_conv, GRAND_conv, GRAND_plusConv, TRANS_conv
 from .features import GlobalFeatureExtractorCNN, expand_to_nodes, field_to_grid
 from . import graph as _graph_mod
 from .graph import MeshGraph, prepare_edge_index
@@ -68,9 +68,12 @@ def get_conv(opt, conv_type, in_dim, out_dim, feat_dim=None):
                               dropout=0.0, edge_dim=None, bias=False, root_weight=False)
     if conv_type == 'TRANS':
         return TRANS_conv(opt, in_dim, out_dim, heads=1)                 # GNN.py:112-113
-    if conv_type in ('GCN', 'GAT', 'GAT_plus'):
-        raise NotImplementedError(f"conv_type={conv_type!r}: a later scope row (SURVEY.md §8(f) rank 3: different edge "
-                                  "scores); GRAND, GRAND_plus and TRANS are built")
+    if conv_type == 'GCN':
+        return GCN_conv(opt, in_dim, out_dim)                            # GNN.py:109-110
+    if conv_type == 'GAT':
+        return GAT_conv(opt, in_dim, out_dim, heads=1)                   # GNN.py:110-111
+    if conv_type == 'GAT_plus':
+        return GAT_plus(opt, in_dim, out_dim)                            # GNN.py:120-121
     raise NotImplementedError                                            # GNN.py:124
 
 
@@ -181,7 +184,9 @@ class GNN(nn.Module):
     def _fusable(self) -> bool:
         o = self.opt
         plain = o['conv_type'] == 'GRAND_plus' or (o['conv_type'] == 'GRAND' and o['non_lin'] == 'identity')   # GNN.py:284-286
-        return bool(o['residual']) and plain and not (self.training and o.get('dropout', 0.0) > 0)
+        native = o['hidden_dim'] in Fn._native.SUPPORTED_HIDDEN and not (o.get('reg_skew') and self.dim == 2) \
+            and o.get('softmax_temp_type') != 'learnable_v'
+        return bool(o['residual']) and plain and native and not (self.training and o.get('dropout', 0.0) > 0)
 
     # ------------------------------------------------------------------ forward
     def forward(self, data):
@@ -228,7 +233,8 @@ class GNN(nn.Module):
             feats = features()
             x = F.linear(feats, self.enc.weight, self.enc.bias) if isinstance(self.enc, nn.Linear) else self.enc(feats)
         elif isinstance(self.enc, nn.Linear) and not self.enc.weight.requires_grad and self.enc.bias is None:
-            native_in = all(t is None or (t.dtype == torch.float32 and t.dim() == 1) for t in (f, uu)) and x_comp.dtype == torch.float32
+            native_in = all(t is None or (t.dtype == torch.float32 and t.dim() == 1) for t in (f, uu)) and x_comp.dtype == torch.float32 \
+                and o['hidden_dim'] in Fn._native.SUPPORTED_HIDDEN         # the encoder kernel's row layouts; other widths: dense GEMM
             if fusable and not (self.training and o.get('dropout', 0.0) > 0):
                 # encoder output lands in slot 0 of the block's activation buffer: no copy
                 x_all = torch.empty(o['num_layers'] + 1, n, o['hidden_dim'], device=dev, dtype=torch.float32)
@@ -248,9 +254,12 @@ class GNN(nn.Module):
                 x = Fn.encode_features(x_comp, f, uu, self.enc.weight, out=out0, conv=conv_w if x_all is not None else None)
                 if conv_w is not None and x_all is not None:
                     x, coeffs = x
-            else:
+            elif o['hidden_dim'] in Fn._native.SUPPORTED_HIDDEN:
                 feats = features()
                 x = Fn.encode_linear(feats, self.enc.weight, out=out0)
+            else:
+                feats = features()
+                x = F.linear(feats, self.enc.weight)
         else:
             feats = features()
             x = self.enc(feats)

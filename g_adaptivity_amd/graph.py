@@ -175,6 +175,18 @@ class MeshGraph:
             m = self._has_in = (self.rowptr_t[1:] > self.rowptr_t[:-1]).to(torch.float32).unsqueeze(-1)
         return m
 
+    def with_self_loops(self) -> 'MeshGraph':
+        """The graph PyG's `remove_self_loops` + `add_self_loops` (GATConv's default) / `add_remaining_self_loops` (gcn_norm,
+        unweighted) make of this one: the non-loop edges in their order, then one loop per node 0..N-1.  Built once."""
+        g = getattr(self, '_looped', None)
+        if g is None:
+            ei = self.edge_index.detach().to('cpu', torch.int64)
+            ei = ei[:, ei[0] != ei[1]]
+            ar = torch.arange(self.num_nodes, dtype=torch.int64)
+            ei = torch.cat([ei, ar.unsqueeze(0).repeat(2, 1)], dim=1).contiguous()
+            g = self._looped = MeshGraph(ei.to(self.edge_index.device), self.num_nodes, self.device)
+        return g
+
     def alpha_to_edge_order(self, alpha_t: torch.Tensor) -> torch.Tensor:
         """[.., E] attention in target-CSR order -> the caller's edge order."""
         out = torch.empty_like(alpha_t)

@@ -235,6 +235,27 @@ def collate(samples: Sequence[MeshData]) -> MeshData:
     return out
 
 
+class _CellNodeMap:
+    def __init__(self, values):
+        self.values = values
+
+
+class _Coordinates:
+    def __init__(self, cells):
+        self._map = _CellNodeMap(cells)
+
+    def cell_node_map(self):
+        return self._map
+
+
+class MeshTopology:
+    """The part of a Firedrake mesh object the model reads: `mesh.coordinates.cell_node_map().values` -> [T,3] node ids
+    per triangle (`src/GRAND_plus.py:281`, used by `reg_skew` only)."""
+
+    def __init__(self, cells: np.ndarray):
+        self.coordinates = _Coordinates(np.asarray(cells))
+
+
 class MeshDataset:
     """In-memory list of samples over one shared mesh (`MeshInMemoryDataset` duck type).
 
@@ -255,7 +276,8 @@ class MeshDataset:
         self.x_comp_shared = base.x_comp
         self.num_x_comp_features = self.dim
         self.samples: List[MeshData] = [attach_random_fields(base, rng, num_gauss) for _ in range(num_data)]
-        self.mesh = None                                     # no Firedrake mesh object here
+        # no Firedrake mesh object here: a stand-in with the one attribute chain the model follows (2-D only)
+        self.mesh = MeshTopology(base.cells.numpy()) if self.dim == 2 else None
 
     def __len__(self):
         return len(self.samples)

@@ -28,9 +28,16 @@ What each function follows (paths under /root/reference):
 * `identity_encoder_weight`- `get_enc` identity branch (`src/GNN.py:75-90`).
 * `transformer_conv`       - PyG `TransformerConv(in, out, heads=1)` defaults, the
                              'TRANS' branch of `get_conv` (`src/GNN.py:112-113`).
+* `gat_attention` / `gat_conv` / `gat_plus` - PyG 2.4.0 `GATConv(in, out, heads=1)` (`src/GNN.py:110-111`) and the
+                             reference's `GAT_plus(GATConv)` with identity source / target maps
+                             (`src/GRAND_plus.py:386-416`): additive score leaky_relu(a_s.x_j + a_d.x_i, 0.2),
+                             `remove_self_loops` + `add_self_loops` (GATConv default), softmax by target.
+* `gcn_conv`               - PyG 2.4.0 `GCNConv(in, out)` (`src/GNN.py:109-110`): gcn_norm with
+                             `add_remaining_self_loops`, D^-1/2 (A+I) D^-1/2 (x W^T) + b.
+* `triangle_edge_area_sum` - the `reg_skew` weights of `src/GRAND_plus.py:280-324`.
 * `OracleGNN`              - `GNN.__init__/forward` (`src/GNN.py:144-306`) for
                              loss_type in {mesh_loss, modular}, enc='identity',
-                             conv_type in {GRAND_plus, GRAND, TRANS}.
+                             conv_type in {GRAND_plus, GRAND, TRANS, GAT_plus, GAT, GCN}.
 """
 from __future__ import annotations
 
@@ -55,7 +62,8 @@ def pyg_softmax(src: torch.Tensor, index: torch.Tensor, num_nodes: int) -> torch
 
 
 def grand_residual(x, edge_index, w_query, b_query, w_key, b_key,
-                   temperature: Optional[torch.Tensor | float] = None, return_attention: bool = False):
+                   temperature: Optional[torch.Tensor | float] = None, return_attention: bool = False,
+                   edge_area_sum: Optional[torch.Tensor] = None):
     """One diffusion residual  A(x)x - x  (`src/GRAND_plus.py:225-267`).
 
     x [N,C]; edge_index [2,E] int64, row 0 = source j, row 1 = target i.
@@ -69,6 +77,8 @@ def grand_residual(x, edge_index, w_query, b_query, w_key, b_key,
     key_j = key.index_select(0, src)                            #                     _j <- edge_index[0]
     value_j = value.index_select(0, src)
     alpha = (query_i * key_j).sum(dim=-1) / math.sqrt(c)        # :279
+    if edge_area_sum is not None:
+        alpha = alpha * edge_area_sum.unsqueeze(-1)             # reg_skew :324
     if temperature is not None:
         alpha = alpha / temperature                             # :35-37,:326-329
     alpha = pyg_softmax(alpha, dst, n)                          # :333
@@ -96,6 +106,80 @@ def transformer_conv(x, edge_index, w_query, b_query, w_key, b_key, w_value, b_v
     out = torch.zeros(n, 1, c, dtype=x.dtype, device=x.device).index_add_(0, dst, msg)
     out = out.view(-1, c)                                       # concat=True, heads=1
     return out + F.linear(x, w_skip, b_skip)                    # root_weight=True
+
+
+def triangle_edge_area_sum(mesh_points: torch.Tensor, cell_node_map, edge_index: torch.Tensor) -> torch.Tensor:
+    """`reg_skew` (`src/GRAND_plus.py:280-324`): per directed edge (a, b) of `edge_index`, the summed area of the
+    triangles that contain it in the orientation (i,j), (j,k), (k,i) of `cell_node_map` rows [i,j,k]; areas from the first
+    two columns of the CURRENT node features (`self.mesh_points = x`, `:229`), differentiable.  An edge with 0 hits (or
+    more than 2) gets 0, as the reference's if/elif chain leaves it (`:310-322`).  Literal O(E*T) matching, vectorised."""
+    cells = torch.as_tensor(cell_node_map, dtype=torch.long)
+    tri = mesh_points[cells]                                     # [T,3,C]  (:283)
+    xx, yy = tri[:, :, 0], tri[:, :, 1]
+    area = 0.5 * torch.abs(xx[:, 0] * (yy[:, 1] - yy[:, 2]) + xx[:, 1] * (yy[:, 2] - yy[:, 0]) + xx[:, 2] * (yy[:, 0] - yy[:, 1]))
+    i_idx, j_idx, k_idx = cells[:, 0], cells[:, 1], cells[:, 2]
+    tri_edges = torch.cat([torch.stack([i_idx, j_idx], 1), torch.stack([j_idx, k_idx], 1), torch.stack([k_idx, i_idx], 1)])   # [3T,2]
+    edge_areas = torch.cat([area, area, area])
+    out = torch.zeros(edge_index.shape[1], dtype=mesh_points.dtype)
+    hit = (tri_edges[None, :, 0] == edge_index[0][:, None]) & (tri_edges[None, :, 1] == edge_index[1][:, None])   # [E,3T]
+    count = hit.sum(1)
+    summed = (hit.to(mesh_points.dtype) * edge_areas[None, :]).sum(1)
+    return torch.where((count == 1) | (count == 2), summed, out)
+
+
+def gat_attention(a_src: torch.Tensor, a_dst: torch.Tensor, edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """`GATConv.edge_update`: alpha = softmax_i(leaky_relu(alpha_j + alpha_i, 0.2)); a_src / a_dst are the per-node
+    sums `(x * att).sum(-1)` [N,1]; edge_index already carries the self-loops."""
+    alpha = a_src.index_select(0, edge_index[0]) + a_dst.index_select(0, edge_index[1])
+    alpha = F.leaky_relu(alpha, 0.2)
+    return pyg_softmax(alpha, edge_index[1], num_nodes)
+
+
+def gat_conv(x, edge_index, w_lin, att_src, att_dst, bias):
+    """PyG 2.4.0 `GATConv(in, out, heads=1)` forward with its defaults (concat=True, negative_slope=0.2,
+    add_self_loops=True, bias=True); lin_src = lin_dst share `w_lin` for an int `in_channels`."""
+    n = x.shape[0]
+    h = F.linear(x, w_lin).view(n, 1, -1)                        # x_src = x_dst = lin_src(x)
+    a_src = (h * att_src).sum(-1)
+    a_dst = (h * att_dst).sum(-1)
+    ei = with_self_loops(edge_index, n)                          # remove_self_loops + add_self_loops
+    alpha = gat_attention(a_src, a_dst, ei, n)                   # [E',1]
+    msg = h.index_select(0, ei[0]) * alpha.unsqueeze(-1)
+    out = torch.zeros_like(h).index_add_(0, ei[1], msg).view(n, -1)
+    return out + bias, (ei, alpha)
+
+
+def gat_plus(x, edge_index, att_src, att_dst, kind: str = 'GAT_res_lap'):
+    """`GAT_plus.forward` (`src/GRAND_plus.py:400-416`): GATConv attention with identity lin_src / lin_dst; the conv's own
+    output is discarded, the attention is re-applied as a sparse matrix: `Ax = sparse(alpha)^T x`; returns Ax - x
+    ('GAT_res_lap') or Ax ('GAT_lin')."""
+    n = x.shape[0]
+    h = x.view(n, 1, -1)
+    a_src = (h * att_src).sum(-1)
+    a_dst = (h * att_dst).sum(-1)
+    ei = with_self_loops(edge_index, n)
+    alpha = gat_attention(a_src, a_dst, ei, n)
+    ax = torch.zeros_like(x).index_add_(0, ei[1], x.index_select(0, ei[0]) * alpha)   # (sparse_alpha.T @ x)_i = sum_j alpha_ij x_j
+    if kind == 'GAT_res_lap':
+        return ax - x, (ei, alpha)
+    if kind == 'GAT_lin':
+        return ax, (ei, alpha)
+    raise NotImplementedError(kind)
+
+
+def gcn_conv(x, edge_index, w_lin, bias):
+    """PyG 2.4.0 `GCNConv(in, out)`: `gcn_norm` (add_remaining_self_loops, fill 1; deg by target; D^-1/2 A D^-1/2),
+    `x = lin(x)`, sum-aggregate, `+ bias`."""
+    n = x.shape[0]
+    ei = with_self_loops(edge_index, n)                          # unweighted: add_remaining_self_loops == remove + add
+    w = torch.ones(ei.shape[1], dtype=x.dtype)
+    deg = torch.zeros(n, dtype=x.dtype).index_add_(0, ei[1], w)
+    dis = deg.pow(-0.5)
+    dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
+    norm = dis.index_select(0, ei[0]) * w * dis.index_select(0, ei[1])
+    h = F.linear(x, w_lin)
+    out = torch.zeros_like(h).index_add_(0, ei[1], h.index_select(0, ei[0]) * norm.unsqueeze(-1))
+    return out + bias
 
 
 def with_self_loops(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
@@ -179,6 +263,45 @@ class _QK(nn.Module):
         self.lin_skip = nn.Linear(c, c, bias=False)           # allocated, never used (root_weight=False)
 
 
+def _glorot_(t: torch.Tensor) -> torch.Tensor:
+    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))              # torch_geometric.nn.inits.glorot
+    with torch.no_grad():
+        return t.uniform_(-a, a)
+
+
+class _GATPlusHolder(nn.Module):
+    """Parameters of `GAT_plus(GATConv)` (`src/GRAND_plus.py:386-398`): att_src / att_dst [1,1,C]; lin_src / lin_dst are
+    replaced by Identity, bias=False."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.att_src = nn.Parameter(_glorot_(torch.empty(1, 1, c)))
+        self.att_dst = nn.Parameter(_glorot_(torch.empty(1, 1, c)))
+
+
+class _GATHolder(nn.Module):
+    """PyG `GATConv(c, c, heads=1)` parameter names: lin_src (== lin_dst), att_src, att_dst, bias."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.lin_src = nn.Linear(c, c, bias=False)
+        _glorot_(self.lin_src.weight)
+        self.lin_dst = self.lin_src
+        self.att_src = nn.Parameter(_glorot_(torch.empty(1, 1, c)))
+        self.att_dst = nn.Parameter(_glorot_(torch.empty(1, 1, c)))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class _GCNHolder(nn.Module):
+    """PyG `GCNConv(c, c)` parameter names: lin.weight (glorot), bias (zeros)."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.lin = nn.Linear(c, c, bias=False)
+        _glorot_(self.lin.weight)
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
 class _GlobalCNN(nn.Module):
     """`GlobalFeatureExtractorCNN` (`src/feature_extractors.py:6-34`): 3x3 convs + SELU, global average pool."""
 
@@ -223,8 +346,8 @@ class OracleGNN(nn.Module):
             if opt.get(flag):
                 in_dim += opt['global_feat_dim']
                 setattr(self, name, _GlobalCNN(1, c, opt['global_feat_dim'], dim=self.dim))
-        assert opt['enc'] == 'identity' and opt['conv_type'] in ('GRAND', 'GRAND_plus', 'TRANS')
-        _QK_ = _QKVS if opt['conv_type'] == 'TRANS' else _QK
+        assert opt['enc'] == 'identity' and opt['conv_type'] in ('GRAND', 'GRAND_plus', 'TRANS', 'GAT_plus', 'GAT', 'GCN')
+        _QK_ = {'TRANS': _QKVS, 'GAT_plus': _GATPlusHolder, 'GAT': _GATHolder, 'GCN': _GCNHolder}.get(opt['conv_type'], _QK)
         self.enc = nn.Linear(in_dim, c, bias=False)
         self.enc.weight.data = identity_encoder_weight(in_dim, c)
         self.enc.weight.requires_grad = False
@@ -267,10 +390,19 @@ class OracleGNN(nn.Module):
                                        layer.lin_key.bias, layer.lin_value.weight, layer.lin_value.bias,
                                        layer.lin_skip.weight, layer.lin_skip.bias)
                 alpha = None
+            elif opt['conv_type'] == 'GAT_plus':                                           # GNN.py:120-121, GRAND_plus.py:400-416
+                res, (_, alpha) = gat_plus(x, edge_index, layer.att_src, layer.att_dst, opt.get('gat_plus_type', 'GAT_res_lap'))
+            elif opt['conv_type'] == 'GAT':                                                # GNN.py:110-111
+                res, (_, alpha) = gat_conv(x, edge_index, layer.lin_src.weight, layer.att_src, layer.att_dst, layer.bias)
+            elif opt['conv_type'] == 'GCN':                                                # GNN.py:109-110
+                res, alpha = gcn_conv(x, edge_index, layer.lin.weight, layer.bias), None
             else:
+                area = None
+                if opt.get('reg_skew') and self.dim == 2:                                  # GRAND_plus.py:280-324
+                    area = triangle_edge_area_sum(x, self.dataset.mesh.coordinates.cell_node_map().values, edge_index)
                 res, (alpha, _, _) = grand_residual(x, edge_index, layer.lin_query.weight, layer.lin_query.bias,
                                                     layer.lin_key.weight, layer.lin_key.bias,
-                                                    self.temperature(), return_attention=True)
+                                                    self.temperature(), return_attention=True, edge_area_sum=area)
             if not (opt['residual'] and opt['conv_type'] == 'GRAND_plus'):
                 res = F.dropout(res, opt.get('dropout', 0.0), training=self.training)      # :285 / :295
                 res = _NONLIN[opt['non_lin']](res)                                         # :286 / :296

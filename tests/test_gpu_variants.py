@@ -1,0 +1,179 @@
+"""GPU tests of the generic message-passing primitives and of the conv variants built on them (pytest -m gpu):
+`GAT_plus`, `GAT`, `GCN` behind `get_conv` (`src/GNN.py:108-124`), `reg_skew`, `learnable_v`, hidden sizes the fused
+kernels are not built for.  Reference = the CPU oracle (gather / scatter restatement of the PyG op sequence)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from g_adaptivity_amd import GNN, MeshDataset, MeshGraph, collate, get_conv, hot_path_opt
+from g_adaptivity_amd import sparse_ops as Sp
+from helpers import hip_model_like, make_case, oracle_fp64_twin, rel_err
+from oracle.pyg_restatement import pyg_softmax
+
+COORD_TOL, GRAD_TOL = 1e-5, 1e-4
+
+
+def _graph(n, e, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g)])
+    ei = torch.cat([ei, torch.tensor([[7] * 30, list(range(30))]), torch.tensor([list(range(40, 80)), [9] * 40])], 1)   # hub out / hub in
+    ei = ei[:, ei[1] != 5]                                             # node 5: no in-edge
+    return ei, MeshGraph(ei, n, dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [3, 8, 64, 100, 260])
+def test_spmm_sddmm_forward_backward(gpu_device, C):
+    """spmm / sddmm and their transposed backward products against index_select + index_add_ on the CPU (fp64), rows of
+    0 / 1 / 40 entries, widths that are not a multiple of 4 and beyond one wave's 64 lanes x 4 floats."""
+    n = 300
+    ei, graph = _graph(n, 2000, 3, gpu_device)
+    e = ei.shape[1]
+    gen = torch.Generator().manual_seed(C)
+    w = torch.randn(e, generator=gen, dtype=torch.float64)
+    x, a = torch.randn(n, C, generator=gen, dtype=torch.float64), torch.randn(n, C, generator=gen, dtype=torch.float64)
+    up, upe = torch.randn(n, C, generator=gen, dtype=torch.float64), torch.randn(e, generator=gen, dtype=torch.float64)
+    order = graph.eid_t.long().cpu()                                   # target-CSR slot -> caller's edge id
+    # reference (caller's edge order)
+    wr, xr, ar = w.clone().requires_grad_(True), x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    out_ref = torch.zeros(n, C, dtype=torch.float64).index_add_(0, ei[1], wr[:, None] * xr.index_select(0, ei[0]))
+    s_ref = (ar.index_select(0, ei[1]) * xr.index_select(0, ei[0])).sum(-1)
+    ((out_ref * up).sum() + (s_ref * upe).sum()).backward()
+    # HIP (edge arrays in target-CSR order)
+    wh = w[order].float().to(gpu_device).requires_grad_(True)
+    xh, ah = x.float().to(gpu_device).requires_grad_(True), a.float().to(gpu_device).requires_grad_(True)
+    out = Sp.spmm(graph, wh, xh)
+    s = Sp.sddmm(graph, ah, xh)
+    ((out * up.float().to(gpu_device)).sum() + (s * upe[order].float().to(gpu_device)).sum()).backward()
+    torch.cuda.synchronize()
+    assert rel_err(out, out_ref)[0] <= 2e-6 and rel_err(s, s_ref[order])[0] <= 2e-6
+    assert rel_err(wh.grad, wr.grad[order])[0] <= 2e-6
+    assert rel_err(xh.grad, xr.grad)[0] <= 2e-6 and rel_err(ah.grad, ar.grad)[0] <= 2e-6
+    assert out[5].abs().max().item() == 0.0                            # empty row
+    plain = Sp.spmm(graph, None, xh.detach())                          # w = None: plain neighbour sum
+    assert rel_err(plain, torch.zeros(n, C, dtype=torch.float64).index_add_(0, ei[1], x.index_select(0, ei[0])))[0] <= 2e-6
+    assert torch.equal(Sp.spmm(graph, wh.detach(), xh.detach()), out.detach())   # bit-reproducible
+
+
+@pytest.mark.gpu
+def test_edge_softmax_and_edge_combine(gpu_device):
+    n = 300
+    ei, graph = _graph(n, 2000, 4, gpu_device)
+    e = ei.shape[1]
+    order = graph.eid_t.long().cpu()
+    gen = torch.Generator().manual_seed(0)
+    s = torch.randn(e, generator=gen, dtype=torch.float64) * 3
+    s[ei[1] == 9] += torch.linspace(-40, 40, int((ei[1] == 9).sum()), dtype=torch.float64)   # a long row with a wide score range
+    u, v = torch.randn(n, generator=gen, dtype=torch.float64), torch.randn(n, generator=gen, dtype=torch.float64)
+    up = torch.randn(e, generator=gen, dtype=torch.float64)
+    sr, ur, vr = s.clone().requires_grad_(True), u.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    a_ref = pyg_softmax(sr.unsqueeze(-1), ei[1], n).squeeze(-1)
+    add_ref = ur.index_select(0, ei[0]) + vr.index_select(0, ei[1])
+    mul_ref = ur.index_select(0, ei[0]) * vr.index_select(0, ei[1])
+    ((a_ref * up).sum() + (add_ref * up).sum() + (mul_ref * up * up).sum()).backward()
+    sh = s[order].float().to(gpu_device).requires_grad_(True)
+    uh, vh = u.float().to(gpu_device).requires_grad_(True), v.float().to(gpu_device).requires_grad_(True)
+    uph = up[order].float().to(gpu_device)
+    a = Sp.edge_softmax(graph, sh)
+    add, mul = Sp.edge_add(graph, uh, vh), Sp.edge_mul(graph, uh, vh)
+    ((a * uph).sum() + (add * uph).sum() + (mul * uph * uph).sum()).backward()
+    torch.cuda.synchronize()
+    assert rel_err(a, a_ref[order])[0] <= 2e-6 and rel_err(add, add_ref[order])[0] <= 1e-6 and rel_err(mul, mul_ref[order])[0] <= 1e-6
+    assert rel_err(sh.grad, sr.grad[order])[0] <= 5e-6
+    assert rel_err(uh.grad, ur.grad)[0] <= 5e-6 and rel_err(vh.grad, vr.grad)[0] <= 5e-6
+    rows = torch.zeros(n, device=gpu_device).index_add_(0, graph.edge_index[1].to(gpu_device), graph.alpha_to_edge_order(a.detach()))
+    has_in = torch.bincount(ei[1], minlength=n) > 0
+    assert (rows.cpu()[has_in] - 1).abs().max().item() <= 2e-6 and rows.cpu()[~has_in].abs().max().item() == 0.0
+
+
+def _model_parity(gpu_device, mesh_dims, batch, hidden, layers, conv_type, **extra):
+    opt, ds, data, oracle = make_case(mesh_dims, batch, hidden, layers, conv_type, **extra)
+    model = hip_model_like(oracle, ds, opt, gpu_device)
+    tgt = data.x_phys
+    ref = oracle(data)
+    F.mse_loss(ref, tgt).backward()
+    o64, ref64 = oracle_fp64_twin(oracle, ds, opt, data, tgt)
+    out = model(data.clone().to(gpu_device))
+    F.mse_loss(out, tgt.to(gpu_device)).backward()
+    torch.cuda.synchronize()
+    assert rel_err(out, ref)[0] <= COORD_TOL and rel_err(out, ref64)[0] <= COORD_TOL, (rel_err(out, ref), rel_err(out, ref64))
+    d32, d64 = dict(oracle.named_parameters()), dict(o64.named_parameters())
+    checked = []
+    for name, ph in model.named_parameters():
+        if name not in d64 or d64[name].grad is None:
+            assert ph.grad is None or name.endswith('lin_key.bias'), name
+            continue
+        if name.endswith('lin_key.bias'):
+            continue
+        e64, noise = rel_err(ph.grad, d64[name].grad)[0], rel_err(d32[name].grad, d64[name].grad)[0]
+        assert e64 <= max(GRAD_TOL, 1.5 * noise), f"{name}.grad vs fp64 oracle: {e64:.2e} (fp32 oracle: {noise:.2e})"
+        checked.append(name)
+    return model, oracle, checked
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,non_lin,share", [('GAT_res_lap', 'identity', True), ('GAT_res_lap', 'tanh', False), ('GAT_lin', 'relu', True)])
+def test_gat_plus_parity(gpu_device, kind, non_lin, share):
+    """`conv_type='GAT_plus'` (`src/GRAND_plus.py:386-416`): additive attention, default self-loops, A^T x - x."""
+    model, oracle, checked = _model_parity(gpu_device, (12, 12), 3, 16, 3, 'GAT_plus', gat_plus_type=kind, non_lin=non_lin, share_conv=share)
+    assert sorted(n.split('.')[-1] for n in checked if n.startswith('conv_layers.0.')) == ['att_dst', 'att_src']
+    layer = model.conv_layers[0]
+    n = 3 * 144
+    assert layer.stored_ei.shape[1] == layer.stored_alpha.shape[0] and layer.stored_alpha.shape[1] == 1
+    assert torch.equal(layer.stored_ei[:, -n:].cpu(), torch.arange(n).repeat(2, 1))      # add_self_loops appends one loop per node
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conv,hidden,non_lin", [('GAT', 16, 'relu'), ('GAT', 64, 'identity'), ('GCN', 8, 'tanh'), ('GCN', 64, 'relu')])
+def test_stock_gat_and_gcn_parity(gpu_device, conv, hidden, non_lin):
+    """`get_conv(opt, 'GAT' | 'GCN', ...)` = stock GATConv / GCNConv (`src/GNN.py:109-111`), layer by layer with non_lin and
+    the residual update (`src/GNN.py:284-291`); coordinates and every parameter gradient against the oracle."""
+    model, oracle, checked = _model_parity(gpu_device, (11, 11), 2, hidden, 3, conv, non_lin=non_lin)
+    want = {'GAT': ['att_dst', 'att_src', 'bias', 'weight'], 'GCN': ['bias', 'weight']}[conv]
+    assert sorted({n.split('.')[-1] for n in checked}) == want
+    keys = set(model.state_dict())
+    if conv == 'GAT':
+        assert {'conv_layers.0.lin_src.weight', 'conv_layers.0.lin_dst.weight', 'conv_layers.0.att_src', 'conv_layers.0.bias'} <= keys
+    else:
+        assert {'conv_layers.0.lin.weight', 'conv_layers.0.bias'} <= keys
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden", [12, 24, 200])
+def test_hidden_sizes_outside_the_fused_set(gpu_device, hidden):
+    """The reference accepts any hidden_dim; widths the fused kernels are not built for run the same arithmetic through the
+    generic primitives (GRAND_plus and GRAND)."""
+    for conv in ('GRAND_plus', 'GRAND'):
+        _model_parity(gpu_device, (10, 10), 2, hidden, 2, conv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 2])
+def test_reg_skew_parity(gpu_device, batch):
+    """`reg_skew` (`src/GRAND_plus.py:280-324`): scores times the summed area of the oriented triangles on the edge, areas from
+    the layer's own input (gradients flow through them).  `mesh` is the dataset's single mesh, so in a batch only the first
+    graph's edges find triangles and every other edge gets weight 0 - the reference's behaviour, reproduced."""
+    model, oracle, checked = _model_parity(gpu_device, (9, 9), batch, 16, 3, 'GRAND_plus', reg_skew=True)
+    assert any(n.endswith('lin_query.weight') for n in checked)
+    # it does change the result
+    opt, ds, data, plain = make_case((9, 9), batch, 16, 3, 'GRAND_plus', reg_skew=False)
+    plain.load_state_dict(oracle.state_dict())
+    with torch.no_grad():
+        assert (plain(data) - oracle(data)).abs().max().item() > 1e-7
+
+
+@pytest.mark.gpu
+def test_learnable_v_fails_as_in_the_reference(gpu_device):
+    """`softmax_temp_type='learnable_v'` (`src/GRAND_plus.py:158-160,330-331`) builds `sm_temp_v = Linear(C, heads)` and applies it
+    to the [E, heads] scores: a shape error in the reference for every hidden size.  Same here: the parameter exists (same
+    state_dict key), the forward raises."""
+    opt = hot_path_opt(mesh_dims=[9, 9], hidden_dim=16, num_layers=2, softmax_temp_type='learnable_v', device=str(gpu_device))
+    ds = MeshDataset([9, 9], 2, seed=0)
+    model = GNN(ds, opt).to(gpu_device)
+    assert 'conv_layers.0.sm_temp_v.weight' in model.state_dict() and model.state_dict()['conv_layers.0.sm_temp_v.weight'].shape == (1, 16)
+    with pytest.raises(RuntimeError, match="learnable_v"):
+        model(collate(ds.samples).to(gpu_device))
+    with pytest.raises(NotImplementedError):
+        get_conv(opt, 'Laplacian', 16, 16)                             # GNN.py:122-124

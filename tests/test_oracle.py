@@ -161,3 +161,79 @@ def test_transformer_conv_matches_dense_fp64():
     ref = A @ V + x @ W[3].T + b[3]
     assert (out - ref).abs().max().item() <= 1e-13
     assert torch.allclose(out[7], x[7] @ W[3].T + b[3], rtol=0, atol=1e-14)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# conv variants behind get_conv (src/GNN.py:108-124): dense fp64 cross-checks of the gather / scatter restatements
+# ---------------------------------------------------------------------------------------------------------------
+def _looped_dense(ei, n):
+    """[N,N] multiplicity matrix M[i,j] of edges j->i after remove_self_loops + add_self_loops."""
+    keep = ei[0] != ei[1]
+    m = torch.zeros(n, n, dtype=torch.float64)
+    m.index_put_((ei[1][keep], ei[0][keep]), torch.ones(int(keep.sum()), dtype=torch.float64), accumulate=True)
+    return m + torch.eye(n, dtype=torch.float64)
+
+
+def test_gat_conv_and_gat_plus_match_dense_fp64():
+    """GATConv (`src/GNN.py:110-111`) and GAT_plus (`src/GRAND_plus.py:386-416`): additive scores, leaky_relu(0.2), self-loops
+    replaced / added for every node, softmax by target - against the dense masked-softmax formulation."""
+    from oracle.pyg_restatement import gat_conv, gat_plus
+    torch.manual_seed(1)
+    n, c = 25, 8
+    ei = torch.unique(torch.stack([torch.randint(0, n, (90,)), torch.randint(0, n, (90,))]), dim=1)
+    ei = torch.cat([ei, torch.tensor([[3, 3], [3, 3]])], dim=1)          # an existing self-loop, twice: replaced by ONE loop
+    x = torch.randn(n, c, dtype=torch.float64)
+    w = torch.randn(c, c, dtype=torch.float64) * 0.4
+    a_s, a_d = torch.randn(1, 1, c, dtype=torch.float64), torch.randn(1, 1, c, dtype=torch.float64)
+    bias = torch.randn(c, dtype=torch.float64)
+    mult = _looped_dense(ei, n)
+
+    def dense(h):
+        s = torch.nn.functional.leaky_relu((h @ a_d.view(-1))[:, None] + (h @ a_s.view(-1))[None, :], 0.2)   # [i,j]
+        e = torch.where(mult > 0, torch.exp(s - torch.where(mult > 0, s, torch.full_like(s, -1e300)).max(1, keepdim=True).values), torch.zeros_like(s)) * mult
+        return e / (e.sum(1, keepdim=True) + 1e-16)
+
+    out, (ei2, alpha) = gat_conv(x, ei, w, a_s, a_d, bias)
+    h = x @ w.T
+    assert (out - (dense(h) @ h + bias)).abs().max().item() <= 1e-12
+    assert ei2.shape[1] == int((ei[0] != ei[1]).sum()) + n and torch.equal(ei2[:, -n:], torch.arange(n).repeat(2, 1))
+    res, _ = gat_plus(x, ei, a_s, a_d, 'GAT_res_lap')
+    lin, _ = gat_plus(x, ei, a_s, a_d, 'GAT_lin')
+    assert (res - (dense(x) @ x - x)).abs().max().item() <= 1e-12 and (lin - dense(x) @ x).abs().max().item() <= 1e-12
+
+
+def test_gcn_conv_matches_dense_fp64():
+    """GCNConv (`src/GNN.py:109-110`): D^-1/2 (A + I) D^-1/2 (x W^T) + b with degrees by target, multiplicities kept."""
+    from oracle.pyg_restatement import gcn_conv
+    torch.manual_seed(2)
+    n, c = 20, 6
+    ei = torch.stack([torch.randint(0, n, (70,)), torch.randint(0, n, (70,))])
+    x = torch.randn(n, c, dtype=torch.float64)
+    w, b = torch.randn(c, c, dtype=torch.float64), torch.randn(c, dtype=torch.float64)
+    mult = _looped_dense(ei, n)
+    dis = mult.sum(1).pow(-0.5)
+    ref = (dis[:, None] * mult * dis[None, :]) @ (x @ w.T) + b
+    assert (gcn_conv(x, ei, w, b) - ref).abs().max().item() <= 1e-12
+
+
+def test_triangle_edge_area_sum_matches_the_reference_loop():
+    """`reg_skew` weights (`src/GRAND_plus.py:280-324`): the vectorised restatement against the literal per-edge loop."""
+    from g_adaptivity_amd import square_mesh
+    from oracle.pyg_restatement import triangle_edge_area_sum
+    m = square_mesh(6)
+    torch.manual_seed(0)
+    pts = torch.cat([m.x_comp.double() + 0.02 * torch.randn(36, 2, dtype=torch.float64), torch.randn(36, 3, dtype=torch.float64)], 1)
+    cells = m.cells.numpy()
+    got = triangle_edge_area_sum(pts, cells, m.edge_index)
+    tri = pts[torch.from_numpy(cells)]
+    xx, yy = tri[:, :, 0], tri[:, :, 1]
+    area = 0.5 * torch.abs(xx[:, 0] * (yy[:, 1] - yy[:, 2]) + xx[:, 1] * (yy[:, 2] - yy[:, 0]) + xx[:, 2] * (yy[:, 0] - yy[:, 1]))
+    tri_edges = [(int(a), int(b)) for a, b in zip(cells[:, 0], cells[:, 1])] + [(int(a), int(b)) for a, b in zip(cells[:, 1], cells[:, 2])] + \
+                [(int(a), int(b)) for a, b in zip(cells[:, 2], cells[:, 0])]
+    want = torch.zeros(m.edge_index.shape[1], dtype=torch.float64)
+    for e, (a, b) in enumerate(m.edge_index.t().tolist()):
+        hits = [k for k, te in enumerate(tri_edges) if te == (a, b)]
+        if len(hits) in (1, 2):
+            want[e] = sum(area[k % len(cells)] for k in hits)
+    assert torch.allclose(got, want, rtol=0, atol=1e-15)
+    assert (want > 0).any() and (want == 0).any()                        # oriented matching: some directed edges get no triangle
