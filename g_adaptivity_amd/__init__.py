@@ -9,10 +9,11 @@ from .conv import GAT_conv, GAT_plus, GCN_conv, GRAND_conv, GRAND_plusConv, TRAN
 from .functional import l1_loss, mse_loss
 from .gnn import GNN, build_conv_list, get_conv, get_dec, get_enc, get_mlp, get_nonlin
 from .graph import GraphCache, MeshGraph, prepare_edge_index
-from .mesh_graph import DeviceMeshLoader, MeshData, MeshDataset, MeshLoader, collate, interval_mesh, square_mesh, synthetic_batch
+from .mesh_graph import (DeviceMeshLoader, MeshData, MeshDataset, MeshLoader, Mixed_DataLoader, MixedMeshDataset, collate, interval_mesh,
+                         square_mesh, synthetic_batch)
 from .params import hot_path_opt
 
 __all__ = ['GNN', 'get_conv', 'build_conv_list', 'get_enc', 'get_dec', 'get_mlp', 'get_nonlin',
            'GRAND_plusConv', 'GRAND_conv', 'TRANS_conv', 'GAT_plus', 'GAT_conv', 'GCN_conv', 'MeshGraph', 'GraphCache', 'prepare_edge_index',
-           'MeshData', 'MeshDataset', 'MeshLoader', 'DeviceMeshLoader', 'collate', 'interval_mesh', 'square_mesh',
+           'MeshData', 'MeshDataset', 'MeshLoader', 'DeviceMeshLoader', 'MixedMeshDataset', 'Mixed_DataLoader', 'collate', 'interval_mesh', 'square_mesh',
            'synthetic_batch', 'hot_path_opt', 'mse_loss', 'l1_loss']

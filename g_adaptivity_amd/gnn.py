@@ -216,7 +216,11 @@ class GNN(nn.Module):
                     field = getattr(data, name).to(dev).float()
                     if o.get('gnn_normalize'):
                         field = field / torch.max(field)
-                    grid = field_to_grid(field, mapping, self.mesh_dims, n_meshes, self.dim)
+                    dims = self.mesh_dims
+                    if o.get('data_type') == 'randg_mix' and self.dim == 2:
+                        side = int(np.sqrt(x_comp.shape[0]))               # GNN.py:247,261: one mesh per batch for this data type
+                        dims = [side, side]
+                    grid = field_to_grid(field, mapping, dims, n_meshes, self.dim)
                     glob.append(expand_to_nodes(getattr(self, extractor)(grid.unsqueeze(1)), batch))
 
         def features():                                                    # the concatenated matrix, only where a caller needs it
@@ -285,9 +289,12 @@ class GNN(nn.Module):
                 for l, layer in enumerate(self.conv_layers):
                     layer.stored_ei, layer._stored = graph.edge_index, (graph, alpha[l])
         else:
+            mesh = getattr(self.dataset, 'mesh', None)
+            if o.get('data_type') == 'randg_mix' and isinstance(getattr(data, 'mesh', None), (list, tuple)) and data.mesh:
+                mesh = data.mesh[-1]                                       # what the loop of GNN.py:277-281 leaves in `mesh`
             for i, layer in enumerate(self.conv_layers):                  # GNN.py:273-296, layer by layer
                 if o['residual'] and o['conv_type'] == 'GRAND_plus':
-                    res = layer(x, graph.edge_index, feats if feats is not None else features(), getattr(self.dataset, 'mesh', None), graph=graph)
+                    res = layer(x, graph.edge_index, feats if feats is not None else features(), mesh, graph=graph)
                 else:
                     res = layer(x, graph.edge_index, graph=graph)
                     res = self.non_lin(F.dropout(res, o.get('dropout', 0.0), training=self.training))

@@ -215,11 +215,11 @@ def attach_random_fields(mesh: MeshData, rng: np.random.Generator, num_gauss: in
 _EDGE_KEYS = ('to_boundary_edge_mask', 'to_corner_nodes_mask', 'diff_boundary_edges_mask')
 
 
-def collate(samples: Sequence[MeshData]) -> MeshData:
-    """PyG `Batch.from_data_list` rules for the keys the model reads."""
+def collate(samples: Sequence[MeshData], exclude_keys: Optional[Sequence[str]] = None) -> MeshData:
+    """PyG `Batch.from_data_list` rules for the keys the model reads (`exclude_keys`: attributes left out of the batch)."""
     out = MeshData()
     offsets = np.cumsum([0] + [s.num_nodes for s in samples])
-    keys = samples[0].keys()
+    keys = [k for k in samples[0].keys() if not (exclude_keys and k in exclude_keys)]
     for k in keys:
         vals = [getattr(s, k) for s in samples]
         if k == 'edge_index' or k == 'cells':
@@ -288,6 +288,60 @@ class MeshDataset:
             sub.samples = [self.samples[int(j)] for j in i]
             return sub
         return self.samples[i]
+
+
+class MixedMeshDataset(MeshDataset):
+    """`data_type='randg_mix'`: samples over SEVERAL meshes (`src/data_mixed.py`), so a batch mixes node counts.  Every
+    sample carries its own `mesh` stand-in and `mapping_tensor` (the model reads `data.mesh[i]` / `data.mapping_tensor` for
+    this data type, `src/GNN.py:247-248,279`) and its `pde_params`."""
+
+    def __init__(self, mesh_sizes: Sequence[int], num_data: int, seed: int = 0, num_gauss: int = 2):
+        self.mesh_sizes = list(mesh_sizes)
+        self.mesh_dims = [self.mesh_sizes[0], self.mesh_sizes[0]]
+        self.dim = 2
+        self.num_x_comp_features = 2
+        rng = np.random.default_rng(seed)
+        bases = {n: square_mesh(n) for n in self.mesh_sizes}
+        self.samples = []
+        for k in range(num_data):
+            n = self.mesh_sizes[k % len(self.mesh_sizes)]
+            d = attach_random_fields(bases[n], rng, num_gauss)
+            d.mesh = MeshTopology(bases[n].cells.numpy())
+            d.mapping_tensor = torch.arange(n * n)
+            self.samples.append(d)
+        self.base = bases[self.mesh_sizes[0]]
+        self.x_comp_shared = self.base.x_comp
+        self.mesh = MeshTopology(self.base.cells.numpy())
+
+
+class Mixed_DataLoader:
+    """`Mixed_DataLoader(dataset, batch_size, shuffle, follow_batch, exclude_keys)` (`src/data_mixed_loader.py:29-35`): the
+    keys in `exclude_keys` stay out of the collated batch and ride along per sample in `batch.batch_dict[i]`
+    (`M2NCustomCollater`, `:6-25`); `GNN.forward` reads `data.batch_dict[i]['pde_params']` for `randg_mix` (`src/GNN.py:199-202`)."""
+
+    def __init__(self, dataset, batch_size: int = 1, shuffle: bool = False, follow_batch=None, exclude_keys=None,
+                 generator: Optional[torch.Generator] = None, **kwargs):
+        self.dataset, self.batch_size, self.shuffle, self.generator = dataset, batch_size, shuffle, generator
+        self.follow_batch, self.exclude_keys = follow_batch, list(exclude_keys or [])
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def collater(self, batch: Sequence[MeshData]) -> MeshData:
+        side = {i: {k: getattr(d, k) for k in d.keys() if k in self.exclude_keys} for i, d in enumerate(batch)}
+        out = collate(batch, exclude_keys=self.exclude_keys)
+        out.batch_dict = side
+        return out
+
+    def __iter__(self) -> Iterable[MeshData]:
+        n = len(self.dataset)
+        if self.shuffle:
+            gen = self.generator if (self.generator is not None and self.generator.device.type == 'cpu') else None
+            order = torch.randperm(n, generator=gen).tolist()
+        else:
+            order = list(range(n))
+        for s in range(0, n, self.batch_size):
+            yield self.collater([self.dataset[i] for i in order[s:s + self.batch_size]])
 
 
 class MeshLoader:

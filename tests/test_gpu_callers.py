@@ -176,3 +176,31 @@ def test_two_rank_step_equals_full_batch_step(gpu_device):
     assert d['grad_rel_err'] <= 1e-5, d          # averaged shard gradients vs the full-batch gradient
     assert d['param_max_abs_diff'] <= 1e-6, d    # after 3 Adam steps (lr 1e-3)
     assert d['ranks_identical'] is True          # replicas stay bit-identical after the reduce
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden", [16, 64])
+def test_mixed_size_batch_parity(gpu_device, hidden):
+    """`data_type='randg_mix'`: batches of 9x9 + 12x12 + 7x7 meshes from `Mixed_DataLoader` (excluded keys in `batch_dict`)
+    through the HIP model, forward and gradients against the oracle; two batch compositions -> two cached graphs."""
+    from g_adaptivity_amd import Mixed_DataLoader, MixedMeshDataset
+    from oracle.pyg_restatement import OracleGNN
+    ds = MixedMeshDataset([9, 12, 7], 6, seed=1)
+    opt = hot_path_opt(mesh_dims=[9, 9], hidden_dim=hidden, num_layers=3, data_type='randg_mix')
+    torch.manual_seed(0)
+    oracle = OracleGNN(ds, dict(opt))
+    model = hip_model_like(oracle, ds, opt, gpu_device)
+    loader = Mixed_DataLoader(ds, batch_size=3, shuffle=False, follow_batch=[], exclude_keys=['pde_params'])
+    for k, data in enumerate(loader):
+        oracle.zero_grad(); model.zero_grad()
+        ref = oracle(data)
+        F.mse_loss(ref, data.x_phys).backward()
+        out = model(data.clone().to(gpu_device))
+        F.mse_loss(out, data.x_phys.to(gpu_device)).backward()
+        torch.cuda.synchronize()
+        assert rel_err(out, ref)[0] <= 1e-5
+        for name in ('lin_query.weight', 'lin_query.bias', 'lin_key.weight'):
+            want = dict(oracle.conv_layers[0].named_parameters())[name].grad
+            got = dict(model.conv_layers[0].named_parameters())[name].grad
+            assert rel_err(got, want)[0] <= 2e-4, (k, name, rel_err(got, want))
+    assert len(model._graphs) == 1            # both batches: the same three meshes in the same order -> one topology

@@ -219,3 +219,26 @@ def test_ell_copy_and_wide_eligibility():
         assert MeshGraph(small, 512, 'cpu').wide_deg == {'t': 0, 's': 0}
     finally:
         graph_mod.WIDE_MIN_NODES = 0
+
+
+def test_mixed_size_batches_and_batch_dict():
+    """`data_type='randg_mix'` (`src/data_mixed_loader.py:6-35`, `src/GNN.py:199-218`): a batch mixes mesh sizes; excluded keys ride
+    in `batch.batch_dict[i]`, non-tensor attributes collate into lists, and the edge surgery (corner offsets from the per-mesh
+    node counts) matches the oracle's restatement."""
+    from g_adaptivity_amd import Mixed_DataLoader, MixedMeshDataset
+    ds = MixedMeshDataset([9, 12, 7], 6, seed=0)
+    loader = Mixed_DataLoader(ds, batch_size=3, shuffle=False, follow_batch=[],
+                              exclude_keys=['boundary_nodes_dict', 'mapping_dict', 'node_boundary_map', 'eval_errors', 'pde_params'])
+    batches = list(loader)
+    assert len(batches) == 2
+    b = batches[0]
+    n = 81 + 144 + 49
+    assert b.x_comp.shape == (n, 2) and torch.bincount(b.batch).tolist() == [81, 144, 49]
+    assert not hasattr(b, 'pde_params') and set(b.batch_dict) == {0, 1, 2} and 'centers' in b.batch_dict[1]['pde_params']
+    assert isinstance(b.mesh, list) and len(b.mesh) == 3 and b.mesh[1].coordinates.cell_node_map().values.shape == (2 * 11 * 11, 3)
+    ours = prepare_edge_index(b, 2, 9, True, False, n)
+    assert torch.equal(ours, masked_edge_index(b, 2, 9))
+    loops = ours[:, ours[0] == ours[1]]
+    assert loops.shape[1] == 12 and sorted(loops[0].tolist())[4:8] == [81, 81 + 11, 81 + 132, 81 + 143]   # second mesh's corners, offset by 81
+    g = MeshGraph(ours, n, 'cpu')
+    assert g.num_edges == ours.shape[1]
