@@ -118,9 +118,13 @@ def main():
     torch.manual_seed(0)                                              # identical replicas
     model = GNN(ds, opt).to(dev)
     model.train()
-    # one GPU: the optimizer step is captured with forward and backward (step count on the device); N > 1: the RCCL
-    # all-reduce of the gradient bucket runs eagerly between the replayed graph and the Adam launch
-    optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=(world == 1))
+    # one GPU: the optimizer step is captured with forward and backward (step count on the device).  N > 1: forward + loss +
+    # backward are the replayed graph, the RCCL all-reduce of the 33 KB gradient bucket and the Adam launch (step count on
+    # the device as well: no host-side value changes from step to step) follow it on the same stream.
+    # GADAPT_BENCH_CAPTURE_ALLREDUCE=1 also captures the collective and Adam in the graph (RCCL collectives are stream-
+    # capturable); off by default because it cannot be rehearsed on a one-GPU box, and a capture that fails falls back.
+    capture_all = world == 1 or os.environ.get('GADAPT_BENCH_CAPTURE_ALLREDUCE') == '1'
+    optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=True)
 
     def fwd_bwd():
         out = model(data)
@@ -146,7 +150,7 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 optim.zero_grad(); fwd_bwd()
-                if world == 1:
+                if capture_all:
                     optim.step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
@@ -154,18 +158,19 @@ def main():
             optim.zero_grad()
             with torch.cuda.graph(g, stream=side):
                 static_loss = fwd_bwd()
-                if world == 1:
+                if capture_all:
                     optim.step()
             graph = g
         except Exception as e:                                        # stay correct: fall back to eager launches
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
             graph = None
+            capture_all = world == 1
             torch.cuda.synchronize()
 
     def step():
         if graph is not None:
-            graph.replay()                                            # forward + loss + backward (+ Adam at N = 1) as one hipGraph
-            if world > 1:
+            graph.replay()                                            # forward + loss + backward (+ all-reduce + Adam when captured)
+            if not capture_all:
                 optim.step()                                          # all-reduce + fused Adam
         else:
             eager_step()
@@ -339,7 +344,7 @@ def main():
             'config': {'workload': args.workload, 'mesh': f"{w['n']}x{w['n']}", 'meshes_per_gpu': w['batch'],
                        'global_batch': w['batch'] * world, 'mp_layers': w['layers'], 'hidden': w['hidden'],
                        'conv_type': w['conv'], 'parallelism': f'dp{world}',
-                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'slots': 'dense' if args.dense_slots else 'compact', 'launch': ('hipgraph' if world > 1 else 'hipgraph+adam') if graph is not None else 'eager'},
+                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'slots': 'dense' if args.dense_slots else 'compact', 'launch': ('hipgraph+adam' if world == 1 else ('hipgraph+allreduce+adam' if capture_all else 'hipgraph, then allreduce+adam')) if graph is not None else 'eager'},
             'roofline': roofline, 'roofline_mfma': roofline_mfma, 'kernels': kernels, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))

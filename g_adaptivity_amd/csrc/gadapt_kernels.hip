@@ -48,6 +48,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_ONE_WAVE_C
 #define GADAPT_ONE_WAVE_C 128
 #endif
+// Hidden sizes from here on would use 512-thread workgroups (Cfg::NT).  Measured at hidden 128 (-DGADAPT_WIDE_WG_C=128
+// -DGADAPT_ONE_WAVE_C=256: the per-wave shares of the dA / projection blocks halve, two waves per SIMD): the backward kernels
+// still spill (52 / 47 registers) and BASELINE config 4 ran 16.1k meshes/s against 17.8k with 256 threads at one wave per
+// SIMD (forward 79 vs 59 us, target 142 vs 147, source 106 vs 93) - not adopted, the geometry stays parametrised.
+#ifndef GADAPT_WIDE_WG_C
+#define GADAPT_WIDE_WG_C 1024
+#endif
 #ifndef GADAPT_FWD_ONE_WAVE
 #define GADAPT_FWD_ONE_WAVE 0
 #endif
@@ -190,7 +197,10 @@ template <int C> struct Cfg {
     static constexpr int FPL = MFMA ? 8 : 4;           // floats per lane
     static constexpr int NV = FPL / 4;                 // float4 chunks per lane
     static constexpr int LPN = C / FPL;                // lanes per node
-    static constexpr int SLOTS = 256 / LPN;            // nodes in flight per workgroup
+    // threads per workgroup (512 from GADAPT_WIDE_WG_C on: see there)
+    static constexpr int NT = (C >= GADAPT_WIDE_WG_C) ? 512 : 256;
+    static constexpr int NW = NT / 64;                 // waves per workgroup
+    static constexpr int SLOTS = NT / LPN;             // nodes in flight per workgroup
     static constexpr int TM = MFMA ? (C == 32 ? 128 : 64) : (SLOTS < 64 ? 64 : SLOTS);
     static constexpr int ITERS = TM / SLOTS;
     static constexpr int LD = C + 4;                   // padded LDS row (floats): conflict-free b128 rows
@@ -323,7 +333,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 
 template <int C, bool TRANS> struct TileGemm {
     using K = Cfg<C>;
-    static constexpr int BPW = (K::CB * K::RB) / 4;    // 32x32 output blocks per wave
+    static constexpr int BPW = (K::CB * K::RB) / K::NW;   // 32x32 output blocks per wave
+    static_assert(!K::MFMA || ((K::CB * K::RB) % K::NW == 0 && K::NW % K::CB == 0), "output blocks split evenly over the waves");
     static constexpr bool SPLIT = GADAPT_GEMM_SPLIT && C <= GADAPT_SPLIT_MAX_C;
     static constexpr int KS = C / 16;                  // k-steps of the bf16 form
     float bf[SPLIT ? 1 : C / 2];
@@ -374,7 +385,7 @@ template <int C, bool TRANS> struct TileGemm {
         const int h = lane >> 5, r31 = lane & 31;
 #pragma unroll
         for (int b = 0; b < BPW; ++b) {
-            const int rb = rb0 + b * (4 / K::CB);
+            const int rb = rb0 + b * (K::NW / K::CB);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
             if constexpr (SPLIT) {
@@ -409,7 +420,7 @@ template <int C, bool TRANS> struct TileGemm {
         const int h = lane >> 5, r31 = lane & 31;
 #pragma unroll
         for (int b = 0; b < BPW; ++b) {
-            const int rb = rb0 + b * (4 / K::CB);
+            const int rb = rb0 + b * (K::NW / K::CB);
             float* ocol = out_tile + cb * 32 + r31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -467,7 +478,7 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
     // Staging is split so a kernel can request tile k+1 while it computes tile k: issue() only starts the
     // loads (results stay in registers), commit() writes them to LDS.  Nothing depends on an earlier load
     // except the slice position, which comes from the metadata word read one tile ahead.
-    static constexpr int CQ = (K::CAP + GADAPT_MAXD + 255) / 256;
+    static constexpr int CQ = (K::CAP + GADAPT_MAXD + K::NT - 1) / K::NT;
     struct Regs {
         int4 meta;
         int rpv, rpv2;
@@ -484,16 +495,16 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
         r.meta = meta_at(k);
         const int eb = r.meta.x;
         r.rpv = rowptr_g[min(min(node0, n_nodes) + min(tid, K::TM), n_nodes)];
-        r.rpv2 = (K::TM >= 256) ? rowptr_g[min(min(node0, n_nodes) + min(256 + tid, K::TM), n_nodes)] : 0;
+        r.rpv2 = (K::TM >= K::NT) ? rowptr_g[min(min(node0, n_nodes) + min(K::NT + tid, K::TM), n_nodes)] : 0;
 #pragma unroll
         for (int q = 0; q < CQ; ++q) {
-            const int idx = q * 256 + tid;
+            const int idx = q * K::NT + tid;
             r.colv[q] = col_g[min(eb + idx, n_edges_m1)];
             if constexpr (EXT > 0) r.extv[q] = ext_g[min(eb + idx, n_edges_m1)];
             if constexpr (AUXW > 0) {
 #pragma unroll
                 for (int w = 0; w < AUXW; ++w) {
-                    const int ia = (q * AUXW + w) * 256 + tid;
+                    const int ia = (q * AUXW + w) * K::NT + tid;
                     r.auxv[q * AUXW + w] = aux_g[min((size_t)AUXW * eb + ia, (size_t)AUXW * n_edges_m1 + (AUXW - 1))];
                 }
             }
@@ -510,13 +521,13 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
     // windowed_tile >= 0: the tile's neighbours all live in slabs t-1..t+1 (metadata word 3): store ring offsets
     // instead of node ids so the gathers read LDS directly.
     __device__ __forceinline__ int commit(const Regs& r, int tid, int node0_pad, int windowed_tile = -1) {
-        static_assert(K::TM + 1 <= 512, "rowptr slice: at most 2 entries per thread");
+        static_assert(K::TM + 1 <= 2 * K::NT, "rowptr slice: at most 2 entries per thread");
         ebase = r.meta.x;
         if (tid <= K::TM) rp[tid] = r.rpv;
-        if (K::TM >= 256 && 256 + tid <= K::TM) rp[256 + tid] = r.rpv2;
+        if (K::TM >= K::NT && K::NT + tid <= K::TM) rp[K::NT + tid] = r.rpv2;
 #pragma unroll
         for (int q = 0; q < CQ; ++q) {
-            const int idx = q * 256 + tid;
+            const int idx = q * K::NT + tid;
             const int cnt = min(r.meta.y, K::CAP);
             const int jv = (idx < cnt) ? r.colv[q] : node0_pad;       // padding entries: a valid node of this tile
             if (idx < K::CAP + GADAPT_MAXD) col[idx] = (windowed_tile >= 0) ? ring_off(jv, windowed_tile) : jv;
@@ -524,7 +535,7 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
             if constexpr (AUXW > 0) {
 #pragma unroll
                 for (int w = 0; w < AUXW; ++w) {
-                    const int ia = (q * AUXW + w) * 256 + tid;
+                    const int ia = (q * AUXW + w) * K::NT + tid;
                     if (ia < AUXW * (K::CAP + GADAPT_MAXD)) aux[ia] = (ia < AUXW * cnt) ? r.auxv[q * AUXW + w] : 0.f;
                 }
             }
@@ -555,7 +566,7 @@ template <int C, bool XC> __device__ __forceinline__ float4 ld_row4x(const float
 template <int C> struct TileRows {
     using K = Cfg<C>;
     static constexpr int V = C / 4;
-    static constexpr int XQ = (K::TM * V + 255) / 256;
+    static constexpr int XQ = (K::TM * V + K::NT - 1) / K::NT;
     float4 v[XQ];
     int node0_;
     // unconditional clamped loads (see TileCsr::issue); rows past N are zeroed at commit
@@ -563,7 +574,7 @@ template <int C> struct TileRows {
         node0_ = node0;
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
-            const int idx = min(q * 256 + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
+            const int idx = min(q * K::NT + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
             v[q] = ld_row4<C>(src, min(max(node0 + r, 0), n_nodes - 1), c4);
         }
     }
@@ -571,7 +582,7 @@ template <int C> struct TileRows {
     // commit_sel writes zeros everywhere else
     template <bool XC> __device__ __forceinline__ void issue_sel(const float* __restrict__ src, int node0, int n_nodes, int tid) {
         if constexpr (XC) {
-            static_assert(K::TM <= 256, "one compact row per thread");
+            static_assert(K::TM <= K::NT, "one compact row per thread");
             node0_ = node0;
             v[0] = *reinterpret_cast<const float4*>(src + 4 * (size_t)min(max(node0 + min(tid, K::TM - 1), 0), n_nodes - 1));
         } else {
@@ -582,7 +593,7 @@ template <int C> struct TileRows {
         if constexpr (XC) {
 #pragma unroll
             for (int q = 0; q < XQ; ++q) {
-                const int idx = q * 256 + tid, r = idx / V, c4 = idx % V;
+                const int idx = q * K::NT + tid, r = idx / V, c4 = idx % V;
                 if (idx < K::TM * V && c4 != 0) *reinterpret_cast<float4*>(tile + r * K::LD + 4 * c4) = f4zero();
             }
             if (tid < K::TM)
@@ -596,14 +607,14 @@ template <int C> struct TileRows {
         node0_ = node0;
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
-            const int idx = min(q * 256 + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
+            const int idx = min(q * K::NT + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
             v[q] = ld_row4_compact(src, min(max(node0 + r, 0), n_nodes - 1), c4, d);
         }
     }
     __device__ __forceinline__ void commit(float* tile, int n_nodes, int tid) const {
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
-            const int idx = q * 256 + tid, r = idx / V, c4 = idx % V;
+            const int idx = q * K::NT + tid, r = idx / V, c4 = idx % V;
             if (idx < K::TM * V)
                 *reinterpret_cast<float4*>(tile + r * K::LD + 4 * c4) = (node0_ + r < n_nodes && node0_ + r >= 0) ? v[q] : f4zero();
         }
@@ -814,7 +825,7 @@ template <int NROWS, int NV> struct RowBuf {
 
 // XC: x_in is the compact [N,4] encoder output (layer 0, identity encoder): see ld_row4x
 template <int C, bool XC = false>
-__global__ __launch_bounds__(256, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_ONE_WAVE) ? 1 : GADAPT_WAVES_FWD)) void grand_fwd_kernel(FwdArgs p) {
+__global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_ONE_WAVE) ? 1 : GADAPT_WAVES_FWD)) void grand_fwd_kernel(FwdArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
@@ -1082,7 +1093,7 @@ template <int NROWS, int NV> struct TBuf {
 // XC: x_in is the compact [N,4] encoder output (layer 0): see ld_row4x.  No source pass follows such a launch (d x0 is
 // not wanted), so it skips what only the source pass reads: the per-edge scratch, dP A and dxd.
 template <int C, bool SUMS, bool GC = false, bool XC = false>
-__global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD_T)) void grand_bwd_target_kernel(BwdTArgs p) {
+__global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD_T)) void grand_bwd_target_kernel(BwdTArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
@@ -1109,11 +1120,12 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
 #pragma unroll
             for (int o = 0; o < C; ++o) acol[t][o] = p.A[o * C + 4 * sub + t];
     }
-    // dA partial accumulators.  MFMA: NB2 = CB*CB 32x32 blocks of dA; >= 4 blocks -> NB2/4 per wave over
+    // dA partial accumulators.  MFMA: NB2 = CB*CB 32x32 blocks of dA; >= NW blocks -> NB2/NW per wave over
     // all TM nodes, 1 block -> the 4 waves split the node range.  VALU: thread owns element tid % C^2 for
     // node subset tid / C^2.
     constexpr int NB2 = K::CB * K::CB;
-    constexpr int DPW = K::MFMA ? (NB2 >= 4 ? NB2 / 4 : 1) : 1;
+    constexpr int DPW = K::MFMA ? (NB2 >= K::NW ? NB2 / K::NW : 1) : 1;
+    static_assert(!K::MFMA || NB2 >= K::NW || (NB2 == 1 && K::NW == 4), "dA blocks per wave");
     f32x16 dacc[DPW];
     float dav = 0.f;
     if constexpr (K::MFMA) {
@@ -1204,7 +1216,11 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
         if constexpr (XC) {
         } else if constexpr (K::LPN >= DM) {
             const float am = pick(a, sub), dm_ = pick(da, sub);
+#ifdef GADAPT_ABL_EDGEWS_LINEAR
+            if (sub < deg) p.edge_ws[csr.ebase + e0 + sub] = make_float2(am * dt, dm_);
+#elif !defined(GADAPT_ABL_NO_EDGEWS)
             if (sub < deg) p.edge_ws[csr.ext[e0 + sub]] = make_float2(am * dt, dm_);
+#endif
         } else {
 #pragma unroll
             for (int k = 0; k < DM; ++k)
@@ -1323,12 +1339,15 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
             __syncthreads();
             GADAPT_STAMP(p.stamps, tslot + 4);
             // ---- dA partial:  dA[o][c] += sum_node dP[node][o] x[node][c]
+#ifdef GADAPT_ABL_NO_DA
+            if (p.n_nodes >= 0) {} else                          // diagnostic build: the dA phase never runs
+#endif
             if constexpr (K::MFMA && TileGemm<C, true>::SPLIT) {
                 // bf16 three-piece form (see split8): k = node, 16 nodes per step; lane (i, h) feeds nodes 8h..8h+7 of the step
                 const int h = lane >> 5, r31 = lane & 31;
-                constexpr int NODES = (NB2 >= 4) ? K::TM : K::TM / 4;   // one 32x32 block: the waves split the nodes
-                const int nbase = (NB2 >= 4) ? 0 : wave * NODES;
-                const int ob = (NB2 >= 4) ? (wave * DPW) / K::CB : 0, cb0 = (NB2 >= 4) ? (wave * DPW) % K::CB : 0;
+                constexpr int NODES = (NB2 >= K::NW) ? K::TM : K::TM / 4;   // one 32x32 block: the waves split the nodes
+                const int nbase = (NB2 >= K::NW) ? 0 : wave * NODES;
+                const int ob = (NB2 >= K::NW) ? (wave * DPW) / K::CB : 0, cb0 = (NB2 >= K::NW) ? (wave * DPW) % K::CB : 0;
 #pragma unroll 2
                 for (int ks = 0; ks < NODES / 16; ++ks) {
                     const int n0 = nbase + 16 * ks + 8 * h;
@@ -1352,7 +1371,7 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
                 }
             } else if constexpr (K::MFMA) {
                 const int h = lane >> 5, r31 = lane & 31;
-                if constexpr (NB2 >= 4) {
+                if constexpr (NB2 >= K::NW) {
                     // wave owns o-block `ob` and DPW consecutive c-blocks
                     const int ob = (wave * DPW) / K::CB, cb0 = (wave * DPW) % K::CB;
 #pragma unroll 4
@@ -1388,10 +1407,12 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
             // ---- dxd = (base-dt) g + dP A
             if constexpr (!XC) {
             if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, nullptr);
+#ifndef GADAPT_ABL_NO_GEMM
             if constexpr (K::MFMA) {
                 gemm.run_in_place(ds);                          // reads dP (like the dA pass), barrier, writes dP A
                 __syncthreads();
             }
+#endif
             GADAPT_STAMP(p.stamps, tslot + 6);
 #pragma unroll
             for (int it = 0; it < K::ITERS; ++it) {
@@ -1426,7 +1447,7 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
     float* row = p.slab + (size_t)blockIdx.x * ROW;
     if constexpr (K::MFMA) {
         const int h = lane >> 5, r31 = lane & 31;
-        if constexpr (NB2 >= 4) {
+        if constexpr (NB2 >= K::NW) {
             const int ob = (wave * DPW) / K::CB, cb0 = (wave * DPW) % K::CB;
 #pragma unroll
             for (int b = 0; b < DPW; ++b)
@@ -1442,7 +1463,7 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + r31] = dacc[0][r];
             __syncthreads();
-            for (int e = tid; e < 1024; e += 256) {
+            for (int e = tid; e < 1024; e += K::NT) {
                 float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
                 if (p.accumulate) v += row[e];
                 row[e] = v;
@@ -1465,7 +1486,7 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
     }
     {   // dp0 and the two scalars: tree over the node slots.  Thread (slot, sub) holds channels 4*(sub+q*LPN)+comp.
         constexpr int W = 4 * K::NV + 2;
-        float* red = xs;                                        // [256][W], spans into the dP tile for small C
+        float* red = xs;                                        // [NT][W], spans into the dP tile for small C
 #pragma unroll
         for (int q = 0; q < K::NV; ++q) {
             red[tid * W + 4 * q + 0] = dp0acc.v[q].x; red[tid * W + 4 * q + 1] = dp0acc.v[q].y;
@@ -1484,7 +1505,7 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
         }
         if (SUMS && p.sums_out && tid < 2) {
             float v = 0.f;
-            for (int s = 0; s < 256; ++s) v += red[s * W + 4 * K::NV + tid];
+            for (int s = 0; s < K::NT; ++s) v += red[s * W + 4 * K::NV + tid];
             if (tid == 1) v = v / sc;                           // d/d(score_scale) = sum d(score') * <P,x>
             atomicAdd(p.sums_out + tid, v);
         }
@@ -1512,7 +1533,7 @@ template <int HN_, int NV> struct SBuf {
 };
 
 template <int C, bool GC = false>
-__global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD_S)) void grand_bwd_source_kernel(BwdSArgs p) {
+__global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD_S)) void grand_bwd_source_kernel(BwdSArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
@@ -1597,7 +1618,11 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
                         b.ev[k] = *reinterpret_cast<const float2*>(csr.aux + 2 * (e0 + k));
                         if (half * HN + k >= deg) b.ev[k] = make_float2(0.f, 0.f);
                         b.g[k] = ld_g(i);
+#ifdef GADAPT_ABL_S_NO_X
+                        b.x[k] = b.g[k];
+#else
                         b.x[k] = ld_vec<C>(p.x_in, i, sub);
+#endif
                     }
                 };
                 V z, y; float sig = 0.f;
@@ -1644,10 +1669,12 @@ __global__ __launch_bounds__(256, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD
         for (int it = 0; it < K::ITERS; ++it) dpre[it] = ld_vec<C>(p.dxd, min(node0 + it * K::SLOTS + slot, p.n_nodes - 1), sub);
         __syncthreads();
         GADAPT_STAMP(p.stamps, tslot + 3);
+#ifndef GADAPT_ABL_S_NO_GEMM
         if constexpr (K::MFMA) {
             gemm.run(ys, os);
             __syncthreads();
         }
+#endif
         GADAPT_STAMP(p.stamps, tslot + 4);
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) {
@@ -2130,6 +2157,9 @@ static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_ou
     return check_launch("wide::fwd_kernel");
 }
 
+// resident set of a launch: two 256-thread workgroups per CU, or one 512-thread workgroup (Cfg::NT)
+template <int C> static constexpr int resident_blocks(int two_per_cu_default) { return Cfg<C>::NT == 512 ? 256 : two_per_cu_default; }
+
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                                        const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st) {
     using K = Cfg<C>;
@@ -2146,10 +2176,10 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
     constexpr int lds = K::lds_bytes(0, K::RING + 1);
     if (x_cols) {
         allow_lds(grand_fwd_kernel<C, true>, lds);
-        hipLaunchKernelGGL((grand_fwd_kernel<C, true>), dim3(grid_for(p.n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((grand_fwd_kernel<C, true>), dim3(grid_for(p.n_tiles, resident_blocks<C>(GADAPT_FWD_MAX_BLOCKS))), dim3(K::NT), lds, st, p);
     } else {
         allow_lds(grand_fwd_kernel<C>, lds);
-        hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, GADAPT_FWD_MAX_BLOCKS)), dim3(256), lds, st, p);
+        hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, resident_blocks<C>(GADAPT_FWD_MAX_BLOCKS))), dim3(K::NT), lds, st, p);
     }
     return check_launch("grand_fwd_kernel");
 }
@@ -2172,16 +2202,16 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
         ProfScope prof(1, st, (g_cols ? 1 : 0) | (x_cols ? 2 : 0));
         if (x_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, false, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, true>), dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else if (g_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true>), dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else if (sums_out) {
             allow_lds(grand_bwd_target_kernel<C, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, true>), dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else {
             allow_lds(grand_bwd_target_kernel<C, false>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false>), dim3(grid_for(n_tiles, GADAPT_BWD_T_MAX_BLOCKS)), dim3(256), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         }
         rc = check_launch("grand_bwd_target_kernel");
     }
@@ -2193,10 +2223,10 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     ProfScope prof(2, st, g_cols ? 1 : 0);
     if (g_cols) {
         allow_lds(grand_bwd_source_kernel<C, true>, lds_s);
-        hipLaunchKernelGGL((grand_bwd_source_kernel<C, true>), dim3(grid_for(n_tiles, GADAPT_BWD_S_MAX_BLOCKS)), dim3(256), lds_s, st, ps);
+        hipLaunchKernelGGL((grand_bwd_source_kernel<C, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_s, st, ps);
     } else {
         allow_lds(grand_bwd_source_kernel<C>, lds_s);
-        hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, GADAPT_BWD_S_MAX_BLOCKS)), dim3(256), lds_s, st, ps);
+        hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_s, st, ps);
     }
     return check_launch("grand_bwd_source_kernel");
 }
@@ -2226,9 +2256,9 @@ extern "C" int gadapt_debug_occupancy(int c, int* out3) {
 #define GADAPT_OCC(CC)                                                                                                  \
     case CC: {                                                                                                          \
         using K = Cfg<CC>;                                                                                              \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_kernel<CC>, 256, K::lds_bytes(0, K::RING + 1)); \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC, false>, 256, K::lds_bytes(1, K::RING + 1, 1)); \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], grand_bwd_source_kernel<CC>, 256, K::lds_bytes(2)); \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_kernel<CC>, K::NT, K::lds_bytes(0, K::RING + 1)); \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC, false>, K::NT, K::lds_bytes(1, K::RING + 1, 1)); \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], grand_bwd_source_kernel<CC>, K::NT, K::lds_bytes(2)); \
         return GADAPT_OK;                                                                                               \
     }
     switch (c) { GADAPT_OCC(4) GADAPT_OCC(8) GADAPT_OCC(16) GADAPT_OCC(32) GADAPT_OCC(64) GADAPT_OCC(128) default: break; }
@@ -2247,7 +2277,7 @@ extern "C" int gadapt_layer_forward(const gadapt_graph* g, const float* x_in, fl
 template <int C> static int tiles_for(int64_t n_nodes) { return (int)((n_nodes + Cfg<C>::TM - 1) / Cfg<C>::TM); }
 extern "C" int gadapt_backward_slab_rows(int64_t n_nodes, int c) {
     if (n_nodes <= 0) return fail(GADAPT_E_BADARG, "slab_rows: bad node count");
-    GADAPT_DISPATCH_C(c, grid_for(tiles_for<CC>(n_nodes), GADAPT_BWD_T_MAX_BLOCKS));
+    GADAPT_DISPATCH_C(c, grid_for(tiles_for<CC>(n_nodes), resident_blocks<CC>(GADAPT_BWD_T_MAX_BLOCKS)));
 }
 extern "C" int64_t gadapt_backward_slab_floats(int64_t n_nodes, int c) {
     const int rows = gadapt_backward_slab_rows(n_nodes, c);

@@ -8,7 +8,8 @@ The BASELINE config-4 shape (64x64, 6 layers, hidden 128) is the extreme of that
 that cancel to 1 part in 1e3..1e4, and BOTH fp32 paths sit at 0.7-3e-4 of the fp64 result with either one ahead depending on
 the parameter (measured on MI355X: HIP 1.4e-4 / 1.2e-4 / 1.1e-4 against the fp32 oracle's 1.0e-4 / 0.7e-4 / 0.7e-4 at two
 meshes; 2.3e-4 / 6.9e-4 / 4.8e-4 against 3.1e-4 / 7.1e-4 / 3.4e-4 at one).  Two such rounding-noise figures are not
-ordered, so that case is held to 2x the oracle's own error (`noise_factor`).  The softmax uses expf and a true division
+ordered (the ratio HIP / oracle ranged 0.7 ... 1.9 over those six), so that case is held to 3x the oracle's own error
+(`noise_factor`).  The softmax uses expf and a true division
 (csrc GADAPT_PRECISE_SOFTMAX): with v_exp_f32 / v_rcp_f32 the same case measured 3.4e-4.
 """
 import pytest
@@ -34,7 +35,7 @@ CASES = [
     ((10, 10), 2, 64, 2, 'GRAND_plus', {'fix_boundary': False, 'self_loops': True}),   # in-degree 7 rows
     ((21,), 3, 8, 3, 'GRAND', {'gnn_inc_feat_f': False}),                               # Burgers features (params.py:148,155)
     # BASELINE config 4 shape: 64x64, 6 layers, hidden 128, GRAND, features [x, y, uu] (two meshes: the oracle stays quick)
-    ((64, 64), 2, 128, 6, 'GRAND', {'gnn_inc_feat_f': False, 'noise_factor': 2.0}),
+    ((64, 64), 2, 128, 6, 'GRAND', {'gnn_inc_feat_f': False, 'noise_factor': 3.0}),
     # BASELINE config 5 shape: 128x128 mesh, 20 Euler steps, hidden 64 (one mesh): 128-node mesh rows exceed the LDS window,
     # so this is the mesh-ordered NON-windowed tile path, and 20 layers of error growth in forward and backward
     ((128, 128), 1, 64, 20, 'GRAND_plus', {}),
