@@ -59,6 +59,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GADAPT_FWD_ONE_WAVE 0
 #endif
 #define GADAPT_SLAB_CHUNKS 32   // second-level partials of the slab reduction
+#ifndef GADAPT_T_MFMA_PRIO
+#define GADAPT_T_MFMA_PRIO 0    // s_setprio level of the target pass's matrix phases (0: leave the priority alone)
+#endif
+#ifndef GADAPT_DA_UNROLL
+#define GADAPT_DA_UNROLL 2      // k-steps of the dA loop unrolled together
+#endif
 // Softmax arithmetic: 1 = expf / IEEE division (<= 1 ulp each), 0 = v_exp_f32 of a rounded product and v_rcp_f32.
 // The approximate forms leave alpha with ~4x the rounding error of the reference's exp / true division; harmless for
 // the coordinates (2e-7 either way) but visible in parameter gradients that are the small remainder of large cancelling
@@ -1339,6 +1345,9 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             __syncthreads();
             GADAPT_STAMP(p.stamps, tslot + 4);
             // ---- dA partial:  dA[o][c] += sum_node dP[node][o] x[node][c]
+#if GADAPT_T_MFMA_PRIO
+            __builtin_amdgcn_s_setprio(GADAPT_T_MFMA_PRIO);
+#endif
 #ifdef GADAPT_ABL_NO_DA
             if (p.n_nodes >= 0) {} else                          // diagnostic build: the dA phase never runs
 #endif
@@ -1348,7 +1357,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                 constexpr int NODES = (NB2 >= K::NW) ? K::TM : K::TM / 4;   // one 32x32 block: the waves split the nodes
                 const int nbase = (NB2 >= K::NW) ? 0 : wave * NODES;
                 const int ob = (NB2 >= K::NW) ? (wave * DPW) / K::CB : 0, cb0 = (NB2 >= K::NW) ? (wave * DPW) % K::CB : 0;
-#pragma unroll 2
+#pragma unroll GADAPT_DA_UNROLL
                 for (int ks = 0; ks < NODES / 16; ++ks) {
                     const int n0 = nbase + 16 * ks + 8 * h;
                     float av[8];
@@ -1412,6 +1421,9 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                 gemm.run_in_place(ds);                          // reads dP (like the dA pass), barrier, writes dP A
                 __syncthreads();
             }
+#endif
+#if GADAPT_T_MFMA_PRIO
+            __builtin_amdgcn_s_setprio(0);
 #endif
             GADAPT_STAMP(p.stamps, tslot + 6);
 #pragma unroll
