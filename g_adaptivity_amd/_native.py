@@ -66,6 +66,7 @@ PROTOTYPES = {
     'gadapt_profile_variants': (_I, [_I, C.POINTER(C.c_int), _I]),
     'gadapt_profile_reset': (_I, []),
     'gadapt_profile_calibrate': (_I, [_I, _P]),
+    'gadapt_debug_set_fused_backward': (_I, [_I]),
     'gadapt_debug_occupancy': (_I, [_I, C.POINTER(C.c_int)]),
 }
 

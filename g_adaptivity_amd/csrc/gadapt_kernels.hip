@@ -58,7 +58,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_FWD_ONE_WAVE
 #define GADAPT_FWD_ONE_WAVE 0
 #endif
-#define GADAPT_SLAB_CHUNKS 32   // second-level partials of the slab reduction
+#ifndef GADAPT_SLAB_CHUNKS
+#define GADAPT_SLAB_CHUNKS 8    // second-level partials of the slab reduction (<= 32: the scratch the callers allocate).
+                                // 32 / 16 / 8 chunks: first level 5.1 / 5.5 / 5.0 us, second level + chain rule 12.1 / 8.8 / 6.6 us
+#endif
 #ifndef GADAPT_T_MFMA_PRIO
 #define GADAPT_T_MFMA_PRIO 0    // s_setprio level of the target pass's matrix phases (0: leave the priority alone)
 #endif
@@ -2063,6 +2066,7 @@ __global__ void adam_step_kernel(float* param, const float* grad, float* m, floa
 }
 
 #include "gadapt_wide.inc"
+#include "gadapt_fused_bwd.inc"
 
 // Same update with the step count kept on the device (state[0] = steps taken, state[1] = exit ticket), so that the
 // launch carries no host-side value that changes from step to step and can sit inside a captured hipGraph.  Every
@@ -2195,6 +2199,24 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
     }
     return check_launch("grand_fwd_kernel");
 }
+// The node pass + fused kernel of gadapt_fused_bwd.inc instead of the target / source pair for dense layers.  OFF by
+// default: measured on MI355X (64x64 b32 C64) the fused kernel takes 79.8 us and the node pass 16.4 us against 42.1 + 29.9 us for
+// the pair.  GADAPT_FUSED_BWD=1 in the environment or gadapt_debug_set_fused_backward(1) turn it on
+// (tests/test_gpu_ops.py::test_fused_backward_matches_two_pass keeps it correct).
+static std::atomic<int> g_fused_bwd{-1};
+static bool fused_bwd_enabled() {
+    int v = g_fused_bwd.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("GADAPT_FUSED_BWD");
+        v = (e && e[0] == '1') ? 1 : 0;
+        g_fused_bwd.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+extern "C" int gadapt_debug_set_fused_backward(int on) { g_fused_bwd.store(on ? 1 : 0, std::memory_order_relaxed); return GADAPT_OK; }
+#ifndef GADAPT_BWD_D_MAX_BLOCKS
+#define GADAPT_BWD_D_MAX_BLOCKS 1024
+#endif
 template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha,
                                        const float* a, const float* p0, const float* lp, float* edge_ws, float* dxd, float* slab,
                                        int accumulate, float* sums_out, float* g_out, int residual_only, int g_cols, int x_cols, hipStream_t st) {
@@ -2210,6 +2232,28 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
 #endif
     constexpr int lds_t = K::lds_bytes(1, K::RING + 1, 1), lds_s = K::lds_bytes(2);
     int rc;
+    if constexpr (C == 32 || C == 64) {
+        // dense layer with a gradient to pass on: node pass for D + ONE fused kernel (gadapt_fused_bwd.inc) instead of the
+        // target / source pair; D [N] lives at the start of the (otherwise unused) dxd workspace
+        if (fused_bwd_enabled() && !g_cols && !x_cols && !sums_out && g_out && g->rowptr_s && g->col_s && g->perm_s) {
+            {
+                BwdDArgs pd{x_in, g_in, alpha, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t), dxd, g->n_nodes, n_tiles, residual_only, g->n_edges};
+                ProfScope prof(5, st, 0);
+                constexpr int lds_d = K::lds_bytes(1, 0);
+                allow_lds(grand_bwd_dnode_kernel<C>, lds_d);
+                hipLaunchKernelGGL(grand_bwd_dnode_kernel<C>, dim3(grid_for(n_tiles, GADAPT_BWD_D_MAX_BLOCKS)), dim3(256), lds_d, st, pd);
+                if ((rc = check_launch("grand_bwd_dnode_kernel"))) return rc;
+            }
+            BwdFArgs pf{x_in, g_in, alpha, dxd, a, p0, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t),
+                        g->rowptr_s, g->col_s, g->perm_s, meta_for<K::TM>(g->meta_s), g_out, slab,
+                        g->n_nodes, n_tiles, accumulate, residual_only, g->n_edges};
+            ProfScope prof(6, st, 0);
+            constexpr int lds_f = fused_bwd_lds_bytes<C>();
+            allow_lds(grand_bwd_fused_kernel<C>, lds_f);
+            hipLaunchKernelGGL(grand_bwd_fused_kernel<C>, dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(256), lds_f, st, pf);
+            return check_launch("grand_bwd_fused_kernel");
+        }
+    }
     {
         ProfScope prof(1, st, (g_cols ? 1 : 0) | (x_cols ? 2 : 0));
         if (x_cols) {

@@ -89,7 +89,9 @@ def content_fingerprint(tensors) -> Tuple:
                 sums.append(torch.zeros(2, dtype=torch.int64, device=v.device))
                 continue
             w = _fp_weight(n, v.device)
-            sums.append(torch.stack([(v * w).sum(), ((v + 1) * (w * w + 7)).sum()]))
+            # two checksums without [n]-sized temporaries: an order-sensitive weighted sum and the plain sum
+            weighted = torch.dot(v, w) if v.device.type == 'cpu' else (v * w).sum()   # integer dot exists on the CPU only
+            sums.append(torch.stack([weighted, v.sum()]))
         by_dev = {}
         for k, s_ in zip(todo, sums):
             by_dev.setdefault(str(s_.device), []).append((k, s_))

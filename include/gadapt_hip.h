@@ -254,6 +254,10 @@ int gadapt_profile_reset(void);
 /* Dispatch share D of an event pair: n x one empty launch (kernel id 3, p1) and n x two empty launches (id 4, p2),
  * bracketed like the hot kernels; D = 2 p1 - p2. */
 int gadapt_profile_calibrate(int n, void* stream);
+/* Diagnostic switch: backward of a dense layer as a node pass (D_i per node) + ONE fused kernel instead of the target /
+ * source pair (csrc/gadapt_fused_bwd.inc; hidden 32 / 64).  Off by default - it measured slower; same results
+ * to fp32 reassociation. */
+int gadapt_debug_set_fused_backward(int on);
 /* Diagnostic: runtime-reported workgroups per CU of {forward, backward target, backward source}. */
 int gadapt_debug_occupancy(int c, int* out3);
 
