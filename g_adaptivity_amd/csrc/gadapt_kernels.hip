@@ -62,6 +62,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GADAPT_SLAB_CHUNKS 8    // second-level partials of the slab reduction (<= 32: the scratch the callers allocate).
                                 // 32 / 16 / 8 chunks: first level 5.1 / 5.5 / 5.0 us, second level + chain rule 12.1 / 8.8 / 6.6 us
 #endif
+#ifndef GADAPT_FPL
+#define GADAPT_FPL 8            // floats per lane at hidden >= 32.  16 (four lanes per node at hidden 64) measured: the row buffers
+                                // double, forward / target pass spill 36 / 117 registers (27.4 / 62.4 us), source pass 28.4 vs 26.2 us
+#endif
 #ifndef GADAPT_T_MFMA_PRIO
 #define GADAPT_T_MFMA_PRIO 0    // s_setprio level of the target pass's matrix phases (0: leave the priority alone)
 #endif
@@ -203,7 +207,7 @@ extern "C" int gadapt_profile_reset(void) {
 // ------------------------------------------------------------------------------------------------
 template <int C> struct Cfg {
     static constexpr bool MFMA = (C >= 32);
-    static constexpr int FPL = MFMA ? 8 : 4;           // floats per lane
+    static constexpr int FPL = MFMA ? GADAPT_FPL : 4;  // floats per lane
     static constexpr int NV = FPL / 4;                 // float4 chunks per lane
     static constexpr int LPN = C / FPL;                // lanes per node
     // threads per workgroup (512 from GADAPT_WIDE_WG_C on: see there)
