@@ -66,6 +66,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GADAPT_FPL 8            // floats per lane at hidden >= 32.  16 (four lanes per node at hidden 64) measured: the row buffers
                                 // double, forward / target pass spill 36 / 117 registers (27.4 / 62.4 us), source pass 28.4 vs 26.2 us
 #endif
+#ifndef GADAPT_DA_IN_SOURCE
+#define GADAPT_DA_IN_SOURCE 0   // 1: at hidden 32 / 64 the source pass accumulates dA / dp0 when one follows the target pass
+                                // (dA = sum_j x_j y_j^T).  Measured (64x64 b32 C64): target pass 39.0 -> 28.2 us (206 instead of
+                                // 255 registers), source pass 26.7 -> 51.0 us dense (25 spilled registers) and 24.4 -> 31.2 us
+                                // with the compact top gradient (no spills): the dA phase costs ~7 us wherever it runs.
+#endif
 #ifndef GADAPT_T_MFMA_PRIO
 #define GADAPT_T_MFMA_PRIO 0    // s_setprio level of the target pass's matrix phases (0: leave the priority alone)
 #endif
@@ -1105,8 +1111,12 @@ template <int NROWS, int NV> struct TBuf {
 // GC: the upstream gradient is compact, [N,g_cols] (top layer: backward of the x[:, :dim] slice) - only its staging differs.
 // XC: x_in is the compact [N,4] encoder output (layer 0): see ld_row4x.  No source pass follows such a launch (d x0 is
 // not wanted), so it skips what only the source pass reads: the per-edge scratch, dP A and dxd.
-template <int C, bool SUMS, bool GC = false, bool XC = false>
+// DA: this launch accumulates the weight-gradient partials (dA, dp0).  false when a source pass follows that does it
+// instead (dA = sum_i dP_i x_i^T = sum_j x_j y_j^T with y_j = sum_i ds_ij x_i, the vector the source pass forms anyway;
+// dp0 = sum_j sigma_j x_j): the target pass then has no dA phase, no accumulators and no slab flush.
+template <int C, bool SUMS, bool GC = false, bool XC = false, bool DA = true>
 __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD_T)) void grand_bwd_target_kernel(BwdTArgs p) {
+    static_assert(DA || (!SUMS && !XC), "only the plain variants hand dA to the source pass");
     using K = Cfg<C>;
     using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
@@ -1161,9 +1171,11 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                     sum_ddt += gi.v[q].x * (m.v[q].x - xi.v[q].x) + gi.v[q].y * (m.v[q].y - xi.v[q].y) +
                                gi.v[q].z * (m.v[q].z - xi.v[q].z) + gi.v[q].w * (m.v[q].w - xi.v[q].w);
             }
+            if constexpr (DA) {
 #pragma unroll
-            for (int q = 0; q < K::NV; ++q) {
-                dp0acc.v[q].x += dP.v[q].x; dp0acc.v[q].y += dP.v[q].y; dp0acc.v[q].z += dP.v[q].z; dp0acc.v[q].w += dP.v[q].w;
+                for (int q = 0; q < K::NV; ++q) {
+                    dp0acc.v[q].x += dP.v[q].x; dp0acc.v[q].y += dP.v[q].y; dp0acc.v[q].z += dP.v[q].z; dp0acc.v[q].w += dP.v[q].w;
+                }
             }
         }
 #pragma unroll
@@ -1358,7 +1370,8 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 #ifdef GADAPT_ABL_NO_DA
             if (p.n_nodes >= 0) {} else                          // diagnostic build: the dA phase never runs
 #endif
-            if constexpr (K::MFMA && TileGemm<C, true>::SPLIT) {
+            if constexpr (!DA) {
+            } else if constexpr (K::MFMA && TileGemm<C, true>::SPLIT) {
                 // bf16 three-piece form (see split8): k = node, 16 nodes per step; lane (i, h) feeds nodes 8h..8h+7 of the step
                 const int h = lane >> 5, r31 = lane & 31;
                 constexpr int NODES = (NB2 >= K::NW) ? K::TM : K::TM / 4;   // one 32x32 block: the waves split the nodes
@@ -1460,6 +1473,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         }
         if constexpr (!XC) store_dxd((ch.t1 - 1) * K::TM);
     }
+    if constexpr (!DA) return;                                  // the source pass owns the weight-gradient partials
     xs = ring;                                                  // scratch for the flush below
 
     // ---- flush partials into this workgroup's slab row (deterministic: one owner per element)
@@ -1542,6 +1556,7 @@ struct BwdSArgs {
     int n_nodes, n_tiles, n_edges;
     unsigned long long* stamps;
     int g_cols;                                                 // GC kernels: g_in is [N,g_cols]
+    float* slab; int accumulate;                                // DA kernels: this workgroup's slab row (layout of the target pass)
 };
 
 // Half of one node's out-edge rows: g_i and x_i of HN targets (two halves cover DM edges)
@@ -1551,15 +1566,32 @@ template <int HN_, int NV> struct SBuf {
     float2 ev[HN_];
 };
 
-template <int C, bool GC = false>
+// DA: also accumulate the weight-gradient partials here instead of in the target pass:
+//   dA[o][c] = sum_i dP_i[o] x_i[c] = sum_j x_j[o] y_j[c],   dp0[o] = sum_i dP_i[o] = sum_j sigma_j x_j[o]
+// with y_j / sigma_j the per-source sums this pass forms for A y_j + sigma_j p0 anyway (exchange the two sums over the
+// edges).  The y tile is in LDS for the projection; the node's own x rows join it in a third tile.
+template <int C, bool GC = false, bool DA = false>
 __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD_S)) void grand_bwd_source_kernel(BwdSArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
+    static_assert(!DA || (K::MFMA && TileGemm<C, false>::SPLIT && K::NW == 4), "dA in the source pass: matrix-core sizes only");
     extern __shared__ float4 smem4[];
     float* ys = reinterpret_cast<float*>(smem4);
     float* os = ys + K::TILE_FLOATS;
+    float* xt = os + K::TILE_FLOATS;                            // DA: own x rows of the tile
     TileCsr<C, 2> csr;                                          // aux = {alpha*dt, d<P,x>} per out-edge (source order)
-    csr.bind(os + K::TILE_FLOATS, p.rowptr, p.col, p.edge_ws, p.meta, p.n_edges);
+    csr.bind(os + (DA ? 2 : 1) * K::TILE_FLOATS, p.rowptr, p.col, p.edge_ws, p.meta, p.n_edges);
+    constexpr int NB2 = K::CB * K::CB;
+    constexpr int DPW = DA ? (NB2 >= 4 ? NB2 / 4 : 1) : 1;
+    f32x16 dacc[DPW];
+    V dp0acc; dp0acc.zero();
+    float sigs[K::ITERS];
+    if constexpr (DA) {
+#pragma unroll
+        for (int b = 0; b < DPW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dacc[b][r] = 0.f;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = tid / K::LPN, sub = tid % K::LPN;
 
@@ -1655,6 +1687,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                         lds_put<C>(ys, li, sub, y);
                         vaxpy(z, sig, p0v);
                         zr[it] = z;
+                        sigs[it] = sig;
                     }
                 };
                 run_pipeline<2 * K::ITERS, SBuf<HN, K::NV>>(fetch, consume, [&]() {});
@@ -1679,6 +1712,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                 lds_put<C>(ys, li, sub, y);
                 vaxpy(z, sig, p0v);
                 zr[it] = z;
+                sigs[it] = sig;
             }
         }
         GADAPT_STAMP(p.stamps, tslot + 2);
@@ -1686,14 +1720,56 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         V dpre[K::ITERS];                                       // own dxd rows: requested here, used after the GEMM
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) dpre[it] = ld_vec<C>(p.dxd, min(node0 + it * K::SLOTS + slot, p.n_nodes - 1), sub);
+        V xo[DA ? K::ITERS : 1];                                // DA: own x rows, in flight under the projection
+        if constexpr (DA) {
+#pragma unroll
+            for (int it = 0; it < K::ITERS; ++it) xo[it] = ld_vec<C>(p.x_in, min(node0 + it * K::SLOTS + slot, p.n_nodes - 1), sub);
+        }
         __syncthreads();
         GADAPT_STAMP(p.stamps, tslot + 3);
 #ifndef GADAPT_ABL_S_NO_GEMM
         if constexpr (K::MFMA) {
             gemm.run(ys, os);
+            if constexpr (DA) {
+#pragma unroll
+                for (int it = 0; it < K::ITERS; ++it) {
+                    const int li = it * K::SLOTS + slot;
+                    if (node0 + li >= p.n_nodes) xo[it].zero();
+                    lds_put<C>(xt, li, sub, xo[it]);
+                    vaxpy(dp0acc, sigs[it], xo[it]);            // dp0 += sigma_j x_j
+                }
+            }
             __syncthreads();
         }
 #endif
+        if constexpr (DA) {
+            // dA[o][c] += sum_node x[node][o] y[node][c]   (three-piece bf16 split, k = node: see the target pass)
+            const int h = lane >> 5, r31 = lane & 31;
+            constexpr int NODES = (NB2 >= 4) ? K::TM : K::TM / 4;
+            const int nbase = (NB2 >= 4) ? 0 : wave * NODES;
+            const int ob = (NB2 >= 4) ? (wave * DPW) / K::CB : 0, cb0 = (NB2 >= 4) ? (wave * DPW) % K::CB : 0;
+#pragma unroll GADAPT_DA_UNROLL
+            for (int ks = 0; ks < NODES / 16; ++ks) {
+                const int n0 = nbase + 16 * ks + 8 * h;
+                float av[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) av[e] = xt[(n0 + e) * K::LD + ob * 32 + r31];
+                const Split3 as = split8(av);
+#pragma unroll
+                for (int b = 0; b < DPW; ++b) {
+                    float bv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = ys[(n0 + e) * K::LD + (cb0 + b) * 32 + r31];
+                    const Split3 bs = split8(bv);
+                    dacc[b] = mfma_bf16(as.h, bs.l, dacc[b]);
+                    dacc[b] = mfma_bf16(as.l, bs.h, dacc[b]);
+                    dacc[b] = mfma_bf16(as.m, bs.m, dacc[b]);
+                    dacc[b] = mfma_bf16(as.h, bs.m, dacc[b]);
+                    dacc[b] = mfma_bf16(as.m, bs.h, dacc[b]);
+                    dacc[b] = mfma_bf16(as.h, bs.h, dacc[b]);
+                }
+            }
+        }
         GADAPT_STAMP(p.stamps, tslot + 4);
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) {
@@ -1724,6 +1800,52 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         GADAPT_STAMP(p.stamps, tslot + 6);
     }
     if (prev_node0 >= 0) store_out(prev_node0);
+    if constexpr (DA) {
+        // ---- flush the partials into this workgroup's slab row (layout and order of the target pass's flush)
+        constexpr int ROW = C * C + C;
+        float* row = p.slab + (size_t)blockIdx.x * ROW;
+        const int h = lane >> 5, r31 = lane & 31;
+        __syncthreads();
+        if constexpr (NB2 >= 4) {
+            const int ob = (wave * DPW) / K::CB, cb0 = (wave * DPW) % K::CB;
+#pragma unroll
+            for (int b = 0; b < DPW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, c = (cb0 + b) * 32 + r31;
+                    float v = dacc[b][r];
+                    if (p.accumulate) v += row[o * C + c];
+                    row[o * C + c] = v;
+                }
+        } else {
+            float* red = ys;                                    // [4][32*32]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + r31] = dacc[0][r];
+            __syncthreads();
+            for (int e = tid; e < 1024; e += K::NT) {
+                float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+                if (p.accumulate) v += row[e];
+                row[e] = v;
+            }
+            __syncthreads();
+        }
+        constexpr int W = 4 * K::NV;
+        float* red = ys;                                        // [NT][W]
+#pragma unroll
+        for (int q = 0; q < K::NV; ++q) {
+            red[tid * W + 4 * q + 0] = dp0acc.v[q].x; red[tid * W + 4 * q + 1] = dp0acc.v[q].y;
+            red[tid * W + 4 * q + 2] = dp0acc.v[q].z; red[tid * W + 4 * q + 3] = dp0acc.v[q].w;
+        }
+        __syncthreads();
+        if (tid < C) {
+            const int c4 = tid / 4, comp = tid % 4;
+            const int sb = c4 % K::LPN, q = c4 / K::LPN;
+            float v = 0.f;
+            for (int s = 0; s < K::SLOTS; ++s) v += red[(s * K::LPN + sb) * W + 4 * q + comp];
+            if (p.accumulate) v += row[C * C + tid];
+            row[C * C + tid] = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2258,9 +2380,22 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
             return check_launch("grand_bwd_fused_kernel");
         }
     }
+    // hidden 32 / 64 with a source pass to follow: the source pass accumulates dA / dp0 (see grand_bwd_source_kernel)
+    constexpr bool CAN_MOVE_DA = (C == 32 || C == 64) && GADAPT_DA_IN_SOURCE;
+    const bool da_in_s = CAN_MOVE_DA && g_out && !sums_out && !x_cols;
     {
         ProfScope prof(1, st, (g_cols ? 1 : 0) | (x_cols ? 2 : 0));
-        if (x_cols) {
+        if constexpr (CAN_MOVE_DA) {
+            if (da_in_s && g_cols) {
+                allow_lds(grand_bwd_target_kernel<C, false, true, false, false>, lds_t);
+                hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true, false, false>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+            } else if (da_in_s) {
+                allow_lds(grand_bwd_target_kernel<C, false, false, false, false>, lds_t);
+                hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, false, false>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+            }
+        }
+        if (da_in_s) {
+        } else if (x_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, false, true>, lds_t);
             hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else if (g_cols) {
@@ -2276,11 +2411,27 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
         rc = check_launch("grand_bwd_target_kernel");
     }
     if (rc || !g_out) return rc;
-    BwdSArgs ps{x_in, g_in, edge_ws, dxd, a, p0, g->rowptr_s, g->col_s, meta_for<K::TM>(g->meta_s), g_out, g->n_nodes, n_tiles, g->n_edges, nullptr, g_cols};
+    BwdSArgs ps{x_in, g_in, edge_ws, dxd, a, p0, g->rowptr_s, g->col_s, meta_for<K::TM>(g->meta_s), g_out, g->n_nodes, n_tiles, g->n_edges, nullptr, g_cols,
+                slab, accumulate};
 #ifdef GADAPT_STAMPS
     ps.stamps = g_stamp_buf ? g_stamp_buf + 2 * 1024 * 32 : nullptr;
 #endif
     ProfScope prof(2, st, g_cols ? 1 : 0);
+    if constexpr (CAN_MOVE_DA) {
+        if (da_in_s) {
+            // same grid as the target pass: the slab holds one row per workgroup of either
+            static_assert(GADAPT_BWD_S_MAX_BLOCKS == GADAPT_BWD_T_MAX_BLOCKS, "slab rows = workgroups of the pass that flushes them");
+            constexpr int lds_sd = K::lds_bytes(2, 3);
+            if (g_cols) {
+                allow_lds(grand_bwd_source_kernel<C, true, true>, lds_sd);
+                hipLaunchKernelGGL((grand_bwd_source_kernel<C, true, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_sd, st, ps);
+            } else {
+                allow_lds(grand_bwd_source_kernel<C, false, true>, lds_sd);
+                hipLaunchKernelGGL((grand_bwd_source_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_sd, st, ps);
+            }
+            return check_launch("grand_bwd_source_kernel");
+        }
+    }
     if (g_cols) {
         allow_lds(grand_bwd_source_kernel<C, true>, lds_s);
         hipLaunchKernelGGL((grand_bwd_source_kernel<C, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_s, st, ps);
