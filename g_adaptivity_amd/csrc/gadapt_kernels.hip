@@ -330,20 +330,43 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // level of an fp32 product, and every piece product is exact in the fp32 accumulator.  v_mfma_f32_32x32x16_bf16
 // does 16x the work of v_mfma_f32_32x32x2_f32 in half its cycles, so six of them per 16 k cost 3/8 of the fp32 form.
 struct Split3 { u32x4 h, m, l; };
+#ifndef GADAPT_SPLIT_PK
+#define GADAPT_SPLIT_PK 0       // 1: residuals of the split on v_pk_add_f32 (two subtractions per instruction); measured 0.3597 ms
+                                // per step against 0.3568 with scalar subtractions (three runs each): no gain
+#endif
 __device__ __forceinline__ Split3 split8(const float (&x)[8]) {
+    Split3 s;
+#if GADAPT_SPLIT_PK
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                       // element 2q in the low half, 2q+1 in the high half
+        const f2 v = {x[2 * q], x[2 * q + 1]};
+        const u2 vb = __builtin_bit_cast(u2, v);
+        const f2 hf = __builtin_bit_cast(f2, vb & 0xFFFF0000u);
+        const f2 r = v - hf;                            // exact
+        const u2 rb = __builtin_bit_cast(u2, r);
+        const f2 mf = __builtin_bit_cast(f2, rb & 0xFFFF0000u);
+        const f2 r2 = r - mf;                           // exact
+        const u2 r2b = __builtin_bit_cast(u2, r2);
+        s.h[q] = __builtin_amdgcn_perm(vb.y, vb.x, 0x07060302u);
+        s.m[q] = __builtin_amdgcn_perm(rb.y, rb.x, 0x07060302u);
+        s.l[q] = __builtin_amdgcn_perm(r2b.y, r2b.x, 0x07060302u);
+    }
+#else
     float r[8], r2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         r[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xFFFF0000u);
         r2[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xFFFF0000u);
     }
-    Split3 s;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                       // element 2q in the low half, 2q+1 in the high half
         s.h[q] = __builtin_amdgcn_perm(__float_as_uint(x[2 * q + 1]), __float_as_uint(x[2 * q]), 0x07060302u);
         s.m[q] = __builtin_amdgcn_perm(__float_as_uint(r[2 * q + 1]), __float_as_uint(r[2 * q]), 0x07060302u);
         s.l[q] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * q + 1]), __float_as_uint(r2[2 * q]), 0x07060302u);
     }
+#endif
     return s;
 }
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
