@@ -128,6 +128,38 @@ def test_no_cpu_fallback():
     m = GNN(ds, opt)
     with pytest.raises(_native.NativeError):
         m(collate(ds.samples))
+    # the conv variants and the generic primitives are no exception
+    from g_adaptivity_amd import sparse_ops as Sp
+    d = collate(ds.samples)
+    for conv in ('GAT_plus', 'GAT', 'GCN', 'TRANS'):
+        mv = GNN(ds, hot_path_opt(mesh_dims=[7, 7], conv_type=conv))
+        with pytest.raises(_native.NativeError):
+            mv(d)
+    g = MeshGraph(prepare_edge_index(d, 2, 7, True, False, 49), 49, 'cpu')
+    with pytest.raises(_native.NativeError):
+        Sp.spmm(g, None, torch.zeros(49, 8))
+    with pytest.raises(_native.NativeError):
+        Sp.edge_softmax(g, torch.zeros(g.num_edges))
+
+
+def test_variant_state_dict_keys_match_the_oracle():
+    """Parameter names of every conv variant behind get_conv (`src/GNN.py:108-124`) = PyG's / the reference's, so state_dicts
+    interchange with the oracle's holders (strict load)."""
+    from oracle.pyg_restatement import OracleGNN
+    ds = MeshDataset([7, 7], 2, seed=0)
+    want = {'GAT_plus': {'att_src', 'att_dst'}, 'GAT': {'att_src', 'att_dst', 'bias', 'lin_src.weight', 'lin_dst.weight'},
+            'GCN': {'lin.weight', 'bias'}, 'TRANS': {'lin_key.weight', 'lin_key.bias', 'lin_query.weight', 'lin_query.bias',
+                                                     'lin_value.weight', 'lin_value.bias', 'lin_skip.weight', 'lin_skip.bias'}}
+    for conv, names in want.items():
+        opt = hot_path_opt(mesh_dims=[7, 7], hidden_dim=8, num_layers=2, conv_type=conv, non_lin='relu')
+        model, oracle = GNN(ds, dict(opt)), OracleGNN(ds, dict(opt))
+        keys = set(model.state_dict())
+        assert {k.split('conv_layers.0.')[1] for k in keys if k.startswith('conv_layers.0.')} == names, conv
+        assert keys == set(oracle.state_dict()), conv
+        model.load_state_dict(oracle.state_dict(), strict=True)
+    # learnable_v: the parameter exists under the reference's name (src/GRAND_plus.py:159)
+    lv = GNN(ds, hot_path_opt(mesh_dims=[7, 7], hidden_dim=8, softmax_temp_type='learnable_v'))
+    assert lv.state_dict()['conv_layers.0.sm_temp_v.weight'].shape == (1, 8)
 
 
 def test_global_cnn_feature_modules_have_the_reference_keys():
