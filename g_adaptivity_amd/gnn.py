@@ -86,6 +86,32 @@ def build_conv_list(opt):
     return nn.ModuleList(layers)
 
 
+class MLP(nn.Module):
+    """The reference's node-wise baseline model (`src/GNN.py:16-45`, built by `run_GNN.get_model` for `opt['model'] == 'MLP'`,
+    `src/run_GNN.py:57-58`): encoder, two residual dense layers on `x_comp`, decoder - no graph, so nothing for the HIP path;
+    dense torch layers (rocBLAS on the GPU), here so that `from g_adaptivity_amd import GNN, MLP` replaces the reference's import."""
+
+    def __init__(self, dataset, opt):
+        super().__init__()
+        self.opt = opt
+        in_dim = dataset.data.x_comp.shape[1]
+        hid_dim = opt['hidden_dim']
+        out_dim = dataset.data.x_comp.shape[1]
+        self.enc = get_enc(opt, in_dim, hid_dim, nonlin_type=opt['non_lin'])
+        self.non_lin = get_nonlin(opt['non_lin'])
+        self.dec = get_dec(opt, hid_dim, out_dim, nonlin_type=opt['non_lin'])
+        self.fc1 = nn.Linear(hid_dim, hid_dim)
+        self.fc2 = nn.Linear(hid_dim, hid_dim)
+
+    def forward(self, data):
+        o = self.opt
+        x = self.enc(data.x_comp)
+        for fc in (self.fc1, self.fc2):                                   # GNN.py:33-43
+            x = x + o['time_step'] * fc(x) if o['residual'] else fc(x)
+            x = self.non_lin(F.dropout(x, o['dropout'], training=self.training))
+        return self.dec(x)
+
+
 class GNN(nn.Module):
     def __init__(self, dataset, opt):
         super().__init__()

@@ -273,6 +273,7 @@ class MeshDataset:
             base = square_mesh(self.mesh_dims[0])
         rng = np.random.default_rng(seed)
         self.base = base
+        self.data = base                                     # `dataset.data.x_comp` (read by the MLP baseline, src/GNN.py:20-22)
         self.x_comp_shared = base.x_comp
         self.num_x_comp_features = self.dim
         self.samples: List[MeshData] = [attach_random_fields(base, rng, num_gauss) for _ in range(num_data)]

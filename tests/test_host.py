@@ -274,3 +274,21 @@ def test_mixed_size_batches_and_batch_dict():
     assert loops.shape[1] == 12 and sorted(loops[0].tolist())[4:8] == [81, 81 + 11, 81 + 132, 81 + 143]   # second mesh's corners, offset by 81
     g = MeshGraph(ours, n, 'cpu')
     assert g.num_edges == ours.shape[1]
+
+
+def test_mlp_baseline_model():
+    """`MLP(dataset, opt)` (`src/GNN.py:16-45`): enc -> x + dt fc1(x) -> non_lin -> x + dt fc2(x) -> non_lin -> dec, on `x_comp`;
+    a literal restatement with the same parameters gives the same numbers, and the identity encoder / decoder pair makes the
+    output [N, hidden] (the reference's `get_dec` is an Identity, `src/GNN.py:101-105`)."""
+    from g_adaptivity_amd import MLP
+    ds = MeshDataset([6, 6], 2, seed=0)
+    opt = hot_path_opt(mesh_dims=[6, 6], hidden_dim=8, non_lin='tanh', time_step=0.1)
+    torch.manual_seed(0)
+    m = MLP(ds, opt)
+    d = collate(ds.samples)
+    out = m(d)
+    x = torch.nn.functional.linear(d.x_comp, m.enc.weight)
+    x = torch.tanh(x + 0.1 * m.fc1(x))
+    x = torch.tanh(x + 0.1 * m.fc2(x))
+    assert out.shape == (72, 8) and torch.allclose(out, x, atol=1e-7)
+    assert set(m.state_dict()) == {'enc.weight', 'fc1.weight', 'fc1.bias', 'fc2.weight', 'fc2.bias'}
