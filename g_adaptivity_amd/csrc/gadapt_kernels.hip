@@ -68,9 +68,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 #ifndef GADAPT_DA_IN_SOURCE
 #define GADAPT_DA_IN_SOURCE 0   // 1: at hidden 32 / 64 the source pass accumulates dA / dp0 when one follows the target pass
-                                // (dA = sum_j x_j y_j^T).  Measured (64x64 b32 C64): target pass 39.0 -> 28.2 us (206 instead of
-                                // 255 registers), source pass 26.7 -> 51.0 us dense (25 spilled registers) and 24.4 -> 31.2 us
-                                // with the compact top gradient (no spills): the dA phase costs ~7 us wherever it runs.
+                                // (dA = sum_j x_j y_j^T).  Measured (64x64 b32 C64): target pass 39.1 -> 27.7 us dense / 32.9 ->
+                                // 25.8 us compact-g (206 instead of 255 registers, no slab flush); source pass 28.3 -> 41.3 / 24.5
+                                // -> 36.5 us (own x rows staged per tile, projection fragments rebuilt per tile to stay under 256
+                                // registers; with resident fragments the dense variant spills 25 registers: 51 us).  Step 0.365
+                                // against 0.356 ms: the dA phase costs more than it frees wherever it runs.
 #endif
 #ifndef GADAPT_T_MFMA_PRIO
 #define GADAPT_T_MFMA_PRIO 0    // s_setprio level of the target pass's matrix phases (0: leave the priority alone)
@@ -1646,7 +1648,9 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 #ifndef GADAPT_S_RESIDENT_B
 #define GADAPT_S_RESIDENT_B 1
 #endif
-    constexpr bool RESIDENT_B = K::MFMA && TileGemm<C, false>::SPLIT && GADAPT_S_RESIDENT_B;   // split fragments: built once per launch
+    // split fragments: built once per launch - unless the dA accumulators need their 48 registers (DA: rebuilt per tile, in
+    // flight under the barrier)
+    constexpr bool RESIDENT_B = K::MFMA && TileGemm<C, false>::SPLIT && GADAPT_S_RESIDENT_B && !DA;
     if constexpr (RESIDENT_B) gemm.load(p.A, nullptr);
     const TileRange tr = tile_range(p.n_tiles);
     typename TileCsr<C, 2>::Regs sr;
@@ -1674,6 +1678,11 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         prev_node0 = node0;
         {   // request the next tile now (unconditional, clamped past the end: see issue()): it lands during this one
             csr.issue(sr, ++kt, (t + tr.step) * K::TM, p.n_nodes, tid);
+        }
+        if constexpr (DA) {                                     // own x rows of this tile -> xt (zeros past N); not held across the edge walk
+            TileRows<C> xrows;
+            xrows.issue(p.x_in, node0, p.n_nodes, tid);
+            xrows.commit(xt, p.n_nodes, tid);
         }
         GADAPT_STAMP(p.stamps, tslot + 1);
         if (dmax >= 0) {
@@ -1743,11 +1752,6 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         V dpre[K::ITERS];                                       // own dxd rows: requested here, used after the GEMM
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) dpre[it] = ld_vec<C>(p.dxd, min(node0 + it * K::SLOTS + slot, p.n_nodes - 1), sub);
-        V xo[DA ? K::ITERS : 1];                                // DA: own x rows, in flight under the projection
-        if constexpr (DA) {
-#pragma unroll
-            for (int it = 0; it < K::ITERS; ++it) xo[it] = ld_vec<C>(p.x_in, min(node0 + it * K::SLOTS + slot, p.n_nodes - 1), sub);
-        }
         __syncthreads();
         GADAPT_STAMP(p.stamps, tslot + 3);
 #ifndef GADAPT_ABL_S_NO_GEMM
@@ -1755,12 +1759,8 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             gemm.run(ys, os);
             if constexpr (DA) {
 #pragma unroll
-                for (int it = 0; it < K::ITERS; ++it) {
-                    const int li = it * K::SLOTS + slot;
-                    if (node0 + li >= p.n_nodes) xo[it].zero();
-                    lds_put<C>(xt, li, sub, xo[it]);
-                    vaxpy(dp0acc, sigs[it], xo[it]);            // dp0 += sigma_j x_j
-                }
+                for (int it = 0; it < K::ITERS; ++it)           // dp0 += sigma_j x_j
+                    vaxpy(dp0acc, sigs[it], lds_vec<C>(xt, it * K::SLOTS + slot, sub));
             }
             __syncthreads();
         }
