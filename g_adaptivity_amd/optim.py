@@ -216,9 +216,9 @@ class FlatAdam:
                     raise RuntimeError("FlatAdam(capturable=True): the set of parameters with gradients changed after the "
                                        "bucket was laid out; a captured step cannot follow it")
                 if self.step_count > 0 and not have <= self._active_ids:
-                    raise RuntimeError("FlatAdam: a parameter received its first gradient after step %d; one flat bucket "
-                                       "shares one step count (bias correction), so build a new optimizer for the new "
-                                       "parameter set" % self.step_count)
+                    raise RuntimeError("FlatAdam: a parameter entered the gradient set after step %d (its first gradient, or "
+                                       "its return after a step without one); one flat bucket shares one step count (bias "
+                                       "correction), so build a new optimizer for the new parameter set" % self.step_count)
                 self._build(carry=(self.active, self.offsets, self.exp_avg, self.exp_avg_sq))
             else:
                 self.grad_bucket = self._flat_grad()

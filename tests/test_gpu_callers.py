@@ -149,7 +149,7 @@ def test_flat_adam_state_dict_param_groups_and_gradient_set_changes(gpu_device):
     torch.cuda.synchronize()
     assert torch.equal(ps[1], before) and torch.allclose(ps[0], qs[0], rtol=1e-5, atol=1e-6)
     # ... and a parameter whose FIRST gradient arrives after steps were taken is refused loudly (one bucket = one step count)
-    with pytest.raises(RuntimeError, match="first gradient"):
+    with pytest.raises(RuntimeError, match="entered the gradient set"):
         step(ours, ps, ref, qs, which=(0, 2))
 
 
