@@ -66,6 +66,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GADAPT_FPL 8            // floats per lane at hidden >= 32.  16 (four lanes per node at hidden 64) measured: the row buffers
                                 // double, forward / target pass spill 36 / 117 registers (27.4 / 62.4 us), source pass 28.4 vs 26.2 us
 #endif
+#ifndef GADAPT_BWD_ONE_PER_CU
+#define GADAPT_BWD_ONE_PER_CU 1
+#endif
+#ifndef GADAPT_T_PREFETCH_MAX_C
+#define GADAPT_T_PREFETCH_MAX_C 128  // target pass: largest hidden size that requests the next tile one tile ahead
+#endif
 #ifndef GADAPT_DA_IN_SOURCE
 #define GADAPT_DA_IN_SOURCE 0   // 1: at hidden 32 / 64 the source pass accumulates dA / dp0 when one follows the target pass
                                 // (dA = sum_j x_j y_j^T).  Measured (64x64 b32 C64): target pass 39.1 -> 27.7 us dense / 32.9 ->
@@ -1335,7 +1341,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         }
         __syncthreads();                                        // tile metadata visible
         // C = 128 has no registers to hold a tile across the edge walk: it stages at the top of the tile instead
-        constexpr bool PREFETCH = (C <= 64);
+        constexpr bool PREFETCH = (C <= GADAPT_T_PREFETCH_MAX_C);
         if constexpr (PREFETCH) {
             xr.template issue_sel<XC>(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);
             if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, ch.t0 * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, ch.t0 * K::TM, p.n_nodes, tid);
@@ -2324,6 +2330,12 @@ static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_ou
 
 // resident set of a launch: two 256-thread workgroups per CU, or one 512-thread workgroup (Cfg::NT)
 template <int C> static constexpr int resident_blocks(int two_per_cu_default) { return Cfg<C>::NT == 512 ? 256 : two_per_cu_default; }
+// ... and the backward kernels of hidden sizes that run one wave per SIMD (GADAPT_ONE_WAVE_C: 392 / 504 registers) fit ONE
+// 256-thread workgroup per CU: 256 workgroups are the resident set, a 512-workgroup launch would run as two rounds (and
+// flush twice as many slab rows).
+template <int C> static constexpr int resident_blocks_bwd(int two_per_cu_default) {
+    return (C >= GADAPT_ONE_WAVE_C && GADAPT_BWD_ONE_PER_CU) ? 256 : resident_blocks<C>(two_per_cu_default);
+}
 
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                                        const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st) {
@@ -2399,7 +2411,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
             ProfScope prof(6, st, 0);
             constexpr int lds_f = fused_bwd_lds_bytes<C>();
             allow_lds(grand_bwd_fused_kernel<C>, lds_f);
-            hipLaunchKernelGGL(grand_bwd_fused_kernel<C>, dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(256), lds_f, st, pf);
+            hipLaunchKernelGGL(grand_bwd_fused_kernel<C>, dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(256), lds_f, st, pf);
             return check_launch("grand_bwd_fused_kernel");
         }
     }
@@ -2411,25 +2423,25 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
         if constexpr (CAN_MOVE_DA) {
             if (da_in_s && g_cols) {
                 allow_lds(grand_bwd_target_kernel<C, false, true, false, false>, lds_t);
-                hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true, false, false>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+                hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true, false, false>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
             } else if (da_in_s) {
                 allow_lds(grand_bwd_target_kernel<C, false, false, false, false>, lds_t);
-                hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, false, false>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+                hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, false, false>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
             }
         }
         if (da_in_s) {
         } else if (x_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, false, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else if (g_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else if (sums_out) {
             allow_lds(grand_bwd_target_kernel<C, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else {
             allow_lds(grand_bwd_target_kernel<C, false>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         }
         rc = check_launch("grand_bwd_target_kernel");
     }
@@ -2447,20 +2459,20 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
             constexpr int lds_sd = K::lds_bytes(2, 3);
             if (g_cols) {
                 allow_lds(grand_bwd_source_kernel<C, true, true>, lds_sd);
-                hipLaunchKernelGGL((grand_bwd_source_kernel<C, true, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_sd, st, ps);
+                hipLaunchKernelGGL((grand_bwd_source_kernel<C, true, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_sd, st, ps);
             } else {
                 allow_lds(grand_bwd_source_kernel<C, false, true>, lds_sd);
-                hipLaunchKernelGGL((grand_bwd_source_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_sd, st, ps);
+                hipLaunchKernelGGL((grand_bwd_source_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_sd, st, ps);
             }
             return check_launch("grand_bwd_source_kernel");
         }
     }
     if (g_cols) {
         allow_lds(grand_bwd_source_kernel<C, true>, lds_s);
-        hipLaunchKernelGGL((grand_bwd_source_kernel<C, true>), dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_s, st, ps);
+        hipLaunchKernelGGL((grand_bwd_source_kernel<C, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_s, st, ps);
     } else {
         allow_lds(grand_bwd_source_kernel<C>, lds_s);
-        hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, resident_blocks<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_s, st, ps);
+        hipLaunchKernelGGL(grand_bwd_source_kernel<C>, dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_s, st, ps);
     }
     return check_launch("grand_bwd_source_kernel");
 }
@@ -2511,7 +2523,7 @@ extern "C" int gadapt_layer_forward(const gadapt_graph* g, const float* x_in, fl
 template <int C> static int tiles_for(int64_t n_nodes) { return (int)((n_nodes + Cfg<C>::TM - 1) / Cfg<C>::TM); }
 extern "C" int gadapt_backward_slab_rows(int64_t n_nodes, int c) {
     if (n_nodes <= 0) return fail(GADAPT_E_BADARG, "slab_rows: bad node count");
-    GADAPT_DISPATCH_C(c, grid_for(tiles_for<CC>(n_nodes), resident_blocks<CC>(GADAPT_BWD_T_MAX_BLOCKS)));
+    GADAPT_DISPATCH_C(c, grid_for(tiles_for<CC>(n_nodes), resident_blocks_bwd<CC>(GADAPT_BWD_T_MAX_BLOCKS)));
 }
 extern "C" int64_t gadapt_backward_slab_floats(int64_t n_nodes, int c) {
     const int rows = gadapt_backward_slab_rows(n_nodes, c);
