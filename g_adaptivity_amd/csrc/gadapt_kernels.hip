@@ -66,6 +66,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GADAPT_FPL 8            // floats per lane at hidden >= 32.  16 (four lanes per node at hidden 64) measured: the row buffers
                                 // double, forward / target pass spill 36 / 117 registers (27.4 / 62.4 us), source pass 28.4 vs 26.2 us
 #endif
+#ifndef GADAPT_BWD_JIT_B_C
+#define GADAPT_BWD_JIT_B_C 1024  // backward kernels rebuild the projection fragments per tile from this hidden size on
+#endif
 #ifndef GADAPT_BWD_ONE_PER_CU
 #define GADAPT_BWD_ONE_PER_CU 1
 #endif
@@ -1332,7 +1335,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         auto slab_ptr = [&](int s_) __attribute__((always_inline)) { return ring + ((s_ + K::RING) % K::RING) * K::TILE_FLOATS; };
         typename CsrT::Regs sr;
         TileRows<C> xr, gr;
-        constexpr bool RESIDENT_B = TileGemm<C, true>::SPLIT;  // split fragments are built once per launch
+        constexpr bool RESIDENT_B = TileGemm<C, true>::SPLIT && C < GADAPT_BWD_JIT_B_C;  // split fragments are built once per launch
         if constexpr (K::MFMA && RESIDENT_B && !XC) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
         csr.load_metas(ch.t0, 1, p.n_tiles, tid);
         if constexpr (K::RING == 3) {
@@ -1656,7 +1659,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 #endif
     // split fragments: built once per launch - unless the dA accumulators need their 48 registers (DA: rebuilt per tile, in
     // flight under the barrier)
-    constexpr bool RESIDENT_B = K::MFMA && TileGemm<C, false>::SPLIT && GADAPT_S_RESIDENT_B && !DA;
+    constexpr bool RESIDENT_B = K::MFMA && TileGemm<C, false>::SPLIT && GADAPT_S_RESIDENT_B && !DA && C < GADAPT_BWD_JIT_B_C;
     if constexpr (RESIDENT_B) gemm.load(p.A, nullptr);
     const TileRange tr = tile_range(p.n_tiles);
     typename TileCsr<C, 2>::Regs sr;
@@ -2333,6 +2336,9 @@ template <int C> static constexpr int resident_blocks(int two_per_cu_default) { 
 // ... and the backward kernels of hidden sizes that run one wave per SIMD (GADAPT_ONE_WAVE_C: 392 / 504 registers) fit ONE
 // 256-thread workgroup per CU: 256 workgroups are the resident set, a 512-workgroup launch would run as two rounds (and
 // flush twice as many slab rows).
+template <int C> static constexpr int resident_blocks_fwd(int two_per_cu_default) {
+    return (C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_ONE_WAVE) ? 256 : resident_blocks<C>(two_per_cu_default);
+}
 template <int C> static constexpr int resident_blocks_bwd(int two_per_cu_default) {
     return (C >= GADAPT_ONE_WAVE_C && GADAPT_BWD_ONE_PER_CU) ? 256 : resident_blocks<C>(two_per_cu_default);
 }
@@ -2353,10 +2359,10 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
     constexpr int lds = K::lds_bytes(0, K::RING + 1);
     if (x_cols) {
         allow_lds(grand_fwd_kernel<C, true>, lds);
-        hipLaunchKernelGGL((grand_fwd_kernel<C, true>), dim3(grid_for(p.n_tiles, resident_blocks<C>(GADAPT_FWD_MAX_BLOCKS))), dim3(K::NT), lds, st, p);
+        hipLaunchKernelGGL((grand_fwd_kernel<C, true>), dim3(grid_for(p.n_tiles, resident_blocks_fwd<C>(GADAPT_FWD_MAX_BLOCKS))), dim3(K::NT), lds, st, p);
     } else {
         allow_lds(grand_fwd_kernel<C>, lds);
-        hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, resident_blocks<C>(GADAPT_FWD_MAX_BLOCKS))), dim3(K::NT), lds, st, p);
+        hipLaunchKernelGGL(grand_fwd_kernel<C>, dim3(grid_for(p.n_tiles, resident_blocks_fwd<C>(GADAPT_FWD_MAX_BLOCKS))), dim3(K::NT), lds, st, p);
     }
     return check_launch("grand_fwd_kernel");
 }
