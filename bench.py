@@ -32,6 +32,9 @@ WORKLOADS = {
     'poisson2d_32x32_b32_L4_C64': dict(n=32, batch=32, layers=4, hidden=64, conv='GRAND_plus', f=True, uu=True),
     'burgers2d_64x64_b32_L6_C128': dict(n=64, batch=32, layers=6, hidden=128, conv='GRAND', f=False, uu=True),
     'euler20_128x128_b16_C64': dict(n=128, batch=16, layers=20, hidden=64, conv='GRAND_plus', f=True, uu=True),
+    # not a BASELINE.json shape: the other hidden sizes of the fused kernels on the metric mesh batch (tuning runs)
+    'poisson2d_64x64_b32_L4_C32': dict(n=64, batch=32, layers=4, hidden=32, conv='GRAND_plus', f=True, uu=True),
+    'poisson2d_64x64_b32_L4_C8': dict(n=64, batch=32, layers=4, hidden=8, conv='GRAND_plus', f=True, uu=True),
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X fp32 matrix (= vector) peak, SURVEY.md §8(d)

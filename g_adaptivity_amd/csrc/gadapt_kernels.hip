@@ -2342,6 +2342,12 @@ template <int C> static constexpr int resident_blocks_fwd(int two_per_cu_default
 template <int C> static constexpr int resident_blocks_bwd(int two_per_cu_default) {
     return (C >= GADAPT_ONE_WAVE_C && GADAPT_BWD_ONE_PER_CU) ? 256 : resident_blocks<C>(two_per_cu_default);
 }
+// ... and the target pass at hidden 32 (128-row tiles: ring + dP tile + slices = 87 KB of LDS) fits one workgroup per CU too
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor: forward / target / source = 2 / 1 / 2 at hidden 32, 2 / 2 / 2 at 64,
+// 2 / 1 / 1 at 128, 3 / 3 / 3 at 8).
+template <int C> static constexpr int resident_blocks_bwd_t(int two_per_cu_default) {
+    return (C == 32 && GADAPT_BWD_ONE_PER_CU) ? 256 : resident_blocks_bwd<C>(two_per_cu_default);
+}
 
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                                        const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st) {
@@ -2417,7 +2423,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
             ProfScope prof(6, st, 0);
             constexpr int lds_f = fused_bwd_lds_bytes<C>();
             allow_lds(grand_bwd_fused_kernel<C>, lds_f);
-            hipLaunchKernelGGL(grand_bwd_fused_kernel<C>, dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(256), lds_f, st, pf);
+            hipLaunchKernelGGL(grand_bwd_fused_kernel<C>, dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(256), lds_f, st, pf);
             return check_launch("grand_bwd_fused_kernel");
         }
     }
@@ -2429,25 +2435,25 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
         if constexpr (CAN_MOVE_DA) {
             if (da_in_s && g_cols) {
                 allow_lds(grand_bwd_target_kernel<C, false, true, false, false>, lds_t);
-                hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true, false, false>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+                hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true, false, false>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
             } else if (da_in_s) {
                 allow_lds(grand_bwd_target_kernel<C, false, false, false, false>, lds_t);
-                hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, false, false>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+                hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, false, false>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
             }
         }
         if (da_in_s) {
         } else if (x_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, false, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else if (g_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else if (sums_out) {
             allow_lds(grand_bwd_target_kernel<C, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, true>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else {
             allow_lds(grand_bwd_target_kernel<C, false>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         }
         rc = check_launch("grand_bwd_target_kernel");
     }
@@ -2529,7 +2535,7 @@ extern "C" int gadapt_layer_forward(const gadapt_graph* g, const float* x_in, fl
 template <int C> static int tiles_for(int64_t n_nodes) { return (int)((n_nodes + Cfg<C>::TM - 1) / Cfg<C>::TM); }
 extern "C" int gadapt_backward_slab_rows(int64_t n_nodes, int c) {
     if (n_nodes <= 0) return fail(GADAPT_E_BADARG, "slab_rows: bad node count");
-    GADAPT_DISPATCH_C(c, grid_for(tiles_for<CC>(n_nodes), resident_blocks_bwd<CC>(GADAPT_BWD_T_MAX_BLOCKS)));
+    GADAPT_DISPATCH_C(c, grid_for(tiles_for<CC>(n_nodes), resident_blocks_bwd_t<CC>(GADAPT_BWD_T_MAX_BLOCKS)));
 }
 extern "C" int64_t gadapt_backward_slab_floats(int64_t n_nodes, int c) {
     const int rows = gadapt_backward_slab_rows(n_nodes, c);
