@@ -66,6 +66,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GADAPT_FPL 8            // floats per lane at hidden >= 32.  16 (four lanes per node at hidden 64) measured: the row buffers
                                 // double, forward / target pass spill 36 / 117 registers (27.4 / 62.4 us), source pass 28.4 vs 26.2 us
 #endif
+#ifndef GADAPT_T_RING_MAX_C
+#define GADAPT_T_RING_MAX_C 128   // target pass: largest hidden size that keeps the rolling LDS window of x rows
+#endif
 #ifndef GADAPT_BWD_JIT_B_C
 #define GADAPT_BWD_JIT_B_C 1024  // backward kernels rebuild the projection fragments per tile from this hidden size on
 #endif
@@ -246,6 +249,10 @@ template <int C> struct Cfg {
     static constexpr int RING = (C <= 64) ? 3 : 1;     // LDS slabs of x rows kept by the rolling-window kernels; C = 128: a
                                                        //   3-slab window would leave one workgroup per CU, so only the tile itself
     static constexpr int LEAD = (RING == 3) ? 1 : 0;   // the slab staged during tile t is slab t + LEAD
+    // The target pass keeps the window at hidden 128 too: its 392 registers allow one workgroup per CU whatever the LDS
+    // footprint is (4 tiles of 33 KB + slices = 145 KB), and at one wave per SIMD an L2 gather is fully exposed latency.
+    static constexpr int RING_T = (C <= GADAPT_T_RING_MAX_C) ? 3 : 1;
+    static constexpr int LEAD_T = (RING_T == 3) ? 1 : 0;
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -565,15 +572,15 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
     }
     // Float offset, inside a RING-slab LDS ring, of the row of node j when slabs t-1, t, t+1 are resident
     // (slab s lives in slot s % RING).
-    static __device__ __forceinline__ int ring_off(int j, int t) {
-        int slot = (t + K::RING - 1) % K::RING + (j / K::TM - (t - 1));
-        if (slot >= K::RING) slot -= K::RING;
+    template <int RINGN = K::RING> static __device__ __forceinline__ int ring_off(int j, int t) {
+        int slot = (t + RINGN - 1) % RINGN + (j / K::TM - (t - 1));
+        if (slot >= RINGN) slot -= RINGN;
         return slot * K::TILE_FLOATS + (j % K::TM) * K::LD;
     }
     // LDS writes of a previously issued tile; returns its row-length bound (-1: slow tile).  Caller barriers.
     // windowed_tile >= 0: the tile's neighbours all live in slabs t-1..t+1 (metadata word 3): store ring offsets
     // instead of node ids so the gathers read LDS directly.
-    __device__ __forceinline__ int commit(const Regs& r, int tid, int node0_pad, int windowed_tile = -1) {
+    template <int RINGN = K::RING> __device__ __forceinline__ int commit(const Regs& r, int tid, int node0_pad, int windowed_tile = -1) {
         static_assert(K::TM + 1 <= 2 * K::NT, "rowptr slice: at most 2 entries per thread");
         ebase = r.meta.x;
         if (tid <= K::TM) rp[tid] = r.rpv;
@@ -583,7 +590,7 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
             const int idx = q * K::NT + tid;
             const int cnt = min(r.meta.y, K::CAP);
             const int jv = (idx < cnt) ? r.colv[q] : node0_pad;       // padding entries: a valid node of this tile
-            if (idx < K::CAP + GADAPT_MAXD) col[idx] = (windowed_tile >= 0) ? ring_off(jv, windowed_tile) : jv;
+            if (idx < K::CAP + GADAPT_MAXD) col[idx] = (windowed_tile >= 0) ? ring_off<RINGN>(jv, windowed_tile) : jv;
             if constexpr (EXT > 0) { if (idx < K::CAP + GADAPT_MAXD) ext[idx] = r.extv[q]; }
             if constexpr (AUXW > 0) {
 #pragma unroll
@@ -1155,7 +1162,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
     using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
     float* ring = reinterpret_cast<float*>(smem4);
-    float* ds = ring + K::RING * K::TILE_FLOATS;                // g tile -> dP tile -> dP A
+    float* ds = ring + K::RING_T * K::TILE_FLOATS;              // g tile -> dP tile -> dP A
     using CsrT = TileCsr<C, 1, 1>;                              // aux = forward alpha (target order), ext = tpos
     CsrT csr;
     csr.bind(ds + K::TILE_FLOATS, p.rowptr, p.col, p.alpha, p.meta, p.n_edges, p.tpos);
@@ -1332,13 +1339,13 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
     const TileChunk ch = tile_chunk(p.n_tiles);                 // an empty chunk still flushes its (zero) slab row
     if (ch.t0 < ch.t1) {
         stagger_start<GADAPT_STAGGER_T>();
-        auto slab_ptr = [&](int s_) __attribute__((always_inline)) { return ring + ((s_ + K::RING) % K::RING) * K::TILE_FLOATS; };
+        auto slab_ptr = [&](int s_) __attribute__((always_inline)) { return ring + ((s_ + K::RING_T) % K::RING_T) * K::TILE_FLOATS; };
         typename CsrT::Regs sr;
         TileRows<C> xr, gr;
         constexpr bool RESIDENT_B = TileGemm<C, true>::SPLIT && C < GADAPT_BWD_JIT_B_C;  // split fragments are built once per launch
         if constexpr (K::MFMA && RESIDENT_B && !XC) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
         csr.load_metas(ch.t0, 1, p.n_tiles, tid);
-        if constexpr (K::RING == 3) {
+        if constexpr (K::RING_T == 3) {
             xr.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xr.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
             xr.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xr.template commit_sel<XC>(slab_ptr(ch.t0), p.n_nodes, tid);
         }
@@ -1346,7 +1353,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         // C = 128 has no registers to hold a tile across the edge walk: it stages at the top of the tile instead
         constexpr bool PREFETCH = (C <= GADAPT_T_PREFETCH_MAX_C);
         if constexpr (PREFETCH) {
-            xr.template issue_sel<XC>(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);
+            xr.template issue_sel<XC>(p.x_in, (ch.t0 + K::LEAD_T) * K::TM, p.n_nodes, tid);
             if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, ch.t0 * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, ch.t0 * K::TM, p.n_nodes, tid);
             csr.issue(sr, 0, ch.t0 * K::TM, p.n_nodes, tid);
         }
@@ -1355,7 +1362,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             const int node0 = t * K::TM;
             const int tslot = (t - ch.t0) * 8;
             if constexpr (!PREFETCH) {
-                xr.template issue_sel<XC>(p.x_in, (t + K::LEAD) * K::TM, p.n_nodes, tid);
+                xr.template issue_sel<XC>(p.x_in, (t + K::LEAD_T) * K::TM, p.n_nodes, tid);
                 if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, t * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, t * K::TM, p.n_nodes, tid);
                 csr.issue(sr, t - ch.t0, t * K::TM, p.n_nodes, tid);
             }
@@ -1364,10 +1371,10 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 #endif
             GADAPT_STAMP(p.stamps, tslot + 0);
             xs = slab_ptr(t);
-            const bool win = K::RING == 3 && sr.meta.w != 0;
-            xr.template commit_sel<XC>(slab_ptr(t + K::LEAD), p.n_nodes, tid);
+            const bool win = K::RING_T == 3 && sr.meta.w != 0;
+            xr.template commit_sel<XC>(slab_ptr(t + K::LEAD_T), p.n_nodes, tid);
             gr.commit(ds, p.n_nodes, tid);
-            const int dmax = csr.commit(sr, tid, node0, win ? t : -1);
+            const int dmax = csr.template commit<K::RING_T>(sr, tid, node0, win ? t : -1);
             GADAPT_STAMP(p.stamps, tslot + 1);
             __syncthreads();
             if constexpr (!XC) { if (t > ch.t0) store_dxd(node0 - K::TM); }   // previous tile's result: see store_dxd
@@ -1392,7 +1399,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                 // request the next tile (unconditional, clamped past the end: see issue()).  Here rather than at the top
                 // of the tile: the edge phase needs every register, and the MFMA phases below cover the round trip.
                 csr.issue(sr, t + 1 - ch.t0, (t + 1) * K::TM, p.n_nodes, tid);
-                xr.template issue_sel<XC>(p.x_in, (t + 1 + K::LEAD) * K::TM, p.n_nodes, tid);
+                xr.template issue_sel<XC>(p.x_in, (t + 1 + K::LEAD_T) * K::TM, p.n_nodes, tid);
                 if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, (t + 1) * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, (t + 1) * K::TM, p.n_nodes, tid);
             }
             __syncthreads();
@@ -2403,7 +2410,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
 #ifdef GADAPT_STAMPS
     pt.stamps = g_stamp_buf ? g_stamp_buf + 1024 * 32 : nullptr;
 #endif
-    constexpr int lds_t = K::lds_bytes(1, K::RING + 1, 1), lds_s = K::lds_bytes(2);
+    constexpr int lds_t = K::lds_bytes(1, K::RING_T + 1, 1), lds_s = K::lds_bytes(2);
     int rc;
     if constexpr (C == 32 || C == 64) {
         // dense layer with a gradient to pass on: node pass for D + ONE fused kernel (gadapt_fused_bwd.inc) instead of the
@@ -2515,7 +2522,7 @@ extern "C" int gadapt_debug_occupancy(int c, int* out3) {
     case CC: {                                                                                                          \
         using K = Cfg<CC>;                                                                                              \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_kernel<CC>, K::NT, K::lds_bytes(0, K::RING + 1)); \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC, false>, K::NT, K::lds_bytes(1, K::RING + 1, 1)); \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC, false>, K::NT, K::lds_bytes(1, K::RING_T + 1, 1)); \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], grand_bwd_source_kernel<CC>, K::NT, K::lds_bytes(2)); \
         return GADAPT_OK;                                                                                               \
     }
