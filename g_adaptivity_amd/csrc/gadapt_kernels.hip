@@ -66,6 +66,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GADAPT_FPL 8            // floats per lane at hidden >= 32.  16 (four lanes per node at hidden 64) measured: the row buffers
                                 // double, forward / target pass spill 36 / 117 registers (27.4 / 62.4 us), source pass 28.4 vs 26.2 us
 #endif
+#ifndef GADAPT_T_TWO_BUFFERS
+#define GADAPT_T_TWO_BUFFERS 0     // 1: one-wave target pass (hidden 128) with two row buffers in the edge walk; measured 128.0 vs 128.3 us
+#endif
 #ifndef GADAPT_T_RING_MAX_C
 #define GADAPT_T_RING_MAX_C 128   // target pass: largest hidden size that keeps the rolling LDS window of x rows
 #endif
@@ -717,9 +720,9 @@ template <int V> struct IntTag { static constexpr int value = V; };
 // Software pipeline over the ITERS node slots of a tile: rows of slot it+1 are requested before slot it
 // is consumed.  `before_first` runs after the first request (e.g. the MFMA phase).  The widest row
 // bound keeps a single buffer: two would cost a wave of occupancy for every tile shape.
-template <int ITERS, typename BufT, typename Fetch, typename Consume, typename Mid>
+template <int ITERS, typename BufT, bool TWO_BUFFERS = false, typename Fetch, typename Consume, typename Mid>
 __device__ __forceinline__ void run_pipeline(Fetch&& fetch, Consume&& consume, Mid&& before_first) {
-    if constexpr (sizeof(BufT) <= 128) {                        // two buffers only while one stays within 32 VGPRs
+    if constexpr (sizeof(BufT) <= 128 || TWO_BUFFERS) {         // two buffers only while one stays within 32 VGPRs (or on request)
         BufT b0, b1;
         fetch(b0, 0);
         before_first();
@@ -1383,7 +1386,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             if (dmax >= 0) {
                 dispatch_dmax(dmax, [&](auto tag) {
                     auto walk = [&](auto win_tag) __attribute__((always_inline)) {
-                        run_pipeline<K::ITERS, TBuf<decltype(tag)::value, K::NV>>(
+                        run_pipeline<K::ITERS, TBuf<decltype(tag)::value, K::NV>, (C >= GADAPT_ONE_WAVE_C && GADAPT_T_TWO_BUFFERS)>(
                             [&](auto& b, int it) { fetch(b, node0, it, win_tag); },
                             [&](const auto& b, int it) { consume(b, node0, it); },
                             [&]() {});
