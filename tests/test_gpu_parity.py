@@ -34,6 +34,12 @@ CASES = [
     ((13, 13), 2, 64, 2, 'GRAND_plus', {'softmax_temp_type': 'fixed', 'softmax_temp': 2.0}),
     ((10, 10), 2, 64, 2, 'GRAND_plus', {'fix_boundary': False, 'self_loops': True}),   # in-degree 7 rows
     ((21,), 3, 8, 3, 'GRAND', {'gnn_inc_feat_f': False}),                               # Burgers features (params.py:148,155)
+    # option combinations of GNN.forward: no residual update (GNN.py:293-296), normalised raw features (GNN.py:230-238),
+    # per-layer learnable steps with unshared convs (GNN.py:179-180,288-289), 1-D without the boundary surgery
+    ((12, 12), 2, 16, 3, 'GRAND', {'residual': False, 'non_lin': 'tanh'}),
+    ((12, 12), 2, 64, 2, 'GRAND_plus', {'gnn_normalize': True}),
+    ((11, 11), 2, 32, 3, 'GRAND_plus', {'learn_step': True, 'share_conv': False}),
+    ((17,), 4, 16, 2, 'GRAND_plus', {'fix_boundary': False}),
     # BASELINE config 4 shape: 64x64, 6 layers, hidden 128, GRAND, features [x, y, uu] (two meshes: the oracle stays quick)
     ((64, 64), 2, 128, 6, 'GRAND', {'gnn_inc_feat_f': False, 'noise_factor': 3.0}),
     # BASELINE config 5 shape: 128x128 mesh, 20 Euler steps, hidden 64 (one mesh): 128-node mesh rows exceed the LDS window,
@@ -66,7 +72,14 @@ def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, c
     oracle, o64, model, ref, ref64, out = _run(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra)
     nf = extra.get('noise_factor', 1.5)
     norm, elem = rel_err(out, ref)
-    assert norm <= COORD_TOL and elem <= COORD_TOL, f"x_phys vs fp32 oracle: normwise {norm:.2e} elementwise {elem:.2e}"
+    if extra.get('residual', True):
+        assert norm <= COORD_TOL and elem <= COORD_TOL, f"x_phys vs fp32 oracle: normwise {norm:.2e} elementwise {elem:.2e}"
+    else:
+        # without the residual update the output is non_lin(A(x)x - x) itself (GNN.py:293-296): small entries are what is left
+        # of a cancellation, so elementwise the bar is the fp32 oracle's own error against fp64, as for the TRANS conv
+        elem64, noise_elem = rel_err(out, ref64)[1], rel_err(ref, ref64)[1]
+        assert norm <= COORD_TOL and elem64 <= max(COORD_TOL, 2.0 * noise_elem), \
+            f"output vs oracle: normwise {norm:.2e}, elementwise vs fp64 {elem64:.2e} (fp32 oracle: {noise_elem:.2e})"
     assert rel_err(out, ref64)[0] <= COORD_TOL
     n_layers = len({id(l) for l in model.conv_layers})
     for li in range(n_layers):
