@@ -1053,9 +1053,11 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
     TileRows<C> xrA, xrB;
     if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, p.p0);   // B fragments stay in registers for the whole launch
     csr.load_metas(ch.t0, 1, p.n_tiles, tid);
-    if constexpr (K::RING == 3) {
-        xrA.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xrA.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
-        xrA.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xrA.template commit_sel<XC>(slab_ptr(ch.t0), p.n_nodes, tid);
+    if constexpr (K::RING == 3) {                                // the two slabs of the window's start: ONE memory round trip
+        xrA.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid);
+        xrB.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid);
+        xrA.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
+        xrB.template commit_sel<XC>(slab_ptr(ch.t0), p.n_nodes, tid);
     }
     __syncthreads();                                             // tile metadata visible
     xrA.template issue_sel<XC>(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);   // rows past N come back as zeros
@@ -1348,9 +1350,11 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         constexpr bool RESIDENT_B = TileGemm<C, true>::SPLIT && C < GADAPT_BWD_JIT_B_C;  // split fragments are built once per launch
         if constexpr (K::MFMA && RESIDENT_B && !XC) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
         csr.load_metas(ch.t0, 1, p.n_tiles, tid);
-        if constexpr (K::RING_T == 3) {
-            xr.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid); xr.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
-            xr.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid); xr.template commit_sel<XC>(slab_ptr(ch.t0), p.n_nodes, tid);
+        if constexpr (K::RING_T == 3) {                          // the two slabs of the window's start: ONE memory round trip
+            xr.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid);           // (gr is free until the first g tile)
+            gr.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid);
+            xr.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
+            gr.template commit_sel<XC>(slab_ptr(ch.t0), p.n_nodes, tid);
         }
         __syncthreads();                                        // tile metadata visible
         // C = 128 has no registers to hold a tile across the edge walk: it stages at the top of the tile instead
