@@ -532,8 +532,16 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
     // meta_at(k): a per-tile global load would be moved to SGPRs by hipcc (v_readfirstlane) and its s_waitcnt,
     // vmcnt being in-order, would also wait for every older load - the GEMM's B fragments.  Caller barriers.
     __device__ __forceinline__ void load_metas(int first, int step, int n_tiles, int tid) {
+        metas_commit(metas_issue(first, step, n_tiles, tid), tid);
+    }
+    // The same in two halves, so a kernel's prologue can put this load in ONE memory round trip with its other first loads
+    // (window slabs, weight fragments): request everything, then consume - vmcnt is in-order, the first wait covers all.
+    __device__ __forceinline__ int4 metas_issue(int first, int step, int n_tiles, int tid) {
         m_first = first; m_step = step; m_ntiles = n_tiles;
-        if (tid < K::MAXM) metas[tid] = meta_g[min(first + tid * step, n_tiles - 1)];
+        return meta_g[min(first + min(tid, K::MAXM - 1) * step, n_tiles - 1)];      // unconditional (see issue())
+    }
+    __device__ __forceinline__ void metas_commit(const int4& m, int tid) {
+        if (tid < K::MAXM) metas[tid] = m;
     }
     // pure LDS read (the launch grid guarantees at most MAXM tiles per workgroup): a global-load fallback here,
     // even on a never-taken branch, makes hipcc wait vmcnt(0) at the join in every tile
@@ -1051,11 +1059,16 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
     constexpr bool RESIDENT_B = (C <= 64) || (C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_ONE_WAVE);
     typename TileCsr<C, 0>::Regs srA, srB;
     TileRows<C> xrA, xrB;
-    if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, p.p0);   // B fragments stay in registers for the whole launch
-    csr.load_metas(ch.t0, 1, p.n_tiles, tid);
-    if constexpr (K::RING == 3) {                                // the two slabs of the window's start: ONE memory round trip
+    // prologue loads in ONE memory round trip: the two slabs of the window's start, the tile metadata, the weight
+    // fragments - all requested before the first use (the fragment split) waits
+    if constexpr (K::RING == 3) {
         xrA.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid);
         xrB.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid);
+    }
+    const int4 mreg = csr.metas_issue(ch.t0, 1, p.n_tiles, tid);
+    if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, p.p0);   // B fragments stay in registers for the whole launch
+    csr.metas_commit(mreg, tid);
+    if constexpr (K::RING == 3) {
         xrA.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
         xrB.template commit_sel<XC>(slab_ptr(ch.t0), p.n_nodes, tid);
     }
@@ -1348,11 +1361,16 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         typename CsrT::Regs sr;
         TileRows<C> xr, gr;
         constexpr bool RESIDENT_B = TileGemm<C, true>::SPLIT && C < GADAPT_BWD_JIT_B_C;  // split fragments are built once per launch
-        if constexpr (K::MFMA && RESIDENT_B && !XC) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
-        csr.load_metas(ch.t0, 1, p.n_tiles, tid);
-        if constexpr (K::RING_T == 3) {                          // the two slabs of the window's start: ONE memory round trip
-            xr.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid);           // (gr is free until the first g tile)
+        // prologue loads in ONE memory round trip: the two slabs of the window's start (gr is free until the first g tile),
+        // the tile metadata, the weight fragments - all requested before the first use (the fragment split) waits
+        if constexpr (K::RING_T == 3) {
+            xr.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid);
             gr.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid);
+        }
+        const int4 mreg = csr.metas_issue(ch.t0, 1, p.n_tiles, tid);
+        if constexpr (K::MFMA && RESIDENT_B && !XC) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
+        csr.metas_commit(mreg, tid);
+        if constexpr (K::RING_T == 3) {
             xr.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
             gr.template commit_sel<XC>(slab_ptr(ch.t0), p.n_nodes, tid);
         }
@@ -1686,10 +1704,11 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
     // split fragments: built once per launch - unless the dA accumulators need their 48 registers (DA: rebuilt per tile, in
     // flight under the barrier)
     constexpr bool RESIDENT_B = K::MFMA && TileGemm<C, false>::SPLIT && GADAPT_S_RESIDENT_B && !DA && C < GADAPT_BWD_JIT_B_C;
-    if constexpr (RESIDENT_B) gemm.load(p.A, nullptr);
     const TileRange tr = tile_range(p.n_tiles);
     typename TileCsr<C, 2>::Regs sr;
-    csr.load_metas(tr.t, tr.step, p.n_tiles, tid);
+    const int4 mreg = csr.metas_issue(tr.t, tr.step, p.n_tiles, tid);   // one round trip with the fragment loads
+    if constexpr (RESIDENT_B) gemm.load(p.A, nullptr);
+    csr.metas_commit(mreg, tid);
     __syncthreads();
     int kt = 0;                                                 // index of the tile in this workgroup's sequence
     if (tr.t < tr.t_end) csr.issue(sr, 0, tr.t * K::TM, p.n_nodes, tid);
