@@ -394,14 +394,123 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int C, bool TRANS> struct TileGemm {
+// Two-piece f16 form (GADAPT_SPLIT_F16_*; where it is used: see below): the operand block is first multiplied by a power of two that brings its
+// largest magnitude into [2^14, 2^15) - exact, and it puts the whole block into f16's range - then x = h + l with
+// h = f16(x) and l = f16(x - h), round to nearest: 22 to 23 significant bits, |x - h - l| <= 2^-23 |x| or 2^-25 (f16's
+// subnormal spacing, i.e. 2^-39 of the block's maximum), whichever is larger.  Products: hh + hl + lh (ll is below 2^-22
+// of |x y| and 2^-24 on average, the rounding level of an fp32 product), every piece product exact in the fp32
+// accumulator; the result is multiplied by the inverse powers of two.  Against the three-piece bf16 form (split8): half
+// the matrix instructions (3 per 16 k instead of 6), 24 instead of 44 vector instructions per 8 values, fragments of 8
+// instead of 12 registers per k-step; in exchange a maximum per scale group per use.  Scale groups follow the operand
+// layout so that they cost two or three cross-lane steps and no wave-wide reduction (a first version with one scale per
+// wave block - DPP reduction, readfirstlane - serialised every matrix phase behind it and was slower than the bf16 form):
+// the A operand (lane (i, h): row i, half h of each k-step) shares a scale between FOUR consecutive rows - quad DPP and
+// one half swap - because the 32x32 output layout gives a lane four consecutive rows per register quad, so it fetches four
+// inverses (ds_bpermute) instead of sixteen; the B operand (lane (j, h): column j) has one scale per column, lane-local
+// after the half swap.  An entry 2^-q below its group's maximum keeps min(23, 39 - q) bits.
+// Measured (MI355X, same box, us per launch, bf16 three-piece -> f16 two-piece): source pass 26.8 -> 25.9 (hidden 64),
+// 86.5 -> 83.4 (hidden 128); tiled forward 61.0 -> 60.3 (hidden 128); wide forward 17.9 -> 18.0; target pass 32.6 -> 34.6
+// (hidden 64), 96.4 -> 98.6 (hidden 128): the f16 form has to hold a whole operand block until its maximum is known, where the
+// bf16 form streams k-step by k-step, and the target pass has neither the registers (3 spills) nor the slack for that.  With
+// the scales known in advance (diagnostic build, unit scale) the target pass would gain 0.9 / 7 us - not pursued.
+// Tiled forward at hidden 64 (128-wide meshes): 50.1 -> 52.0; at hidden 32: 12.6 -> 12.4.
+// So: on for the source pass and for the tiled forward at hidden 32 / 128, off for the target pass and the wide forward.
+#ifndef GADAPT_SPLIT_F16_S
+#define GADAPT_SPLIT_F16_S 1        // source pass A y
+#endif
+#ifndef GADAPT_SPLIT_F16_F
+#define GADAPT_SPLIT_F16_F(C) ((C) != 64)   // tiled forward P = x A^T
+#endif
+#ifndef GADAPT_SPLIT_F16_T
+#define GADAPT_SPLIT_F16_T 0        // TileGemm<C, true> and the dA phase: target pass
+#endif
+#ifndef GADAPT_SPLIT_F16_WIDE
+#define GADAPT_SPLIT_F16_WIDE 0     // wide forward (gadapt_wide.inc)
+#endif
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+struct Split2 { u32x4 h, l; };
+struct Pow2 { float s, inv; };
+// largest power-of-two scale that keeps mx below 2^15, and its inverse (both normal fp32 numbers for every mx)
+__device__ __forceinline__ Pow2 pow2_scale(float mx) {
+    int e = (int)((__float_as_uint(mx) >> 23) & 0xFFu);
+    e = min(max(e, 15), 254);
+    return {__uint_as_float((unsigned)(268 - e) << 23), __uint_as_float((unsigned)(e - 14) << 23)};
+}
+template <int CTRL> __device__ __forceinline__ float dpp_max(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+    return fmaxf(v, __builtin_bit_cast(float, moved));
+}
+// max(v(lane), v(lane ^ 32)), in both lanes
+__device__ __forceinline__ float half_max(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+// scale of an A-operand lane (row r31, half h): maximum over the four rows 4 (r31 / 4) .. + 3 and both halves
+__device__ __forceinline__ float quad_rows_max(float v) {
+#ifdef GADAPT_ABL_FIXED_SCALE
+    return 1.0f;
+#endif
+    v = dpp_max<0xB1>(v); v = dpp_max<0x4E>(v);
+    return half_max(v);
+}
+// the four inverse scales a lane of the 32x32 output needs: register r holds row (r & 3) + 8 (r >> 2) + 4 h, i.e. row quad
+// 2 (r >> 2) + h, whose scale sits in lane 8 (r >> 2) + 4 h of the A operand
+__device__ __forceinline__ void quad_rows_inverse(float inv, int h, float (&out)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        out[q] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(32 * q + 16 * h, __builtin_bit_cast(int, inv)));
+}
+// maximum of a non-negative value over the wave, wave-uniform (scalar register)
+__device__ __forceinline__ float wave_max(float v) {
+#ifdef GADAPT_ABL_FIXED_SCALE
+    return 1.0f;                                        // diagnostic build (timing only): no reduction, unit scale
+#endif
+    v = dpp_max<0xB1>(v); v = dpp_max<0x4E>(v); v = dpp_max<0x141>(v); v = dpp_max<0x140>(v);     // rows of 16 lanes
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F)));   // xor 16
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));                   // xor 32
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fmaxf(a, b))));
+}
+__device__ __forceinline__ float absmax8(const float (&x)[8], float m) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(x[e]));
+    return m;
+}
+__device__ __forceinline__ Split2 split8h(const float (&x)[8], float s) {
+    Split2 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                       // element 2q in the low half, 2q+1 in the high half
+        const float t0 = x[2 * q] * s, t1 = x[2 * q + 1] * s;
+        f16x2 h; h.x = (_Float16)t0; h.y = (_Float16)t1;
+        f16x2 l; l.x = (_Float16)(t0 - (float)h.x); l.y = (_Float16)(t1 - (float)h.y);   // the differences are exact
+        r.h[q] = __builtin_bit_cast(unsigned, h);
+        r.l[q] = __builtin_bit_cast(unsigned, l);
+    }
+    return r;
+}
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma3(const Split2& a, const Split2& b, f32x16 c) {
+    c = mfma_f16(a.h, b.l, c);                          // small pieces first
+    c = mfma_f16(a.l, b.h, c);
+    return mfma_f16(a.h, b.h, c);
+}
+
+template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct TileGemm {
     using K = Cfg<C>;
     static constexpr int BPW = (K::CB * K::RB) / K::NW;   // 32x32 output blocks per wave
     static_assert(!K::MFMA || ((K::CB * K::RB) % K::NW == 0 && K::NW % K::CB == 0), "output blocks split evenly over the waves");
     static constexpr bool SPLIT = GADAPT_GEMM_SPLIT && C <= GADAPT_SPLIT_MAX_C;
     static constexpr int KS = C / 16;                  // k-steps of the bf16 form
+    static constexpr bool F16 = SPLIT && F16_;
     float bf[SPLIT ? 1 : C / 2];
-    Split3 bs[SPLIT ? KS : 1];
+    Split3 bs[(SPLIT && !F16) ? KS : 1];
+    Split2 bh[F16 ? KS : 1];
+    float binv;                                        // F16: inverse scale of this lane's B column
+    float oinv[BPW][4];                                // F16: inverse of (A scale x B scale) of the last accumulate: output block, row quad
     float bias;
     int cb, rb0, lane;
 
@@ -413,7 +522,28 @@ template <int C, bool TRANS> struct TileGemm {
     // Issue the B-operand loads ([C,C] matrix: L2-resident, same lines for every workgroup).
     __device__ __forceinline__ void load(const float* __restrict__ M, const float* __restrict__ bias_vec) {
         const int h = lane >> 5, j = cb * 32 + (lane & 31);
-        if constexpr (SPLIT) {
+        if constexpr (F16) {
+            float v[KS][8];
+            float mx = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (!TRANS) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(M + (size_t)j * C + 16 * ks + 8 * h);
+                    const float4 v1 = *reinterpret_cast<const float4*>(M + (size_t)j * C + 16 * ks + 8 * h + 4);
+                    v[ks][0] = v0.x; v[ks][1] = v0.y; v[ks][2] = v0.z; v[ks][3] = v0.w;
+                    v[ks][4] = v1.x; v[ks][5] = v1.y; v[ks][6] = v1.z; v[ks][7] = v1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[ks][e] = M[(size_t)(16 * ks + 8 * h + e) * C + j];
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) mx = absmax8(v[ks], mx);
+            const Pow2 sb = pow2_scale(half_max(mx));
+            binv = sb.inv;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bh[ks] = split8h(v[ks], sb.s);
+        } else if constexpr (SPLIT) {
             // lane (j, h) holds B[k][j] for k = 16 ks + 8 h + e, e = 0..7 (both operands use this k order)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -444,14 +574,42 @@ template <int C, bool TRANS> struct TileGemm {
     }
 
     // in_tile/out_tile: LDS [TM][LD].  Caller synchronises around it.
-    __device__ __forceinline__ void accumulate(const float* in_tile, f32x16 (&acc)[BPW]) const {
+    __device__ __forceinline__ void accumulate(const float* in_tile, f32x16 (&acc)[BPW]) {
         const int h = lane >> 5, r31 = lane & 31;
 #pragma unroll
         for (int b = 0; b < BPW; ++b) {
             const int rb = rb0 + b * (K::NW / K::CB);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-            if constexpr (SPLIT) {
+            if constexpr (F16) {
+                const float* arow = in_tile + (rb * 32 + r31) * K::LD + 8 * h;
+                auto rd = [&](int ks, float (&v)[8]) __attribute__((always_inline)) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * ks);
+                    const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * ks + 4);
+                    v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+                };
+                float mx = 0.f;
+                if constexpr (KS <= 4) {                               // the block's rows stay in registers between the two uses
+                    float v[KS][8];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) rd(ks, v[ks]);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) mx = absmax8(v[ks], mx);
+                    const Pow2 sa = pow2_scale(quad_rows_max(mx));
+                    quad_rows_inverse(sa.inv, h, oinv[b]);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) acc[b] = mma3(split8h(v[ks], sa.s), bh[ks], acc[b]);
+                } else {                                               // hidden 128: read twice rather than hold 64 registers
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) { float v[8]; rd(ks, v); mx = absmax8(v, mx); }
+                    const Pow2 sa = pow2_scale(quad_rows_max(mx));
+                    quad_rows_inverse(sa.inv, h, oinv[b]);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) { float v[8]; rd(ks, v); acc[b] = mma3(split8h(v, sa.s), bh[ks], acc[b]); }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) oinv[b][q] *= binv;
+            } else if constexpr (SPLIT) {
                 const float* arow = in_tile + (rb * 32 + r31) * K::LD + 8 * h;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -488,17 +646,17 @@ template <int C, bool TRANS> struct TileGemm {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                ocol[row * K::LD] = acc[b][r] + bias;
+                ocol[row * K::LD] = F16 ? fmaf(acc[b][r], oinv[b][r >> 2], bias) : acc[b][r] + bias;
             }
         }
     }
-    __device__ __forceinline__ void run(const float* in_tile, float* out_tile) const {
+    __device__ __forceinline__ void run(const float* in_tile, float* out_tile) {
         f32x16 acc[BPW];
         accumulate(in_tile, acc);
         store(out_tile, acc);
     }
     // out == in: every wave reads its operand rows before any wave overwrites them (two workgroup barriers inside)
-    __device__ __forceinline__ void run_in_place(float* tile) const {
+    __device__ __forceinline__ void run_in_place(float* tile) {
         f32x16 acc[BPW];
         accumulate(tile, acc);
         __syncthreads();
@@ -910,7 +1068,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
     float* xs = ring;                                            // slab of the current tile (set per tile)
     bool win = false;                                            // current tile gathers from the LDS ring
 
-    TileGemm<C, false> gemm;
+    TileGemm<C, false, GADAPT_SPLIT_F16_F(C)> gemm;
     float arow[K::MFMA ? 1 : 4][K::MFMA ? 1 : C];
     float4 p0v = f4zero();
     if constexpr (K::MFMA) {
@@ -1437,6 +1595,50 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             if (p.n_nodes >= 0) {} else                          // diagnostic build: the dA phase never runs
 #endif
             if constexpr (!DA) {
+            } else if constexpr (K::MFMA && TileGemm<C, true>::F16) {
+                // two-piece f16 form (see split8h): k = node, 16 nodes per step; lane (i, h) feeds nodes 8h..8h+7 of the step.
+                // Scales: per quad of dP channels and per x channel over this wave's nodes; fresh accumulator per tile.
+                const int h = lane >> 5, r31 = lane & 31;
+                constexpr int NODES = (NB2 >= K::NW) ? K::TM : K::TM / 4;   // one 32x32 block: the waves split the nodes
+                constexpr int KSN = NODES / 16;
+                const int nbase = (NB2 >= K::NW) ? 0 : wave * NODES;
+                const int ob = (NB2 >= K::NW) ? (wave * DPW) / K::CB : 0, cb0 = (NB2 >= K::NW) ? (wave * DPW) % K::CB : 0;
+                Split2 as[KSN];
+                float ainv[4];
+                {
+                    float av[KSN][8];
+                    float mx = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) av[ks][e] = ds[(nbase + 16 * ks + 8 * h + e) * K::LD + ob * 32 + r31];
+#pragma unroll
+                    for (int ks = 0; ks < KSN; ++ks) mx = absmax8(av[ks], mx);
+                    const Pow2 sa = pow2_scale(quad_rows_max(mx));
+                    quad_rows_inverse(sa.inv, h, ainv);
+#pragma unroll
+                    for (int ks = 0; ks < KSN; ++ks) as[ks] = split8h(av[ks], sa.s);
+                }
+#pragma unroll
+                for (int b = 0; b < DPW; ++b) {
+                    float bv[KSN][8];
+                    float mx = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bv[ks][e] = xs[(nbase + 16 * ks + 8 * h + e) * K::LD + (cb0 + b) * 32 + r31];
+#pragma unroll
+                    for (int ks = 0; ks < KSN; ++ks) mx = absmax8(bv[ks], mx);
+                    const Pow2 sb = pow2_scale(half_max(mx));
+                    f32x16 t;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KSN; ++ks) t = mma3(as[ks], split8h(bv[ks], sb.s), t);
+                    const float u[4] = {ainv[0] * sb.inv, ainv[1] * sb.inv, ainv[2] * sb.inv, ainv[3] * sb.inv};
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dacc[b][r] = fmaf(t[r], u[r >> 2], dacc[b][r]);
+                }
             } else if constexpr (K::MFMA && TileGemm<C, true>::SPLIT) {
                 // bf16 three-piece form (see split8): k = node, 16 nodes per step; lane (i, h) feeds nodes 8h..8h+7 of the step
                 const int h = lane >> 5, r31 = lane & 31;
@@ -1684,7 +1886,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             return ld_vec<C>(p.g_in, i, sub);
         }
     };
-    TileGemm<C, false> gemm;                                    // os = y A^T
+    TileGemm<C, false, GADAPT_SPLIT_F16_S> gemm;                // os = y A^T
     float arow[K::MFMA ? 1 : 4][K::MFMA ? 1 : C];
     if constexpr (K::MFMA) {
         gemm.init(lane, wave);
