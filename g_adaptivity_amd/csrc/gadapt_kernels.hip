@@ -669,7 +669,9 @@ template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct T
 // (gadapt_tile_meta_host), so every load of the stage is issued at once: one memory round trip per tile.
 // A tile whose slice does not fit (more than CAP entries) or that has a row longer than MAXD is "slow":
 // the whole workgroup walks the HBM copy with plain loops instead.
-// EXT: one more per-edge int32 array (separate in HBM) staged with the slice.
+// EXT = 1: one more per-edge int32 array (separate in HBM) staged with the slice.  EXT = 2: no such array in HBM - the LDS
+// array holds the ring offsets of the slice's columns when the tile is windowed, next to the node ids in col (a kernel that
+// gathers one matrix from the ring and another one from HBM through the same edges: the source pass).
 template <int C, int AUXW, int EXT = 0> struct TileCsr {
     using K = Cfg<C>;
     int* rp; int* col; float* aux; int* ext; int4* metas;
@@ -683,7 +685,7 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
         col = rp + (K::TM + 4);
         aux = reinterpret_cast<float*>(col + K::COLN);
         ext = reinterpret_cast<int*>(aux + AUXW * K::COLN);
-        metas = reinterpret_cast<int4*>(ext + EXT * K::COLN);
+        metas = reinterpret_cast<int4*>(ext + (EXT > 0 ? 1 : 0) * K::COLN);
         rowptr_g = rowptr_g_; col_g = col_g_; aux_g = aux_g_; ext_g = ext_g_; meta_g = reinterpret_cast<const int4*>(meta_g_);
     }
     // Metadata of this workgroup's tiles first, first+step, ... -> LDS, once per launch.  Read per tile with
@@ -713,7 +715,7 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
         int rpv, rpv2;
         int colv[CQ];
         float auxv[AUXW > 0 ? AUXW * CQ : 1];
-        int extv[EXT > 0 ? CQ : 1];
+        int extv[EXT == 1 ? CQ : 1];
     };
     // Every load here is
     // UNCONDITIONAL with a clamped address (validity is applied in commit): a load under a branch or an exec mask
@@ -729,7 +731,7 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
         for (int q = 0; q < CQ; ++q) {
             const int idx = q * K::NT + tid;
             r.colv[q] = col_g[min(eb + idx, n_edges_m1)];
-            if constexpr (EXT > 0) r.extv[q] = ext_g[min(eb + idx, n_edges_m1)];
+            if constexpr (EXT == 1) r.extv[q] = ext_g[min(eb + idx, n_edges_m1)];
             if constexpr (AUXW > 0) {
 #pragma unroll
                 for (int w = 0; w < AUXW; ++w) {
@@ -759,8 +761,12 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
             const int idx = q * K::NT + tid;
             const int cnt = min(r.meta.y, K::CAP);
             const int jv = (idx < cnt) ? r.colv[q] : node0_pad;       // padding entries: a valid node of this tile
-            if (idx < K::CAP + GADAPT_MAXD) col[idx] = (windowed_tile >= 0) ? ring_off<RINGN>(jv, windowed_tile) : jv;
-            if constexpr (EXT > 0) { if (idx < K::CAP + GADAPT_MAXD) ext[idx] = r.extv[q]; }
+            if constexpr (EXT == 2) {
+                if (idx < K::CAP + GADAPT_MAXD) { col[idx] = jv; ext[idx] = (windowed_tile >= 0) ? ring_off<RINGN>(jv, windowed_tile) : 0; }
+            } else {
+                if (idx < K::CAP + GADAPT_MAXD) col[idx] = (windowed_tile >= 0) ? ring_off<RINGN>(jv, windowed_tile) : jv;
+            }
+            if constexpr (EXT == 1) { if (idx < K::CAP + GADAPT_MAXD) ext[idx] = r.extv[q]; }
             if constexpr (AUXW > 0) {
 #pragma unroll
                 for (int w = 0; w < AUXW; ++w) {
@@ -1846,20 +1852,35 @@ template <int HN_, int NV> struct SBuf {
     float2 ev[HN_];
 };
 
+// One node's out-edge rows of g (windowed source pass: the x rows come from the LDS ring)
+template <int DM_, int NV> struct SBufG {
+    static constexpr int N = DM_;
+    Vec<NV> g[DM_];
+    float2 ev[DM_];
+    int e0;
+};
+
 // DA: also accumulate the weight-gradient partials here instead of in the target pass:
 //   dA[o][c] = sum_i dP_i[o] x_i[c] = sum_j x_j[o] y_j[c],   dp0[o] = sum_i dP_i[o] = sum_j sigma_j x_j[o]
 // with y_j / sigma_j the per-source sums this pass forms for A y_j + sigma_j p0 anyway (exchange the two sums over the
 // edges).  The y tile is in LDS for the projection; the node's own x rows join it in a third tile.
-template <int C, bool GC = false, bool DA = false>
+// WIN: rolling LDS window of x rows like the target pass (slabs t-1, t, t+1; a workgroup walks consecutive tiles): on
+// mesh-ordered graphs the x_i gathers of the out-edge walk are LDS reads and only the g_i rows go through L1 / L2 - the walk is
+// bound by the 64 bytes per clock of the CU's vector-memory path (512 B per edge), which this halves.  The projection then
+// runs in place in the y tile (window + two tiles would leave one workgroup per CU).
+template <int C, bool GC = false, bool DA = false, bool WIN = false>
 __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD_S)) void grand_bwd_source_kernel(BwdSArgs p) {
     using K = Cfg<C>;
     using V = Vec<K::NV>;
     static_assert(!DA || (K::MFMA && TileGemm<C, false>::SPLIT && K::NW == 4), "dA in the source pass: matrix-core sizes only");
+    static_assert(!WIN || (!DA && K::MFMA), "windowed source pass: matrix-core sizes, weight gradients in the target pass");
     extern __shared__ float4 smem4[];
-    float* ys = reinterpret_cast<float*>(smem4);
-    float* os = ys + K::TILE_FLOATS;
+    float* ring = reinterpret_cast<float*>(smem4);              // WIN: three slabs of x rows
+    float* ys = ring + (WIN ? 3 * K::TILE_FLOATS : 0);
+    float* os = WIN ? ys : ys + K::TILE_FLOATS;
     float* xt = os + K::TILE_FLOATS;                            // DA: own x rows of the tile
-    TileCsr<C, 2> csr;                                          // aux = {alpha*dt, d<P,x>} per out-edge (source order)
+    using CsrT = TileCsr<C, 2, WIN ? 2 : 0>;                    // aux = {alpha*dt, d<P,x>} per out-edge (source order); WIN: ext = ring offsets
+    CsrT csr;
     csr.bind(os + (DA ? 2 : 1) * K::TILE_FLOATS, p.rowptr, p.col, p.edge_ws, p.meta, p.n_edges);
     constexpr int NB2 = K::CB * K::CB;
     constexpr int DPW = DA ? (NB2 >= 4 ? NB2 / 4 : 1) : 1;
@@ -1906,14 +1927,33 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
     // split fragments: built once per launch - unless the dA accumulators need their 48 registers (DA: rebuilt per tile, in
     // flight under the barrier)
     constexpr bool RESIDENT_B = K::MFMA && TileGemm<C, false>::SPLIT && GADAPT_S_RESIDENT_B && !DA && C < GADAPT_BWD_JIT_B_C;
-    const TileRange tr = tile_range(p.n_tiles);
-    typename TileCsr<C, 2>::Regs sr;
-    const int4 mreg = csr.metas_issue(tr.t, tr.step, p.n_tiles, tid);   // one round trip with the fragment loads
-    if constexpr (RESIDENT_B) gemm.load(p.A, nullptr);
-    csr.metas_commit(mreg, tid);
+    // this workgroup's tiles: every step-th one (XCD-interleaved), or - WIN - a run of consecutive ones
+    TileRange tr;
+    if constexpr (WIN) { const TileChunk ch = tile_chunk(p.n_tiles); tr = {ch.t0, ch.t1, 1}; } else { tr = tile_range(p.n_tiles); }
+    typename CsrT::Regs sr;
+    auto slab_ptr = [&](int s_) __attribute__((always_inline)) { return ring + ((s_ + 3) % 3) * K::TILE_FLOATS; };
+    TileRows<C> xr;
+    if constexpr (WIN) {
+        // prologue loads in one memory round trip (see the target pass): the window's first two slabs, metadata, fragments
+        TileRows<C> xr2;
+        xr.issue(p.x_in, (tr.t - 1) * K::TM, p.n_nodes, tid);
+        xr2.issue(p.x_in, tr.t * K::TM, p.n_nodes, tid);
+        const int4 mreg = csr.metas_issue(tr.t, tr.step, p.n_tiles, tid);
+        if constexpr (RESIDENT_B) gemm.load(p.A, nullptr);
+        csr.metas_commit(mreg, tid);
+        xr.commit(slab_ptr(tr.t - 1), p.n_nodes, tid);
+        xr2.commit(slab_ptr(tr.t), p.n_nodes, tid);
+    } else {
+        const int4 mreg = csr.metas_issue(tr.t, tr.step, p.n_tiles, tid);   // one round trip with the fragment loads
+        if constexpr (RESIDENT_B) gemm.load(p.A, nullptr);
+        csr.metas_commit(mreg, tid);
+    }
     __syncthreads();
     int kt = 0;                                                 // index of the tile in this workgroup's sequence
-    if (tr.t < tr.t_end) csr.issue(sr, 0, tr.t * K::TM, p.n_nodes, tid);
+    if (tr.t < tr.t_end) {
+        csr.issue(sr, 0, tr.t * K::TM, p.n_nodes, tid);
+        if constexpr (WIN) xr.issue(p.x_in, (tr.t + 1) * K::TM, p.n_nodes, tid);
+    }
     V zr[K::ITERS];                                             // sum(alpha dt g_i) + sigma p0, kept across the GEMM; then the result rows
     // g_out rows of a finished tile leave the registers only after the NEXT tile's staging (see the target pass)
     auto store_out = [&](int node0) __attribute__((always_inline)) {
@@ -1928,7 +1968,9 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         const int node0 = t * K::TM;
         const int tslot = ((t - tr.t) / tr.step) * 8;
         GADAPT_STAMP(p.stamps, tslot + 0);
-        const int dmax = csr.commit(sr, tid, node0);
+        const bool win = WIN && sr.meta.w != 0;
+        if constexpr (WIN) xr.commit(slab_ptr(t + 1), p.n_nodes, tid);
+        const int dmax = WIN ? csr.template commit<3>(sr, tid, node0, win ? t : -1) : csr.commit(sr, tid, node0);
         __syncthreads();
         if (prev_node0 >= 0) store_out(prev_node0);
         prev_node0 = node0;
@@ -1946,7 +1988,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                 constexpr int DM = decltype(tag)::value;
                 constexpr int HN = (DM + 1) / 2;
                 // pipeline steps = (node slot, half): rows of the next half are requested before this one is summed
-                auto fetch = [&](SBuf<HN, K::NV>& b, int step) __attribute__((always_inline)) {
+                auto fetch_w = [&](SBuf<HN, K::NV>& b, int step, auto win_tag) __attribute__((always_inline)) {
                     const int it = step >> 1, half = step & 1;
                     const int li = it * K::SLOTS + slot;
                     const int e0 = csr.rp[li] - csr.ebase + half * HN;
@@ -1960,7 +2002,13 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 #ifdef GADAPT_ABL_S_NO_X
                         b.x[k] = b.g[k];
 #else
-                        b.x[k] = ld_vec<C>(p.x_in, i, sub);
+                        if constexpr (decltype(win_tag)::value != 0) {
+                            const float* row = ring + csr.ext[e0 + k];
+#pragma unroll
+                            for (int q = 0; q < K::NV; ++q) b.x[k].v[q] = *reinterpret_cast<const float4*>(row + 4 * (sub + q * K::LPN));
+                        } else {
+                            b.x[k] = ld_vec<C>(p.x_in, i, sub);
+                        }
 #endif
                     }
                 };
@@ -1978,7 +2026,47 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                         sigs[it] = sig;
                     }
                 };
-                run_pipeline<2 * K::ITERS, SBuf<HN, K::NV>>(fetch, consume, [&]() {});
+                if constexpr (WIN) {
+                    if (win) {
+                        // windowed tile: the buffer holds g rows only (x rows are LDS reads at the point of use), so one request
+                        // covers a whole node - half as many exposed round trips per tile as the two-matrix half-node steps
+                        auto fetch_n = [&](SBufG<DM, K::NV>& b, int it) __attribute__((always_inline)) {
+                            const int li = it * K::SLOTS + slot;
+                            const int e0 = csr.rp[li] - csr.ebase;
+                            const int deg = (node0 + li < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
+                            b.e0 = e0;
+#pragma unroll
+                            for (int k = 0; k < DM; ++k) {
+                                const int i = csr.col[e0 + k];
+                                b.ev[k] = *reinterpret_cast<const float2*>(csr.aux + 2 * (e0 + k));
+                                if (k >= deg) b.ev[k] = make_float2(0.f, 0.f);
+                                b.g[k] = ld_g(i);
+                            }
+                        };
+                        auto consume_n = [&](const SBufG<DM, K::NV>& b, int it) __attribute__((always_inline)) {
+                            V zz, yy; zz.zero(); yy.zero();
+                            float sg = 0.f;
+#pragma unroll
+                            for (int k = 0; k < DM; ++k) {
+                                const float* row = ring + csr.ext[b.e0 + k];
+                                V xv;
+#pragma unroll
+                                for (int q = 0; q < K::NV; ++q) xv.v[q] = *reinterpret_cast<const float4*>(row + 4 * (sub + q * K::LPN));
+                                vaxpy(zz, b.ev[k].x, b.g[k]); vaxpy(yy, b.ev[k].y, xv); sg += b.ev[k].y;
+                            }
+                            const int li = it * K::SLOTS + slot;
+                            lds_put<C>(ys, li, sub, yy);
+                            vaxpy(zz, sg, p0v);
+                            zr[it] = zz;
+                            sigs[it] = sg;
+                        };
+                        run_pipeline<K::ITERS, SBufG<DM, K::NV>>(fetch_n, consume_n, [&]() {});
+                    } else {
+                        run_pipeline<2 * K::ITERS, SBuf<HN, K::NV>>([&](auto& b, int step) { fetch_w(b, step, IntTag<0>{}); }, consume, [&]() {});
+                    }
+                } else {
+                    run_pipeline<2 * K::ITERS, SBuf<HN, K::NV>>([&](auto& b, int step) { fetch_w(b, step, IntTag<0>{}); }, consume, [&]() {});
+                }
             });
         } else {
 #pragma unroll
@@ -2005,6 +2093,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         }
         GADAPT_STAMP(p.stamps, tslot + 2);
         if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, nullptr);   // in flight under the barrier
+        if constexpr (WIN) xr.issue(p.x_in, (t + 2) * K::TM, p.n_nodes, tid);   // slab of the next tile's window (clamped past the end)
         V dpre[K::ITERS];                                       // own dxd rows: requested here, used after the GEMM
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) dpre[it] = ld_vec<C>(p.dxd, min(node0 + it * K::SLOTS + slot, p.n_nodes - 1), sub);
@@ -2012,7 +2101,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         GADAPT_STAMP(p.stamps, tslot + 3);
 #ifndef GADAPT_ABL_S_NO_GEMM
         if constexpr (K::MFMA) {
-            gemm.run(ys, os);
+            if constexpr (WIN) gemm.run_in_place(ys); else gemm.run(ys, os);
             if constexpr (DA) {
 #pragma unroll
                 for (int it = 0; it < K::ITERS; ++it)           // dp0 += sigma_j x_j
@@ -2521,6 +2610,15 @@ static inline int grid_for(int n_tiles, int max_blocks) {
 #ifndef GADAPT_FWD_MAX_BLOCKS
 #define GADAPT_FWD_MAX_BLOCKS 512        /* 2 resident workgroups per CU (LDS ring: 4 tiles each) x 256 CUs */
 #endif
+#ifndef GADAPT_S_WINDOW
+// Source pass with the LDS window of x rows (grand_bwd_source_kernel, WIN).  Measured (MI355X, same box): hidden 128, one wave
+// per SIMD, every round trip exposed: 82.3 -> 79.3 us with whole-node steps (81.2 with half-node steps).  Hidden 64: 25.5 ->
+// 32.2 us, with either step size - the window needs each workgroup on CONSECUTIVE tiles, and then the 64 workgroups of an XCD
+// gather g rows from 192 distinct slabs at a time instead of 66 (interleaved order: 64 adjacent tiles): the first tile of a
+// workgroup takes 10.4k cycles in the edge walk against 6.8k, and the L2 (4 MB per XCD) does not hold a slab until the
+// neighbouring tile's step.  128-wide meshes (no tile windowed): 61 -> 80 us.  So: hidden 128 only.
+#define GADAPT_S_WINDOW(C) ((C) == 128)
+#endif
 #ifndef GADAPT_BWD_S_MAX_BLOCKS
 #define GADAPT_BWD_S_MAX_BLOCKS 512         /* the resident set (2 workgroups per CU): measured 27.8 vs 28.7 us with 1024 */
 #endif
@@ -2726,6 +2824,17 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
             return check_launch("grand_bwd_source_kernel");
         }
     }
+    if constexpr (K::MFMA && GADAPT_S_WINDOW(C)) {
+        constexpr int lds_sw = K::lds_bytes(2, 4, 1);           // window (3 slabs) + y tile; ext = ring offsets
+        if (g_cols) {
+            allow_lds(grand_bwd_source_kernel<C, true, false, true>, lds_sw);
+            hipLaunchKernelGGL((grand_bwd_source_kernel<C, true, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_sw, st, ps);
+        } else {
+            allow_lds(grand_bwd_source_kernel<C, false, false, true>, lds_sw);
+            hipLaunchKernelGGL((grand_bwd_source_kernel<C, false, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_sw, st, ps);
+        }
+        return check_launch("grand_bwd_source_kernel");
+    }
     if (g_cols) {
         allow_lds(grand_bwd_source_kernel<C, true>, lds_s);
         hipLaunchKernelGGL((grand_bwd_source_kernel<C, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_s, st, ps);
@@ -2763,7 +2872,10 @@ extern "C" int gadapt_debug_occupancy(int c, int* out3) {
         using K = Cfg<CC>;                                                                                              \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], grand_fwd_kernel<CC>, K::NT, K::lds_bytes(0, K::RING + 1)); \
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], grand_bwd_target_kernel<CC, false>, K::NT, K::lds_bytes(1, K::RING_T + 1, 1)); \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], grand_bwd_source_kernel<CC>, K::NT, K::lds_bytes(2)); \
+        if constexpr (K::MFMA && GADAPT_S_WINDOW(CC))                                                                   \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], grand_bwd_source_kernel<CC, false, false, true>, K::NT, K::lds_bytes(2, 4, 1)); \
+        else                                                                                                            \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], grand_bwd_source_kernel<CC>, K::NT, K::lds_bytes(2)); \
         return GADAPT_OK;                                                                                               \
     }
     switch (c) { GADAPT_OCC(4) GADAPT_OCC(8) GADAPT_OCC(16) GADAPT_OCC(32) GADAPT_OCC(64) GADAPT_OCC(128) default: break; }
