@@ -2825,6 +2825,9 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
         }
     }
     if constexpr (K::MFMA && GADAPT_S_WINDOW(C)) {
+      // mesh-ordered graphs only (the wide kernels' test: every out-neighbour near its node): elsewhere no tile is windowed and
+      // the slabs would be staged for nothing
+      if (g->wide_deg_s > 0) {
         constexpr int lds_sw = K::lds_bytes(2, 4, 1);           // window (3 slabs) + y tile; ext = ring offsets
         if (g_cols) {
             allow_lds(grand_bwd_source_kernel<C, true, false, true>, lds_sw);
@@ -2834,6 +2837,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
             hipLaunchKernelGGL((grand_bwd_source_kernel<C, false, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_sw, st, ps);
         }
         return check_launch("grand_bwd_source_kernel");
+      }
     }
     if (g_cols) {
         allow_lds(grand_bwd_source_kernel<C, true>, lds_s);

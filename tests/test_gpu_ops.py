@@ -475,6 +475,36 @@ def test_wide_kernels_size_sweep(gpu_device, mesh_n, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mesh_n,batch", [(9, 3), (17, 2), (33, 9), (63, 5), (64, 3)], ids=lambda v: str(v))
+def test_source_window_size_sweep(gpu_device, mesh_n, batch):
+    """Hidden 128: the source pass with the LDS window of x rows (mesh-ordered graphs, `wide_deg['s'] > 0`) against the
+    plain one (same graph declared not mesh-ordered): tiles that end mid-slab, chunks of one tile, a window clamped at
+    both ends.  Full model, forward + backward."""
+    from g_adaptivity_amd import graph as graph_mod
+    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=128, num_layers=3, conv_type='GRAND', device=str(gpu_device))
+    ds = MeshDataset([mesh_n, mesh_n], batch, seed=11)
+    data = collate(ds.samples).to(gpu_device)
+    res = {}
+    for wide in (True, False):
+        graph_mod.WIDE_KERNELS = wide
+        try:
+            torch.manual_seed(5)
+            model = GNN(ds, opt).to(gpu_device).train()
+            out = model(data)
+            F.mse_loss(out, data.x_phys).backward()
+            torch.cuda.synchronize()
+            g = next(iter(model._graphs.values()))
+            assert (g.wide_deg['s'] > 0) == wide
+            conv0 = model.conv_layers[0]                                # its gradients pass through the source passes of the layers above
+            res[wide] = (out.detach().clone(), conv0.lin_query.weight.grad.clone(), conv0.lin_key.weight.grad.clone(), conv0.lin_query.bias.grad.clone())
+        finally:
+            graph_mod.WIDE_KERNELS = True
+    assert torch.equal(res[True][0], res[False][0])                    # the forward does not depend on it
+    for a, b in zip(res[True][1:], res[False][1:]):                    # same sums, same order: the window only changes where rows are read
+        assert rel_err(a, b)[0] <= 1e-6, rel_err(a, b)
+
+
+@pytest.mark.gpu
 def test_wide_kernels_ragged_rows(gpu_device):
     """Rows of 0, 1, 7 and 8 in-edges inside the window (the ELL-8 limit), next to the mesh's 2..6: a node without
     in-edges gets res = -x (empty aggregation, GRAND_plus.py:338-343), unused ELL slots carry weight 0."""
