@@ -351,6 +351,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // level of an fp32 product, and every piece product is exact in the fp32 accumulator.  v_mfma_f32_32x32x16_bf16
 // does 16x the work of v_mfma_f32_32x32x2_f32 in half its cycles, so six of them per 16 k cost 3/8 of the fp32 form.
 struct Split3 { u32x4 h, m, l; };
+#ifndef GADAPT_MFMA_INTERLEAVE
+#define GADAPT_MFMA_INTERLEAVE 1
+#endif
+// (The same pipeline over the dA phase's (k-step, block) sequence was measured slower - target pass 32.5 -> 35.1 us at hidden
+// 64, 97 -> 104.5 at hidden 128 - and its sched_group_barrier patterns took the build from 2 to 16 minutes: not kept.)
 #ifndef GADAPT_SPLIT_PK
 #define GADAPT_SPLIT_PK 0       // 1: residuals of the split on v_pk_add_f32 (two subtractions per instruction); measured 0.3597 ms
                                 // per step against 0.3568 with scalar subtractions (three runs each): no gain
@@ -423,6 +428,23 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 #endif
 #ifndef GADAPT_SPLIT_F16_T
 #define GADAPT_SPLIT_F16_T 0        // TileGemm<C, true> and the dA phase: target pass
+#endif
+#ifndef GADAPT_DA_F16
+#define GADAPT_DA_F16 0             // dA phase of the target pass in the f16 form (measured with GADAPT_SPLIT_F16_T, see above)
+#endif
+// PRE-SPLIT A operand (GADAPT_PRESPLIT_S / _T): the [TM,C] operand tile is written to LDS ONCE, already in the two-piece f16
+// form, by the lanes that own its rows - one power-of-two scale per ROW (a lane group holds a whole row: its maximum is a DPP
+// reduction over the group), h and l pieces of 8 consecutive k side by side in the 32 bytes the 8 fp32 values would take, so
+// the tile keeps its footprint and a matrix-core lane fetches a k-step's fragment pair with two ds_read_b128 and NO vector
+// arithmetic.  The per-wave splits this replaces are redundant across the waves that share rows: x4 at hidden 128 (every
+// wave split the whole tile: 704 vector instructions per lane and tile in the target pass's projection, 1584 with its dA
+// phase, a quarter of the kernel), x2 at hidden 64.  The row's inverse scale stays with the lanes that wrote the row - the
+// same lanes read the product's row back and fold it into that read.
+#ifndef GADAPT_PRESPLIT_S
+#define GADAPT_PRESPLIT_S 1         // source pass: the y tile
+#endif
+#ifndef GADAPT_PRESPLIT_T
+#define GADAPT_PRESPLIT_T 1         // target pass: dP for dP A (copy in the window slot that is free after the edge walk)
 #endif
 #ifndef GADAPT_SPLIT_F16_WIDE
 #define GADAPT_SPLIT_F16_WIDE 0     // wide forward (gadapt_wide.inc)
@@ -497,6 +519,17 @@ __device__ __forceinline__ f32x16 mma3(const Split2& a, const Split2& b, f32x16 
     c = mfma_f16(a.h, b.l, c);                          // small pieces first
     c = mfma_f16(a.l, b.h, c);
     return mfma_f16(a.h, b.h, c);
+}
+
+// Instruction order for the scheduler (sched_group_barrier): NDS LDS reads, then six times {one matrix instruction, NVALU
+// vector instructions} - the shape of one software-pipelined k-step of the split products.
+template <int NDS, int NVALU, int NM = 6> __device__ __forceinline__ void mfma_gap_pattern() {
+    if constexpr (NDS > 0) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+#pragma unroll
+    for (int g = 0; g < NM; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);
+    }
 }
 
 template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct TileGemm {
@@ -597,26 +630,75 @@ template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct T
                     for (int ks = 0; ks < KS; ++ks) mx = absmax8(v[ks], mx);
                     const Pow2 sa = pow2_scale(quad_rows_max(mx));
                     quad_rows_inverse(sa.inv, h, oinv[b]);
+#if GADAPT_MFMA_INTERLEAVE
+                    Split2 cur = split8h(v[0], sa.s);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {                  // split of k-step ks+1 in the gaps of the three products of ks
+                        Split2 nxt = cur;
+                        if (ks + 1 < KS) nxt = split8h(v[ks + 1], sa.s);
+                        acc[b] = mma3(cur, bh[ks], acc[b]);
+                        if (ks + 1 < KS) mfma_gap_pattern<0, 8, 3>();
+                        cur = nxt;
+                    }
+#else
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) acc[b] = mma3(split8h(v[ks], sa.s), bh[ks], acc[b]);
+#endif
                 } else {                                               // hidden 128: read twice rather than hold 64 registers
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) { float v[8]; rd(ks, v); mx = absmax8(v, mx); }
                     const Pow2 sa = pow2_scale(quad_rows_max(mx));
                     quad_rows_inverse(sa.inv, h, oinv[b]);
+#if GADAPT_MFMA_INTERLEAVE
+                    float v0[8];
+                    rd(0, v0);
+                    Split2 cur = split8h(v0, sa.s);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        Split2 nxt = cur;
+                        if (ks + 1 < KS) { float v[8]; rd(ks + 1, v); nxt = split8h(v, sa.s); }
+                        acc[b] = mma3(cur, bh[ks], acc[b]);
+                        if (ks + 1 < KS) mfma_gap_pattern<2, 8, 3>();
+                        cur = nxt;
+                    }
+#else
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) { float v[8]; rd(ks, v); acc[b] = mma3(split8h(v, sa.s), bh[ks], acc[b]); }
+#endif
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) oinv[b][q] *= binv;
             } else if constexpr (SPLIT) {
                 const float* arow = in_tile + (rb * 32 + r31) * K::LD + 8 * h;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
+                auto ldsplit = [&](int ks) __attribute__((always_inline)) {
                     const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * ks);
                     const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * ks + 4);
                     const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                    const Split3 as = split8(v);
+                    return split8(v);
+                };
+#if GADAPT_MFMA_INTERLEAVE
+                // Software pipeline: the split of k-step ks+1 (44 vector instructions) is issued in the gaps of the six matrix
+                // instructions of k-step ks.  A wave issues in order, so six matrix instructions back to back (192 cycles of
+                // pipe time, 8 cycles of issue each) followed by the next split leave the matrix pipe idle during the split and
+                // the vector ALU idle during the six: 384 cycles per k-step measured at one wave per SIMD (hidden 128).
+                Split3 cur = ldsplit(0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    Split3 nxt = cur;
+                    if (ks + 1 < KS) nxt = ldsplit(ks + 1);
+                    acc[b] = mfma_bf16(cur.h, bs[ks].l, acc[b]);        // small pieces first
+                    acc[b] = mfma_bf16(cur.l, bs[ks].h, acc[b]);
+                    acc[b] = mfma_bf16(cur.m, bs[ks].m, acc[b]);
+                    acc[b] = mfma_bf16(cur.h, bs[ks].m, acc[b]);
+                    acc[b] = mfma_bf16(cur.m, bs[ks].h, acc[b]);
+                    acc[b] = mfma_bf16(cur.h, bs[ks].h, acc[b]);
+                    if (ks + 1 < KS) mfma_gap_pattern<2, 8>();
+                    cur = nxt;
+                }
+#else
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const Split3 as = ldsplit(ks);
                     acc[b] = mfma_bf16(as.h, bs[ks].l, acc[b]);         // small pieces first
                     acc[b] = mfma_bf16(as.l, bs[ks].h, acc[b]);
                     acc[b] = mfma_bf16(as.m, bs[ks].m, acc[b]);
@@ -624,6 +706,7 @@ template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct T
                     acc[b] = mfma_bf16(as.m, bs[ks].h, acc[b]);
                     acc[b] = mfma_bf16(as.h, bs[ks].h, acc[b]);
                 }
+#endif
             } else {
                 const float* arow = in_tile + (rb * 32 + r31) * K::LD + 4 * h;
 #pragma unroll
@@ -648,6 +731,36 @@ template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct T
                 const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 ocol[row * K::LD] = F16 ? fmaf(acc[b][r], oinv[b][r >> 2], bias) : acc[b][r] + bias;
             }
+        }
+    }
+    // PRE-SPLIT A operand (lds_put_split): in_tile holds, per row and group of 8 k, the h pieces (16 bytes) then the l pieces
+    __device__ __forceinline__ void accumulate_presplit(const float* in_tile, f32x16 (&acc)[BPW]) const {
+        static_assert(F16, "pre-split operands are two-piece f16");
+        const int h = lane >> 5, r31 = lane & 31;
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+            const int rb = rb0 + b * (K::NW / K::CB);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+            const float* arow = in_tile + (rb * 32 + r31) * K::LD + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Split2 a;
+                a.h = *reinterpret_cast<const u32x4*>(arow + 16 * ks);
+                a.l = *reinterpret_cast<const u32x4*>(arow + 16 * ks + 4);
+                acc[b] = mma3(a, bh[ks], acc[b]);
+            }
+        }
+    }
+    // result of accumulate_presplit times the B column's inverse scale; the row's inverse scale is applied by the reader
+    __device__ __forceinline__ void store_presplit(float* out_tile, const f32x16 (&acc)[BPW]) const {
+        const int h = lane >> 5, r31 = lane & 31;
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+            const int rb = rb0 + b * (K::NW / K::CB);
+            float* ocol = out_tile + cb * 32 + r31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ocol[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * K::LD] = acc[b][r] * binv;
         }
     }
     __device__ __forceinline__ void run(const float* in_tile, float* out_tile) {
@@ -948,7 +1061,7 @@ extern "C" int gadapt_debug_set_stamp_buffer(void* p) { g_stamp_buf = static_cas
     } while (0)
 #define GADAPT_STAMP(buf, slot_)                                                                   \
     do {                                                                                           \
-        if ((buf) && threadIdx.x == 0) {                                                           \
+        if ((buf) && threadIdx.x == 0 && (slot_) < 32) {                                           \
             __builtin_amdgcn_sched_barrier(0);                                                     \
             unsigned long long t_;                                                                 \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
@@ -1038,6 +1151,38 @@ template <int C> __device__ __forceinline__ void lds_put(float* tile, int li, in
 #pragma unroll
     for (int i = 0; i < Cfg<C>::NV; ++i) *reinterpret_cast<float4*>(tile + li * Cfg<C>::LD + 4 * (sub + i * Cfg<C>::LPN)) = x.v[i];
 }
+// Maximum over the LPN lanes that share a node (non-negative values), in every lane: the DPP steps of group_sum.
+template <int LPN> __device__ __forceinline__ float group_max(float v) {
+    if constexpr (LPN >= 2) v = dpp_max<0xB1>(v);
+    if constexpr (LPN >= 4) v = dpp_max<0x4E>(v);
+    if constexpr (LPN >= 8) v = dpp_max<0x141>(v);
+    if constexpr (LPN >= 16) v = dpp_max<0x140>(v);
+    static_assert(LPN <= 16, "group_max: lane groups of at most one DPP row");
+    return v;
+}
+// A row's channels of this lane -> the pre-split f16 layout of the row in an LDS tile (see GADAPT_PRESPLIT_*): chunk c (4
+// channels) is half c & 1 of k-group c >> 1, whose 32 bytes hold 8 h pieces then 8 l pieces.  Returns the row's inverse scale.
+template <int C> __device__ __forceinline__ float lds_put_split(float* tile, int li, int sub, const Vec<Cfg<C>::NV>& x) {
+    using K = Cfg<C>;
+    float m = 0.f;
+#pragma unroll
+    for (int q = 0; q < K::NV; ++q) m = fmaxf(fmaxf(fmaxf(m, fabsf(x.v[q].x)), fabsf(x.v[q].y)), fmaxf(fabsf(x.v[q].z), fabsf(x.v[q].w)));
+    const Pow2 s = pow2_scale(group_max<K::LPN>(m));
+#pragma unroll
+    for (int q = 0; q < K::NV; ++q) {
+        const int c = sub + q * K::LPN;
+        const float t0 = x.v[q].x * s.s, t1 = x.v[q].y * s.s, t2 = x.v[q].z * s.s, t3 = x.v[q].w * s.s;
+        f16x2 h01, h23, l01, l23;
+        h01.x = (_Float16)t0; h01.y = (_Float16)t1; h23.x = (_Float16)t2; h23.y = (_Float16)t3;
+        l01.x = (_Float16)(t0 - (float)h01.x); l01.y = (_Float16)(t1 - (float)h01.y);
+        l23.x = (_Float16)(t2 - (float)h23.x); l23.y = (_Float16)(t3 - (float)h23.y);
+        uint2* grp = reinterpret_cast<uint2*>(tile + li * K::LD + 8 * (c >> 1));
+        grp[c & 1] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+        grp[2 + (c & 1)] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+    }
+    return s.inv;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -1356,7 +1501,11 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
     constexpr int ROW = C * C + C;                              // slab row: dA then dp0
     float* xs = ring;                                           // slab of the current tile
 
-    TileGemm<C, true> gemm;                                     // dxd = dP A
+    // PRE: dP A takes dP from a pre-split f16 copy (lds_put_split) made after the edge walk in the window slot of slab t-1,
+    // which nothing reads between that barrier and the next tile's commit; dinv = its row scales
+    constexpr bool PRE = K::MFMA && !XC && GADAPT_PRESPLIT_T && K::RING_T == 3 && TileGemm<C, true>::SPLIT && C < GADAPT_BWD_JIT_B_C;
+    float dinv[K::ITERS];
+    TileGemm<C, true, GADAPT_SPLIT_F16_T || PRE> gemm;          // dxd = dP A
     float acol[K::MFMA ? 1 : 4][K::MFMA ? 1 : C];               // VALU: A[o][4sub+t]
     if constexpr (K::MFMA) {
         gemm.init(lane, wave);
@@ -1593,6 +1742,14 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             }
             __syncthreads();
             GADAPT_STAMP(p.stamps, tslot + 4);
+            if constexpr (PRE) {
+                float* cv = slab_ptr(t - 1);                    // dead until the next tile's commit puts slab t+2 there
+#pragma unroll
+                for (int it = 0; it < K::ITERS; ++it) {
+                    const int li = it * K::SLOTS + slot;
+                    dinv[it] = lds_put_split<C>(cv, li, sub, lds_vec<C>(ds, li, sub));   // own rows: written by this lane group in finish()
+                }
+            }
             // ---- dA partial:  dA[o][c] += sum_node dP[node][o] x[node][c]
 #if GADAPT_T_MFMA_PRIO
             __builtin_amdgcn_s_setprio(GADAPT_T_MFMA_PRIO);
@@ -1601,7 +1758,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             if (p.n_nodes >= 0) {} else                          // diagnostic build: the dA phase never runs
 #endif
             if constexpr (!DA) {
-            } else if constexpr (K::MFMA && TileGemm<C, true>::F16) {
+            } else if constexpr (K::MFMA && TileGemm<C, true>::SPLIT && GADAPT_DA_F16) {
                 // two-piece f16 form (see split8h): k = node, 16 nodes per step; lane (i, h) feeds nodes 8h..8h+7 of the step.
                 // Scales: per quad of dP channels and per x channel over this wave's nodes; fresh accumulator per tile.
                 const int h = lane >> 5, r31 = lane & 31;
@@ -1711,7 +1868,13 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             if constexpr (!XC) {
             if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, nullptr);
 #ifndef GADAPT_ABL_NO_GEMM
-            if constexpr (K::MFMA) {
+            if constexpr (PRE) {
+                __syncthreads();                                // the pre-split copy is complete; every wave is done with dP in ds (dA)
+                f32x16 acc[decltype(gemm)::BPW];
+                gemm.accumulate_presplit(slab_ptr(t - 1), acc);
+                gemm.store_presplit(ds, acc);
+                __syncthreads();
+            } else if constexpr (K::MFMA) {
                 gemm.run_in_place(ds);                          // reads dP (like the dA pass), barrier, writes dP A
                 __syncthreads();
             }
@@ -1736,9 +1899,11 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                         r.v[0].z = fmaf(d, acol[2][o], r.v[0].z); r.v[0].w = fmaf(d, acol[3][o], r.v[0].w);
                     }
                 }
+                const float ri = PRE ? dinv[it] : 1.0f;         // pre-split operand: the row's inverse scale
 #pragma unroll
                 for (int q = 0; q < K::NV; ++q) {
-                    gk[it].v[q].x += r.v[q].x; gk[it].v[q].y += r.v[q].y; gk[it].v[q].z += r.v[q].z; gk[it].v[q].w += r.v[q].w;
+                    gk[it].v[q].x = fmaf(r.v[q].x, ri, gk[it].v[q].x); gk[it].v[q].y = fmaf(r.v[q].y, ri, gk[it].v[q].y);
+                    gk[it].v[q].z = fmaf(r.v[q].z, ri, gk[it].v[q].z); gk[it].v[q].w = fmaf(r.v[q].w, ri, gk[it].v[q].w);
                 }
             }
             }
@@ -1907,7 +2072,10 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             return ld_vec<C>(p.g_in, i, sub);
         }
     };
-    TileGemm<C, false, GADAPT_SPLIT_F16_S> gemm;                // os = y A^T
+    // PRE: the y tile is written in the pre-split f16 form by the lanes that sum its rows (lds_put_split); yinv = row scales
+    constexpr bool PRE = K::MFMA && !DA && GADAPT_PRESPLIT_S && TileGemm<C, false>::SPLIT;
+    float yinv[K::ITERS];
+    TileGemm<C, false, GADAPT_SPLIT_F16_S || PRE> gemm;         // os = y A^T
     float arow[K::MFMA ? 1 : 4][K::MFMA ? 1 : C];
     if constexpr (K::MFMA) {
         gemm.init(lane, wave);
@@ -2020,7 +2188,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                     for (int k = 0; k < HN; ++k) { vaxpy(z, b.ev[k].x, b.g[k]); vaxpy(y, b.ev[k].y, b.x[k]); sig += b.ev[k].y; }
                     if (half == 1) {
                         const int li = it * K::SLOTS + slot;
-                        lds_put<C>(ys, li, sub, y);
+                        if constexpr (PRE) yinv[it] = lds_put_split<C>(ys, li, sub, y); else lds_put<C>(ys, li, sub, y);
                         vaxpy(z, sig, p0v);
                         zr[it] = z;
                         sigs[it] = sig;
@@ -2055,7 +2223,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                                 vaxpy(zz, b.ev[k].x, b.g[k]); vaxpy(yy, b.ev[k].y, xv); sg += b.ev[k].y;
                             }
                             const int li = it * K::SLOTS + slot;
-                            lds_put<C>(ys, li, sub, yy);
+                            if constexpr (PRE) yinv[it] = lds_put_split<C>(ys, li, sub, yy); else lds_put<C>(ys, li, sub, yy);
                             vaxpy(zz, sg, p0v);
                             zr[it] = zz;
                             sigs[it] = sg;
@@ -2085,7 +2253,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                         sig += ev.y;
                     }
                 }
-                lds_put<C>(ys, li, sub, y);
+                if constexpr (PRE) yinv[it] = lds_put_split<C>(ys, li, sub, y); else lds_put<C>(ys, li, sub, y);
                 vaxpy(z, sig, p0v);
                 zr[it] = z;
                 sigs[it] = sig;
@@ -2101,7 +2269,16 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         GADAPT_STAMP(p.stamps, tslot + 3);
 #ifndef GADAPT_ABL_S_NO_GEMM
         if constexpr (K::MFMA) {
-            if constexpr (WIN) gemm.run_in_place(ys); else gemm.run(ys, os);
+            if constexpr (PRE) {
+                f32x16 acc[decltype(gemm)::BPW];
+                gemm.accumulate_presplit(ys, acc);
+                if constexpr (WIN) __syncthreads();             // in place: every wave has read its operand rows
+                gemm.store_presplit(os, acc);
+            } else if constexpr (WIN) {
+                gemm.run_in_place(ys);
+            } else {
+                gemm.run(ys, os);
+            }
             if constexpr (DA) {
 #pragma unroll
                 for (int it = 0; it < K::ITERS; ++it)           // dp0 += sigma_j x_j
@@ -2157,10 +2334,11 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                 }
             }
             const V d = dpre[it];
+            const float ri = PRE ? yinv[it] : 1.0f;             // pre-split operand: the row's inverse scale (1: exact either way)
 #pragma unroll
             for (int q = 0; q < K::NV; ++q) {
-                zr[it].v[q].x = (r.v[q].x + zr[it].v[q].x) + d.v[q].x; zr[it].v[q].y = (r.v[q].y + zr[it].v[q].y) + d.v[q].y;
-                zr[it].v[q].z = (r.v[q].z + zr[it].v[q].z) + d.v[q].z; zr[it].v[q].w = (r.v[q].w + zr[it].v[q].w) + d.v[q].w;
+                zr[it].v[q].x = fmaf(r.v[q].x, ri, zr[it].v[q].x) + d.v[q].x; zr[it].v[q].y = fmaf(r.v[q].y, ri, zr[it].v[q].y) + d.v[q].y;
+                zr[it].v[q].z = fmaf(r.v[q].z, ri, zr[it].v[q].z) + d.v[q].z; zr[it].v[q].w = fmaf(r.v[q].w, ri, zr[it].v[q].w) + d.v[q].w;
             }
         }
         GADAPT_STAMP(p.stamps, tslot + 5);

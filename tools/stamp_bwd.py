@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from g_adaptivity_amd import _native, MeshDataset, collate, hot_path_opt, GNN
 handle = C.CDLL(_native.LIB_PATH)
 dev = torch.device('cuda:0')
-n, B, Cc, L = 64, 32, 64, 4
+n, B, Cc, L = 64, 32, int(os.environ.get("STAMP_C", "64")), 4
 opt = hot_path_opt(mesh_dims=[n, n], hidden_dim=Cc, num_layers=L, device='cuda:0', show_mesh_evol_plots='False')
 ds = MeshDataset([n, n], B, seed=0); data = collate(ds.samples).to(dev)
 model = GNN(ds, opt).to(dev).train()
@@ -24,7 +24,7 @@ allb = buf.cpu().numpy().reshape(3, 1024, 32).astype(np.float64)
 for name, s, names in (('backward_target (last launch = layer 0)', allb[1], ['start', 'commit', 'barrier+st', 'edge done', 'issue+barrier', 'dA done', 'gemm(b)', 'epilogue(b)']),
                        ('backward_source (last launch = layer 1)', allb[2], ['start', 'staged(b)', 'edge done', 'barrier', 'gemm(b)', 'epilogue', 'end(b)', '-'])):
     print(name)
-    for tile in range(4):
+    for tile in range(int(os.environ.get("STAMP_TILES", "4"))):
         seg = s[:, tile * 8:(tile + 1) * 8]
         ok = seg[:, 1] > 0
         if not ok.any():
@@ -35,7 +35,7 @@ for name, s, names in (('backward_target (last launch = layer 0)', allb[1], ['st
             d = seg[ok, k] - seg[ok, k - 1]
             line += f"  {names[k]} {np.median(d):.0f}"
         line += f"  | total {np.median(seg[ok, nst - 1] - seg[ok, 0]):.0f}"
-        if tile < 3:
+        if tile < int(os.environ.get("STAMP_TILES", "4")) - 1:
             nxt = s[:, (tile + 1) * 8]
             ok2 = ok & (nxt > 0)
             if ok2.any():
