@@ -77,6 +77,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='poisson2d_64x64_b32_L4_C64', choices=list(WORKLOADS))
     ap.add_argument('--torch-loss', action='store_true', help='torch F.mse_loss instead of the one-launch native loss')
+    ap.add_argument('--plain-backward', action='store_true', help='loss.backward() without the preallocated root gradient')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dense-slots', action='store_true',
@@ -108,7 +109,7 @@ def main():
 
     from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt, _native
     from g_adaptivity_amd.optim import FlatAdam
-    from g_adaptivity_amd import mse_loss as native_mse_loss
+    from g_adaptivity_amd import mse_loss as native_mse_loss, unit_gradient
     loss_fn = F.mse_loss if args.torch_loss else native_mse_loss
 
     w = WORKLOADS[args.workload]
@@ -129,10 +130,17 @@ def main():
     capture_all = world == 1 or os.environ.get('GADAPT_BENCH_CAPTURE_ALLREDUCE') == '1'
     optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=True)
 
+    # loss.backward() with the root gradient handed over instead of created per step (g_adaptivity_amd.unit_gradient: same
+    # value, two launches fewer - the one-element fill and the multiplication by it); --plain-backward: the literal call
+    root = None if (args.plain_backward or args.torch_loss) else unit_gradient(dev)
+
     def fwd_bwd():
         out = model(data)
         loss = loss_fn(out, target)
-        loss.backward()
+        if root is None:
+            loss.backward()
+        else:
+            loss.backward(gradient=root)
         return loss
 
     def eager_step():
@@ -347,7 +355,7 @@ def main():
             'config': {'workload': args.workload, 'mesh': f"{w['n']}x{w['n']}", 'meshes_per_gpu': w['batch'],
                        'global_batch': w['batch'] * world, 'mp_layers': w['layers'], 'hidden': w['hidden'],
                        'conv_type': w['conv'], 'parallelism': f'dp{world}',
-                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'slots': 'dense' if args.dense_slots else 'compact', 'launch': ('hipgraph+adam' if world == 1 else ('hipgraph+allreduce+adam' if capture_all else 'hipgraph, then allreduce+adam')) if graph is not None else 'eager'},
+                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'root_gradient': 'created per step (loss.backward())' if root is None else 'preallocated (unit_gradient)', 'slots': 'dense' if args.dense_slots else 'compact', 'launch': ('hipgraph+adam' if world == 1 else ('hipgraph+allreduce+adam' if capture_all else 'hipgraph, then allreduce+adam')) if graph is not None else 'eager'},
             'roofline': roofline, 'roofline_mfma': roofline_mfma, 'kernels': kernels, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))

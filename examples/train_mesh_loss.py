@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from g_adaptivity_amd import GNN, DeviceMeshLoader, MeshDataset, MeshLoader, hot_path_opt, l1_loss, mse_loss   # noqa: E402
+from g_adaptivity_amd import GNN, DeviceMeshLoader, MeshDataset, MeshLoader, hot_path_opt, l1_loss, mse_loss, unit_gradient   # noqa: E402
 from g_adaptivity_amd.optim import FlatAdam                                      # noqa: E402
 
 
@@ -43,7 +43,7 @@ def main(opt, dataset, log=print):
             data = data.to(opt['device'])
             out = model(data)
             loss = loss_fn(out, data.x_phys)
-            loss.backward()
+            loss.backward(gradient=unit_gradient(loss.device))   # = loss.backward(), root gradient not re-created per step
             optimizer.step()
             epoch_loss += loss.detach()                      # no .item() per batch: one sync per epoch
         loss_list.append(float(epoch_loss))

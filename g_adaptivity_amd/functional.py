@@ -291,7 +291,27 @@ class _MeshLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (seed,) = ctx.saved_tensors
+        unit = _unit_grads.get(g.device)
+        if unit is not None and g.data_ptr() == unit.data_ptr():
+            return seed, None, None          # the caller passed unit_gradient(): d loss / d loss = 1, nothing to multiply
         return seed * g, None, None
+
+
+_unit_grads = {}
+
+
+def unit_gradient(device) -> torch.Tensor:
+    """The root gradient of a scalar loss, kept per device: `loss.backward(gradient=unit_gradient(dev))` is
+    `loss.backward()` (`src/run_GNN.py:84`) without the two launches autograd otherwise adds per step - filling a fresh
+    one-element tensor with 1 and multiplying the loss derivative by it (`mse_loss` / `l1_loss` recognise this tensor by
+    its address and hand their derivative on as it is).  Read-only by contract."""
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    t = _unit_grads.get(device)
+    if t is None:
+        t = _unit_grads[device] = torch.ones((), device=device, dtype=torch.float32)
+    return t
 
 
 def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:

@@ -204,3 +204,30 @@ def test_mixed_size_batch_parity(gpu_device, hidden):
             got = dict(model.conv_layers[0].named_parameters())[name].grad
             assert rel_err(got, want)[0] <= 2e-4, (k, name, rel_err(got, want))
     assert len(model._graphs) == 1            # both batches: the same three meshes in the same order -> one topology
+
+
+@pytest.mark.gpu
+def test_unit_gradient_is_plain_backward(gpu_device):
+    """`loss.backward(gradient=unit_gradient(dev))` gives bit-identical gradients to `loss.backward()` for the native
+    losses (the derivative is handed on without the multiplication by 1), and still multiplies for any other root."""
+    from g_adaptivity_amd import mse_loss, l1_loss, unit_gradient
+    opt = hot_path_opt(mesh_dims=[12, 12], hidden_dim=32, num_layers=2, device=str(gpu_device))
+    ds = MeshDataset([12, 12], 3, seed=2)
+    data = collate(ds.samples).to(gpu_device)
+    torch.manual_seed(1)
+    model = GNN(ds, opt).to(gpu_device).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def grads(fn, root):
+        for p in params:
+            p.grad = None
+        loss = fn(model(data), data.x_phys)
+        loss.backward() if root is None else loss.backward(gradient=root)
+        return [p.grad.clone() for p in params if p.grad is not None]
+
+    for fn in (mse_loss, l1_loss):
+        plain, unit = grads(fn, None), grads(fn, unit_gradient(gpu_device))
+        assert len(plain) == len(unit) > 0 and all(torch.equal(a, b) for a, b in zip(plain, unit))
+        half = grads(fn, torch.full((), 0.5, device=gpu_device))
+        assert all(torch.equal(0.5 * a, b) for a, b in zip(plain, half))       # a power of two: exact
+    assert unit_gradient(gpu_device) is unit_gradient(gpu_device) and float(unit_gradient(gpu_device)) == 1.0
