@@ -111,6 +111,7 @@ def main():
     from g_adaptivity_amd.optim import FlatAdam
     from g_adaptivity_amd import mse_loss as native_mse_loss, unit_gradient
     loss_fn = F.mse_loss if args.torch_loss else native_mse_loss
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # the step is captured on a side stream by design
 
     w = WORKLOADS[args.workload]
     opt = hot_path_opt(mesh_dims=[w['n'], w['n']], hidden_dim=w['hidden'], num_layers=w['layers'], conv_type=w['conv'],
