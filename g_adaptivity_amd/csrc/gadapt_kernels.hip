@@ -92,6 +92,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_T_MFMA_PRIO
 #define GADAPT_T_MFMA_PRIO 0    // s_setprio level of the target pass's matrix phases (0: leave the priority alone)
 #endif
+#ifndef GADAPT_T_ALTERNATE
+#define GADAPT_T_ALTERNATE 1     /* target pass: every other workgroup walks its chunk backwards (see the kernel) */
+#endif
 #ifndef GADAPT_DA_UNROLL
 #define GADAPT_DA_UNROLL 2      // k-steps of the dA loop unrolled together
 #endif
@@ -811,7 +814,7 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
     // (window slabs, weight fragments): request everything, then consume - vmcnt is in-order, the first wait covers all.
     __device__ __forceinline__ int4 metas_issue(int first, int step, int n_tiles, int tid) {
         m_first = first; m_step = step; m_ntiles = n_tiles;
-        return meta_g[min(first + min(tid, K::MAXM - 1) * step, n_tiles - 1)];      // unconditional (see issue())
+        return meta_g[max(min(first + min(tid, K::MAXM - 1) * step, n_tiles - 1), 0)];   // unconditional (see issue())
     }
     __device__ __forceinline__ void metas_commit(const int4& m, int tid) {
         if (tid < K::MAXM) metas[tid] = m;
@@ -838,8 +841,9 @@ template <int C, int AUXW, int EXT = 0> struct TileCsr {
     __device__ __forceinline__ void issue(Regs& r, int k, int node0, int n_nodes, int tid) const {
         r.meta = meta_at(k);
         const int eb = r.meta.x;
-        r.rpv = rowptr_g[min(min(node0, n_nodes) + min(tid, K::TM), n_nodes)];
-        r.rpv2 = (K::TM >= K::NT) ? rowptr_g[min(min(node0, n_nodes) + min(K::NT + tid, K::TM), n_nodes)] : 0;
+        const int nb = min(max(node0, 0), n_nodes);              // a request one tile past either end of the chunk stays in bounds
+        r.rpv = rowptr_g[min(nb + min(tid, K::TM), n_nodes)];
+        r.rpv2 = (K::TM >= K::NT) ? rowptr_g[min(nb + min(K::NT + tid, K::TM), n_nodes)] : 0;
 #pragma unroll
         for (int q = 0; q < CQ; ++q) {
             const int idx = q * K::NT + tid;
@@ -1676,33 +1680,40 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         constexpr bool RESIDENT_B = TileGemm<C, true>::SPLIT && C < GADAPT_BWD_JIT_B_C;  // split fragments are built once per launch
         // prologue loads in ONE memory round trip: the two slabs of the window's start (gr is free until the first g tile),
         // the tile metadata, the weight fragments - all requested before the first use (the fragment split) waits
+        // Walk direction: every other workgroup of an XCD walks its chunk BACKWARDS.  Neighbouring chunks then meet at their common
+        // boundary at the same time - both at the start or both at the end of the launch - so the halo slab one of them
+        // stages is the slab the other one stages for its own tile within the same few microseconds: an L2 hit instead of a
+        // second trip to the fabric (with every chunk walked forwards the two reads are a whole launch apart: x came in 1.5x).
+        const int dir = (GADAPT_T_ALTERNATE && K::RING_T == 3 && ((blockIdx.x >> 3) & 1)) ? -1 : 1;
+        const int tb = dir > 0 ? ch.t0 : ch.t1 - 1, n_my = ch.t1 - ch.t0;
         if constexpr (K::RING_T == 3) {
-            xr.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid);
-            gr.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid);
+            xr.template issue_sel<XC>(p.x_in, (tb - dir) * K::TM, p.n_nodes, tid);
+            gr.template issue_sel<XC>(p.x_in, tb * K::TM, p.n_nodes, tid);
         }
-        const int4 mreg = csr.metas_issue(ch.t0, 1, p.n_tiles, tid);
+        const int4 mreg = csr.metas_issue(tb, dir, p.n_tiles, tid);
         if constexpr (K::MFMA && RESIDENT_B && !XC) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
         csr.metas_commit(mreg, tid);
         if constexpr (K::RING_T == 3) {
-            xr.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
-            gr.template commit_sel<XC>(slab_ptr(ch.t0), p.n_nodes, tid);
+            xr.template commit_sel<XC>(slab_ptr(tb - dir), p.n_nodes, tid);
+            gr.template commit_sel<XC>(slab_ptr(tb), p.n_nodes, tid);
         }
         __syncthreads();                                        // tile metadata visible
         // C = 128 has no registers to hold a tile across the edge walk: it stages at the top of the tile instead
         constexpr bool PREFETCH = (C <= GADAPT_T_PREFETCH_MAX_C);
         if constexpr (PREFETCH) {
-            xr.template issue_sel<XC>(p.x_in, (ch.t0 + K::LEAD_T) * K::TM, p.n_nodes, tid);
-            if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, ch.t0 * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, ch.t0 * K::TM, p.n_nodes, tid);
-            csr.issue(sr, 0, ch.t0 * K::TM, p.n_nodes, tid);
+            xr.template issue_sel<XC>(p.x_in, (tb + dir * K::LEAD_T) * K::TM, p.n_nodes, tid);
+            if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, tb * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, tb * K::TM, p.n_nodes, tid);
+            csr.issue(sr, 0, tb * K::TM, p.n_nodes, tid);
         }
 #pragma unroll 1
-        for (int t = ch.t0; t < ch.t1; ++t) {
+        for (int k = 0; k < n_my; ++k) {
+            const int t = tb + k * dir;
             const int node0 = t * K::TM;
-            const int tslot = (t - ch.t0) * 8;
+            const int tslot = k * 8;
             if constexpr (!PREFETCH) {
-                xr.template issue_sel<XC>(p.x_in, (t + K::LEAD_T) * K::TM, p.n_nodes, tid);
+                xr.template issue_sel<XC>(p.x_in, (t + dir * K::LEAD_T) * K::TM, p.n_nodes, tid);
                 if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, t * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, t * K::TM, p.n_nodes, tid);
-                csr.issue(sr, t - ch.t0, t * K::TM, p.n_nodes, tid);
+                csr.issue(sr, k, t * K::TM, p.n_nodes, tid);
             }
 #ifdef GADAPT_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // diagnostic: separates the prefetch wait from the LDS writes
@@ -1710,12 +1721,12 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             GADAPT_STAMP(p.stamps, tslot + 0);
             xs = slab_ptr(t);
             const bool win = K::RING_T == 3 && sr.meta.w != 0;
-            xr.template commit_sel<XC>(slab_ptr(t + K::LEAD_T), p.n_nodes, tid);
+            xr.template commit_sel<XC>(slab_ptr(t + dir * K::LEAD_T), p.n_nodes, tid);
             gr.commit(ds, p.n_nodes, tid);
             const int dmax = csr.template commit<K::RING_T>(sr, tid, node0, win ? t : -1);
             GADAPT_STAMP(p.stamps, tslot + 1);
             __syncthreads();
-            if constexpr (!XC) { if (t > ch.t0) store_dxd(node0 - K::TM); }   // previous tile's result: see store_dxd
+            if constexpr (!XC) { if (k > 0) store_dxd((t - dir) * K::TM); }   // previous tile's result: see store_dxd
             GADAPT_STAMP(p.stamps, tslot + 2);
             // ---- edge phase: dP_i per node -> LDS
             if (dmax >= 0) {
@@ -1736,14 +1747,14 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             if constexpr (PREFETCH) {
                 // request the next tile (unconditional, clamped past the end: see issue()).  Here rather than at the top
                 // of the tile: the edge phase needs every register, and the MFMA phases below cover the round trip.
-                csr.issue(sr, t + 1 - ch.t0, (t + 1) * K::TM, p.n_nodes, tid);
-                xr.template issue_sel<XC>(p.x_in, (t + 1 + K::LEAD_T) * K::TM, p.n_nodes, tid);
-                if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, (t + 1) * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, (t + 1) * K::TM, p.n_nodes, tid);
+                csr.issue(sr, k + 1, (t + dir) * K::TM, p.n_nodes, tid);
+                xr.template issue_sel<XC>(p.x_in, (t + dir * (1 + K::LEAD_T)) * K::TM, p.n_nodes, tid);
+                if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, (t + dir) * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, (t + dir) * K::TM, p.n_nodes, tid);
             }
             __syncthreads();
             GADAPT_STAMP(p.stamps, tslot + 4);
             if constexpr (PRE) {
-                float* cv = slab_ptr(t - 1);                    // dead until the next tile's commit puts slab t+2 there
+                float* cv = slab_ptr(t - dir);                  // the slab behind: dead until the next tile's commit puts the slab two ahead there
 #pragma unroll
                 for (int it = 0; it < K::ITERS; ++it) {
                     const int li = it * K::SLOTS + slot;
@@ -1871,7 +1882,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             if constexpr (PRE) {
                 __syncthreads();                                // the pre-split copy is complete; every wave is done with dP in ds (dA)
                 f32x16 acc[decltype(gemm)::BPW];
-                gemm.accumulate_presplit(slab_ptr(t - 1), acc);
+                gemm.accumulate_presplit(slab_ptr(t - dir), acc);
                 gemm.store_presplit(ds, acc);
                 __syncthreads();
             } else if constexpr (K::MFMA) {
@@ -1910,7 +1921,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             __syncthreads();
             GADAPT_STAMP(p.stamps, tslot + 7);
         }
-        if constexpr (!XC) store_dxd((ch.t1 - 1) * K::TM);
+        if constexpr (!XC) store_dxd((tb + (n_my - 1) * dir) * K::TM);
     }
     if constexpr (!DA) return;                                  // the source pass owns the weight-gradient partials
     xs = ring;                                                  // scratch for the flush below
