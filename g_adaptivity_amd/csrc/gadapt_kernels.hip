@@ -1374,32 +1374,36 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
     TileRows<C> xrA, xrB;
     // prologue loads in ONE memory round trip: the two slabs of the window's start, the tile metadata, the weight
     // fragments - all requested before the first use (the fragment split) waits
+    // walk direction: every other workgroup of an XCD walks its chunk backwards (see the target pass)
+    const int dir = (GADAPT_T_ALTERNATE && K::RING == 3 && ((blockIdx.x >> 3) & 1)) ? -1 : 1;
+    const int tb = dir > 0 ? ch.t0 : ch.t1 - 1, n_my = ch.t1 - ch.t0;
     if constexpr (K::RING == 3) {
-        xrA.template issue_sel<XC>(p.x_in, (ch.t0 - 1) * K::TM, p.n_nodes, tid);
-        xrB.template issue_sel<XC>(p.x_in, ch.t0 * K::TM, p.n_nodes, tid);
+        xrA.template issue_sel<XC>(p.x_in, (tb - dir) * K::TM, p.n_nodes, tid);
+        xrB.template issue_sel<XC>(p.x_in, tb * K::TM, p.n_nodes, tid);
     }
-    const int4 mreg = csr.metas_issue(ch.t0, 1, p.n_tiles, tid);
+    const int4 mreg = csr.metas_issue(tb, dir, p.n_tiles, tid);
     if constexpr (K::MFMA && RESIDENT_B) gemm.load(p.A, p.p0);   // B fragments stay in registers for the whole launch
     csr.metas_commit(mreg, tid);
     if constexpr (K::RING == 3) {
-        xrA.template commit_sel<XC>(slab_ptr(ch.t0 - 1), p.n_nodes, tid);
-        xrB.template commit_sel<XC>(slab_ptr(ch.t0), p.n_nodes, tid);
+        xrA.template commit_sel<XC>(slab_ptr(tb - dir), p.n_nodes, tid);
+        xrB.template commit_sel<XC>(slab_ptr(tb), p.n_nodes, tid);
     }
     __syncthreads();                                             // tile metadata visible
-    xrA.template issue_sel<XC>(p.x_in, (ch.t0 + K::LEAD) * K::TM, p.n_nodes, tid);   // rows past N come back as zeros
-    csr.issue(srA, 0, ch.t0 * K::TM, p.n_nodes, tid);
+    xrA.template issue_sel<XC>(p.x_in, (tb + dir * K::LEAD) * K::TM, p.n_nodes, tid);   // rows past N come back as zeros
+    csr.issue(srA, 0, tb * K::TM, p.n_nodes, tid);
     if constexpr (AHEAD == 2) {
-        xrB.template issue_sel<XC>(p.x_in, (ch.t0 + 2) * K::TM, p.n_nodes, tid);
-        csr.issue(srB, 1, (ch.t0 + 1) * K::TM, p.n_nodes, tid);
+        xrB.template issue_sel<XC>(p.x_in, (tb + dir * (1 + K::LEAD)) * K::TM, p.n_nodes, tid);
+        csr.issue(srB, 1, (tb + dir) * K::TM, p.n_nodes, tid);
     }
 
     // Order inside a tile: GEMM first (its A operand, slab t, was committed during tile t-1; B fragments are
     // resident), THEN commit the prefetched slab t+1 / CSR slice of tile t.  vmcnt is in-order and hipcc waits
     // conservatively (vmcnt(0)) before the commit reads the prefetch registers, so anything still in flight -
     // the previous tile's output stores included - is paid for there: behind the MFMA phase it is (mostly) free.
-    auto do_tile = [&](int t, TileRows<C>& xr, typename TileCsr<C, 0>::Regs& sr) __attribute__((always_inline)) {
+    auto do_tile = [&](int k, TileRows<C>& xr, typename TileCsr<C, 0>::Regs& sr) __attribute__((always_inline)) {
+        const int t = tb + k * dir;
         const int node0 = t * K::TM;
-        const int tslot = (t - ch.t0) * 8;                      // stamps of the first 4 tiles of this workgroup
+        const int tslot = k * 8;                                // stamps of the first 4 tiles of this workgroup
         GADAPT_STAMP(p.stamps, tslot + 0);
         xs = slab_ptr(t);
         int dmax;
@@ -1408,9 +1412,9 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
             if constexpr (K::MFMA) gemm.run(xs, ps);
             GADAPT_STAMP(p.stamps, tslot + 1);
             win = sr.meta.w != 0;
-            xr.template commit_sel<XC>(slab_ptr(t + 1), p.n_nodes, tid);
+            xr.template commit_sel<XC>(slab_ptr(t + dir), p.n_nodes, tid);
             dmax = csr.commit(sr, tid, node0, win ? t : -1);
-            __syncthreads();                                    // P tile, slab t+1 and the CSR slice are complete
+            __syncthreads();                                    // P tile, the next slab and the CSR slice are complete
         } else {                                                // no window: the tile itself is staged first, then projected
             win = false;
             xr.template commit_sel<XC>(xs, p.n_nodes, tid);
@@ -1419,8 +1423,8 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
             __syncthreads();
         }
         {   // this register set's next job: tile t+AHEAD (slab t+AHEAD+LEAD).  Unconditional (clamped past the chunk end): see issue()
-            csr.issue(sr, t + AHEAD - ch.t0, (t + AHEAD) * K::TM, p.n_nodes, tid);
-            xr.template issue_sel<XC>(p.x_in, (t + AHEAD + K::LEAD) * K::TM, p.n_nodes, tid);
+            csr.issue(sr, k + AHEAD, (t + AHEAD * dir) * K::TM, p.n_nodes, tid);
+            xr.template issue_sel<XC>(p.x_in, (t + (AHEAD + K::LEAD) * dir) * K::TM, p.n_nodes, tid);
         }
         if constexpr (K::RING != 3) {
             if constexpr (K::MFMA) { gemm.run(xs, ps); __syncthreads(); }
@@ -1445,13 +1449,13 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
         GADAPT_STAMP(p.stamps, tslot + 7);
     };
     if constexpr (AHEAD == 2) {
-        for (int t = ch.t0; t < ch.t1; t += 2) {
-            do_tile(t, xrA, srA);
-            if (t + 1 < ch.t1) do_tile(t + 1, xrB, srB);
+        for (int k = 0; k < n_my; k += 2) {
+            do_tile(k, xrA, srA);
+            if (k + 1 < n_my) do_tile(k + 1, xrB, srB);
         }
     } else {
 #pragma unroll 1
-        for (int t = ch.t0; t < ch.t1; ++t) do_tile(t, xrA, srA);
+        for (int k = 0; k < n_my; ++k) do_tile(k, xrA, srA);
     }
 }
 
