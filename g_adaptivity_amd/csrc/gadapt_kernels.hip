@@ -92,6 +92,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_T_MFMA_PRIO
 #define GADAPT_T_MFMA_PRIO 0    // s_setprio level of the target pass's matrix phases (0: leave the priority alone)
 #endif
+#ifndef GADAPT_S_ALTERNATE
+#define GADAPT_S_ALTERNATE 0
+#endif
 #ifndef GADAPT_T_ALTERNATE
 #define GADAPT_T_ALTERNATE 1     /* target pass: every other workgroup walks its chunk backwards (see the kernel) */
 #endif
@@ -2111,31 +2114,43 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
     // flight under the barrier)
     constexpr bool RESIDENT_B = K::MFMA && TileGemm<C, false>::SPLIT && GADAPT_S_RESIDENT_B && !DA && C < GADAPT_BWD_JIT_B_C;
     // this workgroup's tiles: every step-th one (XCD-interleaved), or - WIN - a run of consecutive ones
-    TileRange tr;
-    if constexpr (WIN) { const TileChunk ch = tile_chunk(p.n_tiles); tr = {ch.t0, ch.t1, 1}; } else { tr = tile_range(p.n_tiles); }
+    // (tb, stp, n_my): first tile, stride, count.  (WIN: walking every other workgroup's run backwards, as the target pass
+    // does, was measured at hidden 128: 70.5 -> 72.1 us - the rows this pass shares between workgroups are gathered g rows, not
+    // halo slabs.  GADAPT_S_ALTERNATE=1 builds it.)
+    int tb, stp, n_my;
+    if constexpr (WIN) {
+        const TileChunk ch = tile_chunk(p.n_tiles);
+        stp = (GADAPT_S_ALTERNATE && ((blockIdx.x >> 3) & 1)) ? -1 : 1;
+        tb = stp > 0 ? ch.t0 : ch.t1 - 1;
+        n_my = max(ch.t1 - ch.t0, 0);
+    } else {
+        const TileRange tr = tile_range(p.n_tiles);
+        tb = tr.t; stp = tr.step;
+        n_my = tr.t < tr.t_end ? (tr.t_end - tr.t + tr.step - 1) / tr.step : 0;
+    }
     typename CsrT::Regs sr;
     auto slab_ptr = [&](int s_) __attribute__((always_inline)) { return ring + ((s_ + 3) % 3) * K::TILE_FLOATS; };
     TileRows<C> xr;
     if constexpr (WIN) {
         // prologue loads in one memory round trip (see the target pass): the window's first two slabs, metadata, fragments
         TileRows<C> xr2;
-        xr.issue(p.x_in, (tr.t - 1) * K::TM, p.n_nodes, tid);
-        xr2.issue(p.x_in, tr.t * K::TM, p.n_nodes, tid);
-        const int4 mreg = csr.metas_issue(tr.t, tr.step, p.n_tiles, tid);
+        xr.issue(p.x_in, (tb - stp) * K::TM, p.n_nodes, tid);
+        xr2.issue(p.x_in, tb * K::TM, p.n_nodes, tid);
+        const int4 mreg = csr.metas_issue(tb, stp, p.n_tiles, tid);
         if constexpr (RESIDENT_B) gemm.load(p.A, nullptr);
         csr.metas_commit(mreg, tid);
-        xr.commit(slab_ptr(tr.t - 1), p.n_nodes, tid);
-        xr2.commit(slab_ptr(tr.t), p.n_nodes, tid);
+        xr.commit(slab_ptr(tb - stp), p.n_nodes, tid);
+        xr2.commit(slab_ptr(tb), p.n_nodes, tid);
     } else {
-        const int4 mreg = csr.metas_issue(tr.t, tr.step, p.n_tiles, tid);   // one round trip with the fragment loads
+        const int4 mreg = csr.metas_issue(tb, stp, p.n_tiles, tid);   // one round trip with the fragment loads
         if constexpr (RESIDENT_B) gemm.load(p.A, nullptr);
         csr.metas_commit(mreg, tid);
     }
     __syncthreads();
     int kt = 0;                                                 // index of the tile in this workgroup's sequence
-    if (tr.t < tr.t_end) {
-        csr.issue(sr, 0, tr.t * K::TM, p.n_nodes, tid);
-        if constexpr (WIN) xr.issue(p.x_in, (tr.t + 1) * K::TM, p.n_nodes, tid);
+    if (n_my > 0) {
+        csr.issue(sr, 0, tb * K::TM, p.n_nodes, tid);
+        if constexpr (WIN) xr.issue(p.x_in, (tb + stp) * K::TM, p.n_nodes, tid);
     }
     V zr[K::ITERS];                                             // sum(alpha dt g_i) + sigma p0, kept across the GEMM; then the result rows
     // g_out rows of a finished tile leave the registers only after the NEXT tile's staging (see the target pass)
@@ -2147,18 +2162,19 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         }
     };
     int prev_node0 = -1;
-    for (int t = tr.t; t < tr.t_end; t += tr.step) {
+    for (int k = 0; k < n_my; ++k) {
+        const int t = tb + k * stp;
         const int node0 = t * K::TM;
-        const int tslot = ((t - tr.t) / tr.step) * 8;
+        const int tslot = k * 8;
         GADAPT_STAMP(p.stamps, tslot + 0);
         const bool win = WIN && sr.meta.w != 0;
-        if constexpr (WIN) xr.commit(slab_ptr(t + 1), p.n_nodes, tid);
+        if constexpr (WIN) xr.commit(slab_ptr(t + stp), p.n_nodes, tid);
         const int dmax = WIN ? csr.template commit<3>(sr, tid, node0, win ? t : -1) : csr.commit(sr, tid, node0);
         __syncthreads();
         if (prev_node0 >= 0) store_out(prev_node0);
         prev_node0 = node0;
         {   // request the next tile now (unconditional, clamped past the end: see issue()): it lands during this one
-            csr.issue(sr, ++kt, (t + tr.step) * K::TM, p.n_nodes, tid);
+            csr.issue(sr, ++kt, (t + stp) * K::TM, p.n_nodes, tid);
         }
         if constexpr (DA) {                                     // own x rows of this tile -> xt (zeros past N); not held across the edge walk
             TileRows<C> xrows;
@@ -2276,7 +2292,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         }
         GADAPT_STAMP(p.stamps, tslot + 2);
         if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, nullptr);   // in flight under the barrier
-        if constexpr (WIN) xr.issue(p.x_in, (t + 2) * K::TM, p.n_nodes, tid);   // slab of the next tile's window (clamped past the end)
+        if constexpr (WIN) xr.issue(p.x_in, (t + 2 * stp) * K::TM, p.n_nodes, tid);   // slab of the next tile's window (clamped past the end)
         V dpre[K::ITERS];                                       // own dxd rows: requested here, used after the GEMM
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) dpre[it] = ld_vec<C>(p.dxd, min(node0 + it * K::SLOTS + slot, p.n_nodes - 1), sub);
