@@ -92,6 +92,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_T_MFMA_PRIO
 #define GADAPT_T_MFMA_PRIO 0    // s_setprio level of the target pass's matrix phases (0: leave the priority alone)
 #endif
+#ifndef GADAPT_T_STREAM
+#define GADAPT_T_STREAM 0        /* target pass: own g rows and dxd rows non-temporal.  Measured: the target pass gains 0.3 us, the source pass
+                                    that follows LOSES 6 us (24.9 -> 31.0 at hidden 64): it reads dxd, and a normally written dxd is still in
+                                    the caches (L2 / Infinity Cache) when it does.  Off. */
+#endif
+#ifndef GADAPT_S_STREAM
+#define GADAPT_S_STREAM 1        /* windowed source pass: dxd reads and g_out writes non-temporal (they pass through once) */
+#endif
 #ifndef GADAPT_S_ALTERNATE
 #define GADAPT_S_ALTERNATE 0
 #endif
@@ -292,6 +300,18 @@ template <int LPN> __device__ __forceinline__ float group_sum(float v) {
 template <int C> __device__ __forceinline__ float4 ld_row4(const float* __restrict__ base, int row, int sub) {
     const uint32_t off = (uint32_t)row * (uint32_t)(C * 4) + (uint32_t)sub * 16u;
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off);
+}
+// streaming forms (read or written once per launch: keep them from displacing the rows other workgroups gather through L2)
+typedef float f32x4nt __attribute__((ext_vector_type(4)));
+template <int C> __device__ __forceinline__ float4 ld_row4_nt(const float* __restrict__ base, int row, int sub) {
+    const uint32_t off = (uint32_t)row * (uint32_t)(C * 4) + (uint32_t)sub * 16u;
+    const f32x4nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(reinterpret_cast<const char*>(base) + off));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <int C> __device__ __forceinline__ void st_row4_nt(float* __restrict__ base, int row, int sub, const float4& v) {
+    const uint32_t off = (uint32_t)row * (uint32_t)(C * 4) + (uint32_t)sub * 16u;
+    const f32x4nt t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4nt*>(reinterpret_cast<char*>(base) + off));
 }
 template <int C> __device__ __forceinline__ void st_row4(float* __restrict__ base, int row, int sub, const float4& v) {
     const uint32_t off = (uint32_t)row * (uint32_t)(C * 4) + (uint32_t)sub * 16u;
@@ -925,12 +945,14 @@ template <int C> struct TileRows {
     float4 v[XQ];
     int node0_;
     // unconditional clamped loads (see TileCsr::issue); rows past N are zeroed at commit
-    __device__ __forceinline__ void issue(const float* __restrict__ src, int node0, int n_nodes, int tid) {
+    // NT: non-temporal loads (rows that pass through once, e.g. the target pass's own g rows)
+    template <bool NT = false> __device__ __forceinline__ void issue(const float* __restrict__ src, int node0, int n_nodes, int tid) {
         node0_ = node0;
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
             const int idx = min(q * K::NT + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
-            v[q] = ld_row4<C>(src, min(max(node0 + r, 0), n_nodes - 1), c4);
+            if constexpr (NT) v[q] = ld_row4_nt<C>(src, min(max(node0 + r, 0), n_nodes - 1), c4);
+            else v[q] = ld_row4<C>(src, min(max(node0 + r, 0), n_nodes - 1), c4);
         }
     }
     // XC: src is the compact [N,4] matrix (see ld_row4x): one 16-byte load per row (thread t < TM takes row t, in v[0]);
@@ -1675,7 +1697,14 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) {
             const int i = node0 + it * K::SLOTS + slot;
-            if (i < p.n_nodes) st_vec<C>(p.dxd, i, sub, gk[it]);
+            if (i < p.n_nodes) {
+                if constexpr (GADAPT_T_STREAM) {
+#pragma unroll
+                    for (int q = 0; q < K::NV; ++q) st_row4_nt<C>(p.dxd, i, sub + q * K::LPN, gk[it].v[q]);
+                } else {
+                    st_vec<C>(p.dxd, i, sub, gk[it]);
+                }
+            }
         }
     };
     const TileChunk ch = tile_chunk(p.n_tiles);                 // an empty chunk still flushes its (zero) slab row
@@ -1709,7 +1738,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         constexpr bool PREFETCH = (C <= GADAPT_T_PREFETCH_MAX_C);
         if constexpr (PREFETCH) {
             xr.template issue_sel<XC>(p.x_in, (tb + dir * K::LEAD_T) * K::TM, p.n_nodes, tid);
-            if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, tb * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, tb * K::TM, p.n_nodes, tid);
+            if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, tb * K::TM, p.n_nodes, tid); else gr.template issue<GADAPT_T_STREAM != 0>(p.g_in, tb * K::TM, p.n_nodes, tid);
             csr.issue(sr, 0, tb * K::TM, p.n_nodes, tid);
         }
 #pragma unroll 1
@@ -1719,7 +1748,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             const int tslot = k * 8;
             if constexpr (!PREFETCH) {
                 xr.template issue_sel<XC>(p.x_in, (t + dir * K::LEAD_T) * K::TM, p.n_nodes, tid);
-                if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, t * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, t * K::TM, p.n_nodes, tid);
+                if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, t * K::TM, p.n_nodes, tid); else gr.template issue<GADAPT_T_STREAM != 0>(p.g_in, t * K::TM, p.n_nodes, tid);
                 csr.issue(sr, k, t * K::TM, p.n_nodes, tid);
             }
 #ifdef GADAPT_STAMPS
@@ -1756,7 +1785,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                 // of the tile: the edge phase needs every register, and the MFMA phases below cover the round trip.
                 csr.issue(sr, k + 1, (t + dir) * K::TM, p.n_nodes, tid);
                 xr.template issue_sel<XC>(p.x_in, (t + dir * (1 + K::LEAD_T)) * K::TM, p.n_nodes, tid);
-                if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, (t + dir) * K::TM, p.n_nodes, tid); else gr.issue(p.g_in, (t + dir) * K::TM, p.n_nodes, tid);
+                if constexpr (GC) gr.issue_compact(p.g_in, p.g_cols, (t + dir) * K::TM, p.n_nodes, tid); else gr.template issue<GADAPT_T_STREAM != 0>(p.g_in, (t + dir) * K::TM, p.n_nodes, tid);
             }
             __syncthreads();
             GADAPT_STAMP(p.stamps, tslot + 4);
@@ -2158,7 +2187,14 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) {
             const int j = node0 + it * K::SLOTS + slot;
-            if (j < p.n_nodes) st_vec<C>(p.g_out, j, sub, zr[it]);
+            if (j < p.n_nodes) {
+                if constexpr (WIN && GADAPT_S_STREAM) {
+#pragma unroll
+                    for (int q = 0; q < K::NV; ++q) st_row4_nt<C>(p.g_out, j, sub + q * K::LPN, zr[it].v[q]);
+                } else {
+                    st_vec<C>(p.g_out, j, sub, zr[it]);
+                }
+            }
         }
     };
     int prev_node0 = -1;
@@ -2295,7 +2331,15 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         if constexpr (WIN) xr.issue(p.x_in, (t + 2 * stp) * K::TM, p.n_nodes, tid);   // slab of the next tile's window (clamped past the end)
         V dpre[K::ITERS];                                       // own dxd rows: requested here, used after the GEMM
 #pragma unroll
-        for (int it = 0; it < K::ITERS; ++it) dpre[it] = ld_vec<C>(p.dxd, min(node0 + it * K::SLOTS + slot, p.n_nodes - 1), sub);
+        for (int it = 0; it < K::ITERS; ++it) {
+            const int jr = min(node0 + it * K::SLOTS + slot, p.n_nodes - 1);
+            if constexpr (WIN && GADAPT_S_STREAM) {
+#pragma unroll
+                for (int q = 0; q < K::NV; ++q) dpre[it].v[q] = ld_row4_nt<C>(p.dxd, jr, sub + q * K::LPN);
+            } else {
+                dpre[it] = ld_vec<C>(p.dxd, jr, sub);
+            }
+        }
         __syncthreads();
         GADAPT_STAMP(p.stamps, tslot + 3);
 #ifndef GADAPT_ABL_S_NO_GEMM
