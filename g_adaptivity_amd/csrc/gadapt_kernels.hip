@@ -97,8 +97,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
                                     that follows LOSES 6 us (24.9 -> 31.0 at hidden 64): it reads dxd, and a normally written dxd is still in
                                     the caches (L2 / Infinity Cache) when it does.  Off. */
 #endif
+#ifndef GADAPT_S_STREAM_DXD
+#define GADAPT_S_STREAM_DXD 0
+#endif
 #ifndef GADAPT_S_STREAM
-#define GADAPT_S_STREAM 1        /* windowed source pass: dxd reads and g_out writes non-temporal (they pass through once) */
+#define GADAPT_S_STREAM 2        /* windowed source pass: dxd reads and g_out writes (1), and the x slab reads (2), non-temporal: they pass through
+                                    once, the g rows the other workgroups gather should stay in L2 (hidden 128: 70.6 -> 69.1 -> 66.9 us) */
 #endif
 #ifndef GADAPT_S_ALTERNATE
 #define GADAPT_S_ALTERNATE 0
@@ -2163,8 +2167,8 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
     if constexpr (WIN) {
         // prologue loads in one memory round trip (see the target pass): the window's first two slabs, metadata, fragments
         TileRows<C> xr2;
-        xr.issue(p.x_in, (tb - stp) * K::TM, p.n_nodes, tid);
-        xr2.issue(p.x_in, tb * K::TM, p.n_nodes, tid);
+        xr.template issue<GADAPT_S_STREAM == 2>(p.x_in, (tb - stp) * K::TM, p.n_nodes, tid);
+        xr2.template issue<GADAPT_S_STREAM == 2>(p.x_in, tb * K::TM, p.n_nodes, tid);
         const int4 mreg = csr.metas_issue(tb, stp, p.n_tiles, tid);
         if constexpr (RESIDENT_B) gemm.load(p.A, nullptr);
         csr.metas_commit(mreg, tid);
@@ -2179,7 +2183,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
     int kt = 0;                                                 // index of the tile in this workgroup's sequence
     if (n_my > 0) {
         csr.issue(sr, 0, tb * K::TM, p.n_nodes, tid);
-        if constexpr (WIN) xr.issue(p.x_in, (tb + stp) * K::TM, p.n_nodes, tid);
+        if constexpr (WIN) xr.template issue<GADAPT_S_STREAM == 2>(p.x_in, (tb + stp) * K::TM, p.n_nodes, tid);
     }
     V zr[K::ITERS];                                             // sum(alpha dt g_i) + sigma p0, kept across the GEMM; then the result rows
     // g_out rows of a finished tile leave the registers only after the NEXT tile's staging (see the target pass)
@@ -2328,12 +2332,12 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         }
         GADAPT_STAMP(p.stamps, tslot + 2);
         if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, nullptr);   // in flight under the barrier
-        if constexpr (WIN) xr.issue(p.x_in, (t + 2 * stp) * K::TM, p.n_nodes, tid);   // slab of the next tile's window (clamped past the end)
+        if constexpr (WIN) xr.template issue<GADAPT_S_STREAM == 2>(p.x_in, (t + 2 * stp) * K::TM, p.n_nodes, tid);   // slab of the next tile's window (clamped past the end)
         V dpre[K::ITERS];                                       // own dxd rows: requested here, used after the GEMM
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) {
             const int jr = min(node0 + it * K::SLOTS + slot, p.n_nodes - 1);
-            if constexpr (WIN && GADAPT_S_STREAM) {
+            if constexpr ((WIN && GADAPT_S_STREAM) || GADAPT_S_STREAM_DXD) {
 #pragma unroll
                 for (int q = 0; q < K::NV; ++q) dpre[it].v[q] = ld_row4_nt<C>(p.dxd, jr, sub + q * K::LPN);
             } else {
