@@ -55,6 +55,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_WIDE_WG_C
 #define GADAPT_WIDE_WG_C 1024
 #endif
+// Forward at hidden 128 as ONE workgroup per CU at one wave per SIMD with resident weight fragments, the rolling LDS window
+// (Cfg::RING) and staging two tiles ahead - what made the hidden-128 backward kernels faster.  Measured: 62.4 us against 60.4 us
+// for two workgroups per CU gathering through L2 (without the window: 68 against 61).  Off.
 #ifndef GADAPT_FWD_ONE_WAVE
 #define GADAPT_FWD_ONE_WAVE 0
 #endif
@@ -267,7 +270,7 @@ template <int C> struct Cfg {
     // LDS: `tiles` [TM][LD] tiles, rowptr[TM+1] (padded to TM+4), col[COLN], aux[AUXW*COLN]
     static constexpr int MAXM = 64;                    // tile-metadata words of this workgroup's tiles kept in LDS
     static constexpr int lds_bytes(int auxw, int tiles = 2, int ext = 0) { return (tiles * TILE_FLOATS + (TM + 4) + COLN + (auxw + ext) * COLN + 4 * MAXM) * 4; }
-    static constexpr int RING = (C <= 64) ? 3 : 1;     // LDS slabs of x rows kept by the rolling-window kernels; C = 128: a
+    static constexpr int RING = (C <= 64 || (C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_ONE_WAVE)) ? 3 : 1;   // LDS slabs of x rows kept by the rolling-window kernels; C = 128: a
                                                        //   3-slab window would leave one workgroup per CU, so only the tile itself
     static constexpr int LEAD = (RING == 3) ? 1 : 0;   // the slab staged during tile t is slab t + LEAD
     // The target pass keeps the window at hidden 128 too: its 392 registers allow one workgroup per CU whatever the LDS
@@ -1397,7 +1400,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
     // Staging runs TWO tiles ahead (two register sets, used alternately): every workgroup of the launch requests
     // its next slab at the same moment, so one tile of compute does not cover that burst.
     // C = 128 does not have the registers for that (nor for resident B fragments): one set, one tile ahead.
-    constexpr int AHEAD = (C <= 64) ? 2 : 1;
+    constexpr int AHEAD = (C <= 64 || (C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_ONE_WAVE)) ? 2 : 1;
     constexpr bool RESIDENT_B = (C <= 64) || (C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_ONE_WAVE);
     typename TileCsr<C, 0>::Regs srA, srB;
     TileRows<C> xrA, xrB;
