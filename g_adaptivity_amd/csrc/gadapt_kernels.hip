@@ -2638,10 +2638,18 @@ __global__ void slab_reduce1_kernel(const float* slab, float* part, int n_rows, 
     if (e >= row_len) return;
     const int per = (n_rows + GADAPT_SLAB_CHUNKS - 1) / GADAPT_SLAB_CHUNKS;
     const int r0 = blockIdx.y * per, r1 = min(n_rows, r0 + per);
-    float v = 0.f;
-#pragma unroll 8
-    for (int r = r0; r < r1; ++r) v += slab[(size_t)r * row_len + e];
-    part[(size_t)blockIdx.y * row_len + e] = v;
+    // 32 rows in flight per thread, four partial sums (fixed order): the kernel is a handful of memory round trips long
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int r = r0;
+    for (; r + 32 <= r1; r += 32) {
+        float t[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t[k] = slab[(size_t)(r + k) * row_len + e];
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) { v0 += t[k]; v1 += t[k + 1]; v2 += t[k + 2]; v3 += t[k + 3]; }
+    }
+    for (; r < r1; ++r) v0 += slab[(size_t)r * row_len + e];
+    part[(size_t)blockIdx.y * row_len + e] = (v0 + v1) + (v2 + v3);
 }
 __global__ void slab_reduce2_kernel(const float* part, float* d_a, float* d_p0, int c) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
