@@ -3290,6 +3290,30 @@ extern "C" int gadapt_loss_forward(const float* pred, int64_t pred_stride, const
 }
 extern "C" int gadapt_loss_scratch_floats(void) { return GADAPT_LOSS_BLOCKS + 1; }
 
+// ---- gradient exchange: the caller's RCCL communicator, ncclAllReduce resolved at run time (no link-time dependency: the process
+// usually has an RCCL loaded already - torch ships one - and a second copy must not come in with this library)
+#include <dlfcn.h>
+extern "C" int gadapt_allreduce_flat(void* comm, float* bucket, int64_t n, int average, void* stream) {
+    if (!comm || !bucket || n <= 0) return fail(GADAPT_E_BADARG, "allreduce_flat: null communicator / bucket or empty bucket");
+    // ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)
+    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static std::atomic<allreduce_fn> fn{nullptr};
+    allreduce_fn f = fn.load(std::memory_order_acquire);
+    if (!f) {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);          // the copy the process already uses, if any
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return fail(GADAPT_E_RUNTIME, "allreduce_flat: no librccl.so in this process or on the library path");
+        f = reinterpret_cast<allreduce_fn>(dlsym(h, "ncclAllReduce"));
+        if (!f) return fail(GADAPT_E_RUNTIME, "allreduce_flat: librccl.so without ncclAllReduce");
+        fn.store(f, std::memory_order_release);
+    }
+    constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0, NCCL_AVG = 4;          // rccl.h: ncclFloat, ncclSum, ncclAvg
+    const int rc = f(bucket, bucket, (size_t)n, NCCL_FLOAT32, average ? NCCL_AVG : NCCL_SUM, comm, static_cast<hipStream_t>(stream));
+    if (rc != 0) return fail(GADAPT_E_RUNTIME, "allreduce_flat: ncclAllReduce failed");
+    return GADAPT_OK;
+}
+
 extern "C" int gadapt_pad_columns(const float* g_phys, float* g_top, int64_t n_nodes, int d, int c, void* stream) {
     if (!g_phys || !g_top || n_nodes <= 0 || d <= 0 || d > c || c % 4) return fail(GADAPT_E_BADARG, "pad_columns: bad argument");
     const int64_t n = n_nodes * (c / 4);

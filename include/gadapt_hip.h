@@ -33,6 +33,7 @@ extern "C" {
 #define GADAPT_E_BADARG     -1   /* null pointer, negative size, unsupported hidden_dim ... */
 #define GADAPT_E_LAUNCH     -2   /* hipGetLastError() after a launch */
 #define GADAPT_E_RANGE      -3   /* edge endpoint outside [0, n_nodes) */
+#define GADAPT_E_RUNTIME    -4   /* a run-time dependency is missing or failed (gadapt_allreduce_flat: RCCL) */
 
 /* Hidden sizes the fused kernels are built for; others -> GADAPT_E_BADARG. */
 int  gadapt_supported_hidden_dim(int c);
@@ -239,6 +240,16 @@ int gadapt_adam_step(float* param, const float* grad, float* exp_avg, float* exp
 int gadapt_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                          int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                          int32_t* state, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ data-parallel gradient exchange
+ * SUM (average = 0) or AVERAGE (average = 1) of a flat fp32 bucket over the ranks of an RCCL communicator, in place, enqueued
+ * on `stream` (capturable like any RCCL collective).  Replaces what `torch.distributed` / DDP would do for the reference's
+ * `loss.backward()` under data parallelism (src/run_GNN.py:106-131 runs single-process; SURVEY.md section 8(b) item 6 and 8(e): one
+ * all-reduce of the 2(C^2+C)-float bucket per step).  `comm` is the CALLER's ncclComm_t (ncclCommInitRank, or the one a
+ * framework hands out); the library owns no communicator and links no RCCL: it resolves ncclAllReduce from the librccl.so
+ * already loaded in the process (or loads it), GADAPT_E_RUNTIME if there is none.  The Python mirror keeps using
+ * torch.distributed (its process group owns the communicator); this entry point is for callers that hold their own. */
+int gadapt_allreduce_flat(void* comm, float* bucket, int64_t n, int average, void* stream);
 
 /* ------------------------------------------------------------------ timing (bench only)
  * When enabled, every launch of the three hot kernels is bracketed by hipEvents on its

@@ -231,3 +231,38 @@ def test_unit_gradient_is_plain_backward(gpu_device):
         half = grads(fn, torch.full((), 0.5, device=gpu_device))
         assert all(torch.equal(0.5 * a, b) for a, b in zip(plain, half))       # a power of two: exact
     assert unit_gradient(gpu_device) is unit_gradient(gpu_device) and float(unit_gradient(gpu_device)) == 1.0
+
+
+@pytest.mark.gpu
+def test_allreduce_flat_on_a_caller_owned_communicator(gpu_device):
+    """`gadapt_allreduce_flat` with a communicator the caller created itself (RCCL through ctypes, one rank - what a one-GPU
+    box offers): SUM and AVERAGE over one rank leave the bucket as it is, the call is enqueued on the given stream, and
+    a null communicator is refused.  (Two ranks need two GPUs: the N > 1 path of the Python mirror is covered by
+    test_two_rank_step_equals_full_batch_step with torch.distributed.)"""
+    import ctypes as C
+    from g_adaptivity_amd import _native
+    rccl = C.CDLL('librccl.so')                                  # the copy torch has loaded already
+
+    class UniqueId(C.Structure):
+        _fields_ = [('internal', C.c_char * 128)]
+
+    uid, comm = UniqueId(), C.c_void_p()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    torch.cuda.set_device(gpu_device)
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        lib = _native.lib()
+        bucket = torch.randn(2 * (64 * 64 + 64), device=gpu_device)
+        ref = bucket.clone()
+        stream = torch.cuda.current_stream(gpu_device).cuda_stream
+        for average in (0, 1):
+            assert lib.gadapt_allreduce_flat(comm, bucket.data_ptr(), bucket.numel(), average, stream) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(bucket, ref)
+        assert lib.gadapt_allreduce_flat(None, bucket.data_ptr(), bucket.numel(), 0, stream) < 0
+        assert b'allreduce_flat' in lib.gadapt_last_error()
+    finally:
+        rccl.ncclCommDestroy(comm)
