@@ -47,6 +47,11 @@ CASES = [
     ((128, 128), 1, 64, 20, 'GRAND_plus', {}),
     # BASELINE config 2 at its full batch (32 meshes 32x32, 4 layers, hidden 64)
     ((32, 32), 32, 64, 4, 'GRAND_plus', {}),
+    # The other BASELINE configs at their FULL sizes (the fp64 oracle takes 8 / 16 / 56 s on the GPU box's host cores): config 3's
+    # per-GPU shard = the metric workload, config 4, config 5
+    ((64, 64), 32, 64, 4, 'GRAND_plus', {}),
+    ((64, 64), 32, 128, 6, 'GRAND', {'gnn_inc_feat_f': False, 'noise_factor': 3.0}),
+    ((128, 128), 16, 64, 20, 'GRAND_plus', {}),
 ]
 TRANS_CASES = [((11, 11), 2, 8, 3, 'relu'), ((14, 14), 3, 64, 2, 'tanh'), ((12, 12), 2, 32, 2, 'identity')]
 IDS = [f"{'x'.join(map(str, c[0]))}-b{c[1]}-C{c[2]}-L{c[3]}-{c[4]}" + ('-' + ','.join(k for k in c[5] if k != 'noise_factor') if c[5] else '') for c in CASES]
