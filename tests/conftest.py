@@ -15,6 +15,12 @@ _graph_mod.WIDE_MIN_NODES = 0
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle is torch code: on a many-core host torch's default thread count oversubscribes its index_add_ / gather
+    # loops (measured on the 256-core GPU box: 6 meshes/s at 128 threads, 27 at 16).  Cap it unless the caller chose a count.
+    if 'OMP_NUM_THREADS' not in os.environ:
+        import torch
+        if torch.get_num_threads() > 16:
+            torch.set_num_threads(16)
 
 
 @pytest.fixture(scope="session")
