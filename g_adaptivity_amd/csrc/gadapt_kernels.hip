@@ -986,14 +986,12 @@ template <int C> struct TileRows {
             commit(tile, n_nodes, tid);
         }
     }
-    // same for a compact [N,d] source (ld_row4_compact)
+    // same for a compact [N,d] source (ld_row4_compact): like the XC form, thread t < TM takes row t (chunk 0, in v[0]) and the
+    // commit (commit_sel<true>) writes zeros everywhere else - not XQ chunk loads per thread of which one in V carries data
     __device__ __forceinline__ void issue_compact(const float* __restrict__ src, int d, int node0, int n_nodes, int tid) {
+        static_assert(K::TM <= K::NT, "one compact row per thread");
         node0_ = node0;
-#pragma unroll
-        for (int q = 0; q < XQ; ++q) {
-            const int idx = min(q * K::NT + tid, K::TM * V - 1), r = idx / V, c4 = idx % V;
-            v[q] = ld_row4_compact(src, min(max(node0 + r, 0), n_nodes - 1), c4, d);
-        }
+        v[0] = ld_row4_compact(src, min(max(node0 + min(tid, K::TM - 1), 0), n_nodes - 1), 0, d);
     }
     __device__ __forceinline__ void commit(float* tile, int n_nodes, int tid) const {
 #pragma unroll
@@ -1765,7 +1763,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             xs = slab_ptr(t);
             const bool win = K::RING_T == 3 && sr.meta.w != 0;
             xr.template commit_sel<XC>(slab_ptr(t + dir * K::LEAD_T), p.n_nodes, tid);
-            gr.commit(ds, p.n_nodes, tid);
+            gr.template commit_sel<GC>(ds, p.n_nodes, tid);
             const int dmax = csr.template commit<K::RING_T>(sr, tid, node0, win ? t : -1);
             GADAPT_STAMP(p.stamps, tslot + 1);
             __syncthreads();
