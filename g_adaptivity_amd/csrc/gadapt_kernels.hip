@@ -2117,8 +2117,9 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
     auto ld_g = [&](int i) __attribute__((always_inline)) {
         if constexpr (GC) {
             V r;
+            r.v[0] = ld_row4_compact(p.g_in, i, sub, p.g_cols);  // chunk `sub` of the row: data in chunk 0 only, zeros elsewhere
 #pragma unroll
-            for (int q = 0; q < K::NV; ++q) r.v[q] = ld_row4_compact(p.g_in, i, sub + q * K::LPN, p.g_cols);
+            for (int q = 1; q < K::NV; ++q) r.v[q] = f4zero();   // chunks sub + q LPN > 0: no load
             return r;
         } else {
             return ld_vec<C>(p.g_in, i, sub);
