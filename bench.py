@@ -168,7 +168,10 @@ def main():
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             optim.zero_grad()
-            with torch.cuda.graph(g, stream=side):
+            # N > 1: other threads of the process make CUDA calls while this one captures (the RCCL process group's watchdog
+            # polls events); "thread_local" keeps those from invalidating the capture.  GADAPT_BENCH_CAPTURE_MODE overrides.
+            mode = os.environ.get('GADAPT_BENCH_CAPTURE_MODE', 'thread_local' if world > 1 else 'global')
+            with torch.cuda.graph(g, stream=side, capture_error_mode=mode):
                 static_loss = fwd_bwd()
                 if capture_all:
                     optim.step()
