@@ -19,6 +19,14 @@
  * the second term does not depend on j and cancels in the softmax, so the kernels
  * work from (A, p0): one [C,C] projection per node instead of two, and the edge walk
  * gathers x_j only.
+ *
+ * Arithmetic.  Everything is fp32 in and out.  At hidden sizes >= 32 the [nodes,C] x [C,C] products (P = x A^T, dP A, A y and
+ * the dA partial) run on the 16-bit matrix cores from operands split into pieces that restore fp32 accuracy: three bf16
+ * pieces (x = h + m + l exactly, six piece products, the dropped ones below 2^-23 |x y|) or, where the operand tile is prepared
+ * once per tile, two f16 pieces after an exact power-of-two scaling per row / column group (hh + hl + lh, dropped term below
+ * 2^-22 |x y|); piece products are exact in the fp32 accumulators.  The softmax uses expf and a true
+ * division.  Measured against an fp64 evaluation: coordinates 1e-7 relative, parameter gradients at the fp32 reference
+ * path's own rounding level (tests/test_gpu_parity.py, full BASELINE sizes included).
  */
 #ifndef GADAPT_HIP_H
 #define GADAPT_HIP_H
