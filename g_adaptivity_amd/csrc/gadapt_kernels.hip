@@ -113,6 +113,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_T_ALTERNATE
 #define GADAPT_T_ALTERNATE 1     /* target pass: every other workgroup walks its chunk backwards (see the kernel) */
 #endif
+#ifndef GADAPT_DA_BPREFETCH
+#define GADAPT_DA_BPREFETCH 1
+#endif
 #ifndef GADAPT_DA_UNROLL
 #define GADAPT_DA_UNROLL 2      // k-steps of the dA loop unrolled together
 #endif
@@ -1867,6 +1870,27 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 #pragma unroll
                     for (int e = 0; e < 8; ++e) av[e] = ds[(n0 + e) * K::LD + ob * 32 + r31];
                     const Split3 as = split8(av);
+#if GADAPT_DA_BPREFETCH
+                    // several blocks per wave (hidden 128): the x columns of block b + 1 are requested before block b is split
+                    // and multiplied
+                    float bv[2][8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[0][e] = xs[(n0 + e) * K::LD + cb0 * 32 + r31];
+#pragma unroll
+                    for (int b = 0; b < DPW; ++b) {
+                        if (b + 1 < DPW) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) bv[(b + 1) & 1][e] = xs[(n0 + e) * K::LD + (cb0 + b + 1) * 32 + r31];
+                        }
+                        const Split3 bs = split8(bv[b & 1]);
+                        dacc[b] = mfma_bf16(as.h, bs.l, dacc[b]);
+                        dacc[b] = mfma_bf16(as.l, bs.h, dacc[b]);
+                        dacc[b] = mfma_bf16(as.m, bs.m, dacc[b]);
+                        dacc[b] = mfma_bf16(as.h, bs.m, dacc[b]);
+                        dacc[b] = mfma_bf16(as.m, bs.h, dacc[b]);
+                        dacc[b] = mfma_bf16(as.h, bs.h, dacc[b]);
+                    }
+#else
 #pragma unroll
                     for (int b = 0; b < DPW; ++b) {
                         float bv[8];
@@ -1880,6 +1904,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                         dacc[b] = mfma_bf16(as.m, bs.h, dacc[b]);
                         dacc[b] = mfma_bf16(as.h, bs.h, dacc[b]);
                     }
+#endif
                 }
             } else if constexpr (K::MFMA) {
                 const int h = lane >> 5, r31 = lane & 31;
