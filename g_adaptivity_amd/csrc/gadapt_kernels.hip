@@ -642,6 +642,41 @@ template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct T
         bias = bias_vec ? bias_vec[j] : 0.f;
     }
 
+    // The same in two halves for kernels that rebuild the fragments per tile (hidden 128 forward): the loads are requested
+    // before other work of the tile (staging commits), the split runs after it - the L2 round trip is no longer exposed.
+    struct BRaw { float v[(SPLIT && F16_) ? KS : 1][8]; };
+    __device__ __forceinline__ void load_issue(const float* __restrict__ M, BRaw& raw) const {
+        if constexpr (F16) {
+            const int h = lane >> 5, j = cb * 32 + (lane & 31);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (!TRANS) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(M + (size_t)j * C + 16 * ks + 8 * h);
+                    const float4 v1 = *reinterpret_cast<const float4*>(M + (size_t)j * C + 16 * ks + 8 * h + 4);
+                    raw.v[ks][0] = v0.x; raw.v[ks][1] = v0.y; raw.v[ks][2] = v0.z; raw.v[ks][3] = v0.w;
+                    raw.v[ks][4] = v1.x; raw.v[ks][5] = v1.y; raw.v[ks][6] = v1.z; raw.v[ks][7] = v1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) raw.v[ks][e] = M[(size_t)(16 * ks + 8 * h + e) * C + j];
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void load_finish(const float* __restrict__ M, const float* __restrict__ bias_vec, const BRaw& raw) {
+        if constexpr (F16) {
+            float mx = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) mx = absmax8(raw.v[ks], mx);
+            const Pow2 sb = pow2_scale(half_max(mx));
+            binv = sb.inv;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bh[ks] = split8h(raw.v[ks], sb.s);
+            bias = bias_vec ? bias_vec[cb * 32 + (lane & 31)] : 0.f;
+        } else {
+            load(M, bias_vec);
+        }
+    }
+
     // in_tile/out_tile: LDS [TM][LD].  Caller synchronises around it.
     __device__ __forceinline__ void accumulate(const float* in_tile, f32x16 (&acc)[BPW]) {
         const int h = lane >> 5, r31 = lane & 31;
@@ -1450,9 +1485,11 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
             __syncthreads();                                    // P tile, the next slab and the CSR slice are complete
         } else {                                                // no window: the tile itself is staged first, then projected
             win = false;
+            typename decltype(gemm)::BRaw braw;
+            if constexpr (K::MFMA && !RESIDENT_B) gemm.load_issue(p.A, braw);   // weight rows requested first: in flight under the commits
             xr.template commit_sel<XC>(xs, p.n_nodes, tid);
             dmax = csr.commit(sr, tid, node0, -1);
-            if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, p.p0);
+            if constexpr (K::MFMA && !RESIDENT_B) gemm.load_finish(p.A, p.p0, braw);
             __syncthreads();
         }
         {   // this register set's next job: tile t+AHEAD (slab t+AHEAD+LEAD).  Unconditional (clamped past the chunk end): see issue()
