@@ -479,6 +479,9 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 #ifndef GADAPT_PRESPLIT_S
 #define GADAPT_PRESPLIT_S 1         // source pass: the y tile
 #endif
+#ifndef GADAPT_PRESPLIT_F
+#define GADAPT_PRESPLIT_F 1         // forward without the LDS window (hidden 128): the x tile, at staging
+#endif
 #ifndef GADAPT_PRESPLIT_T
 #define GADAPT_PRESPLIT_T 1         // target pass: dP for dP A (copy in the window slot that is free after the edge walk)
 #endif
@@ -1024,6 +1027,31 @@ template <int C> struct TileRows {
             commit(tile, n_nodes, tid);
         }
     }
+    // commit() plus a pre-split f16 copy of the rows (layout of lds_put_split) in `ptile`, the row's inverse scale in ptile's
+    // first pad column: for a tile whose rows are projected right after staging (forward without the LDS window, hidden 128).
+    // A row's V = 32 chunks sit in 32 consecutive threads - half a wave - so its maximum is four DPP steps and one swizzle.
+    __device__ __forceinline__ void commit_presplit(float* tile, float* ptile, int n_nodes, int tid) const {
+        static_assert(V == 32 && (K::TM * V) % K::NT == 0, "pre-split staging: rows of 32 chunks, whole rows per pass");
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = q * K::NT + tid, r = idx / V, c4 = idx % V;
+            const float4 x = (node0_ + r < n_nodes && node0_ + r >= 0) ? v[q] : f4zero();
+            *reinterpret_cast<float4*>(tile + r * K::LD + 4 * c4) = x;
+            float m = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+            m = dpp_max<0xB1>(m); m = dpp_max<0x4E>(m); m = dpp_max<0x141>(m); m = dpp_max<0x140>(m);
+            m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, m), 0x401F)));
+            const Pow2 s = pow2_scale(m);
+            const float t0 = x.x * s.s, t1 = x.y * s.s, t2 = x.z * s.s, t3 = x.w * s.s;
+            f16x2 h01, h23, l01, l23;
+            h01.x = (_Float16)t0; h01.y = (_Float16)t1; h23.x = (_Float16)t2; h23.y = (_Float16)t3;
+            l01.x = (_Float16)(t0 - (float)h01.x); l01.y = (_Float16)(t1 - (float)h01.y);
+            l23.x = (_Float16)(t2 - (float)h23.x); l23.y = (_Float16)(t3 - (float)h23.y);
+            uint2* grp = reinterpret_cast<uint2*>(ptile + r * K::LD + 8 * (c4 >> 1));
+            grp[c4 & 1] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+            grp[2 + (c4 & 1)] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+            if (c4 == 0) ptile[r * K::LD + C] = s.inv;
+        }
+    }
     // same for a compact [N,d] source (ld_row4_compact): like the XC form, thread t < TM takes row t (chunk 0, in v[0]) and the
     // commit (commit_sel<true>) writes zeros everywhere else - not XQ chunk loads per thread of which one in V carries data
     __device__ __forceinline__ void issue_compact(const float* __restrict__ src, int d, int node0, int n_nodes, int tid) {
@@ -1305,9 +1333,26 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
         p0v = *reinterpret_cast<const float4*>(p.p0 + 4 * sub);
     }
 
+    // PREA: the tile's rows are staged twice - fp32 for the edge walk and pre-split f16 (per-row scale) as the projection's A
+    // operand, which no wave then splits again (hidden 128 without the LDS window: every wave needed every row); the P tile
+    // holds acc x (column scale) and the reader applies the row scale and p0
+    constexpr bool PREA = K::MFMA && K::RING != 3 && !XC && GADAPT_PRESPLIT_F && C / 4 == 32 && TileGemm<C, false, GADAPT_SPLIT_F16_F(C)>::F16;
+    V p0c;
+    if constexpr (PREA) {
+#pragma unroll
+        for (int q = 0; q < K::NV; ++q) p0c.v[q] = *reinterpret_cast<const float4*>(p.p0 + 4 * (sub + q * K::LPN));
+    }
     auto projected = [&](int li) __attribute__((always_inline)) {                               // P_i = A x_i + p0 for this lane's channels
         V Pi;
-        if constexpr (K::MFMA) {
+        if constexpr (PREA) {
+            Pi = lds_vec<C>(ps, li, sub);
+            const float ri = ps[li * K::LD + C];
+#pragma unroll
+            for (int q = 0; q < K::NV; ++q) {
+                Pi.v[q].x = fmaf(Pi.v[q].x, ri, p0c.v[q].x); Pi.v[q].y = fmaf(Pi.v[q].y, ri, p0c.v[q].y);
+                Pi.v[q].z = fmaf(Pi.v[q].z, ri, p0c.v[q].z); Pi.v[q].w = fmaf(Pi.v[q].w, ri, p0c.v[q].w);
+            }
+        } else if constexpr (K::MFMA) {
             Pi = lds_vec<C>(ps, li, sub);
         } else {
             Pi.v[0] = p0v;
@@ -1487,6 +1532,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
             win = false;
             typename decltype(gemm)::BRaw braw;
             if constexpr (K::MFMA && !RESIDENT_B) gemm.load_issue(p.A, braw);   // weight rows requested first: in flight under the commits
+            if constexpr (PREA) xr.commit_presplit(xs, ps, p.n_nodes, tid); else
             xr.template commit_sel<XC>(xs, p.n_nodes, tid);
             dmax = csr.commit(sr, tid, node0, -1);
             if constexpr (K::MFMA && !RESIDENT_B) gemm.load_finish(p.A, p.p0, braw);
@@ -1497,7 +1543,13 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
             xr.template issue_sel<XC>(p.x_in, (t + (AHEAD + K::LEAD) * dir) * K::TM, p.n_nodes, tid);
         }
         if constexpr (K::RING != 3) {
-            if constexpr (K::MFMA) { gemm.run(xs, ps); __syncthreads(); }
+            if constexpr (PREA) {
+                f32x16 acc[decltype(gemm)::BPW];
+                gemm.accumulate_presplit(ps, acc);
+                __syncthreads();                                // in place: every wave has read its operand rows
+                gemm.store_presplit(ps, acc);
+                __syncthreads();
+            } else if constexpr (K::MFMA) { gemm.run(xs, ps); __syncthreads(); }
             GADAPT_STAMP(p.stamps, tslot + 1);
         }
         GADAPT_STAMP(p.stamps, tslot + 2);
