@@ -479,6 +479,9 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 #ifndef GADAPT_PRESPLIT_S
 #define GADAPT_PRESPLIT_S 1         // source pass: the y tile
 #endif
+#ifndef GADAPT_XC_ONE_KSTEP
+#define GADAPT_XC_ONE_KSTEP 1       // compact layer input [N,4]: the projection's operand is zero beyond column 3 - one k-step of 16
+#endif
 #ifndef GADAPT_PRESPLIT_F
 #define GADAPT_PRESPLIT_F 1         // forward without the LDS window (hidden 128): the x tile, at staging
 #endif
@@ -681,7 +684,8 @@ template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct T
     }
 
     // in_tile/out_tile: LDS [TM][LD].  Caller synchronises around it.
-    __device__ __forceinline__ void accumulate(const float* in_tile, f32x16 (&acc)[BPW]) {
+    // KSU: k-steps that carry data (the caller knows the operand is zero beyond 16 KSU columns: compact layer input)
+    template <int KSU = KS> __device__ __forceinline__ void accumulate(const float* in_tile, f32x16 (&acc)[BPW]) {
         const int h = lane >> 5, r31 = lane & 31;
 #pragma unroll
         for (int b = 0; b < BPW; ++b) {
@@ -696,31 +700,31 @@ template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct T
                     v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
                 };
                 float mx = 0.f;
-                if constexpr (KS <= 4) {                               // the block's rows stay in registers between the two uses
-                    float v[KS][8];
+                if constexpr (KSU <= 4) {                               // the block's rows stay in registers between the two uses
+                    float v[KSU][8];
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) rd(ks, v[ks]);
+                    for (int ks = 0; ks < KSU; ++ks) rd(ks, v[ks]);
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) mx = absmax8(v[ks], mx);
+                    for (int ks = 0; ks < KSU; ++ks) mx = absmax8(v[ks], mx);
                     const Pow2 sa = pow2_scale(quad_rows_max(mx));
                     quad_rows_inverse(sa.inv, h, oinv[b]);
 #if GADAPT_MFMA_INTERLEAVE
                     Split2 cur = split8h(v[0], sa.s);
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {                  // split of k-step ks+1 in the gaps of the three products of ks
+                    for (int ks = 0; ks < KSU; ++ks) {                  // split of k-step ks+1 in the gaps of the three products of ks
                         Split2 nxt = cur;
-                        if (ks + 1 < KS) nxt = split8h(v[ks + 1], sa.s);
+                        if (ks + 1 < KSU) nxt = split8h(v[ks + 1], sa.s);
                         acc[b] = mma3(cur, bh[ks], acc[b]);
-                        if (ks + 1 < KS) mfma_gap_pattern<0, 8, 3>();
+                        if (ks + 1 < KSU) mfma_gap_pattern<0, 8, 3>();
                         cur = nxt;
                     }
 #else
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) acc[b] = mma3(split8h(v[ks], sa.s), bh[ks], acc[b]);
+                    for (int ks = 0; ks < KSU; ++ks) acc[b] = mma3(split8h(v[ks], sa.s), bh[ks], acc[b]);
 #endif
                 } else {                                               // hidden 128: read twice rather than hold 64 registers
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) { float v[8]; rd(ks, v); mx = absmax8(v, mx); }
+                    for (int ks = 0; ks < KSU; ++ks) { float v[8]; rd(ks, v); mx = absmax8(v, mx); }
                     const Pow2 sa = pow2_scale(quad_rows_max(mx));
                     quad_rows_inverse(sa.inv, h, oinv[b]);
 #if GADAPT_MFMA_INTERLEAVE
@@ -728,16 +732,16 @@ template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct T
                     rd(0, v0);
                     Split2 cur = split8h(v0, sa.s);
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
+                    for (int ks = 0; ks < KSU; ++ks) {
                         Split2 nxt = cur;
-                        if (ks + 1 < KS) { float v[8]; rd(ks + 1, v); nxt = split8h(v, sa.s); }
+                        if (ks + 1 < KSU) { float v[8]; rd(ks + 1, v); nxt = split8h(v, sa.s); }
                         acc[b] = mma3(cur, bh[ks], acc[b]);
-                        if (ks + 1 < KS) mfma_gap_pattern<2, 8, 3>();
+                        if (ks + 1 < KSU) mfma_gap_pattern<2, 8, 3>();
                         cur = nxt;
                     }
 #else
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) { float v[8]; rd(ks, v); acc[b] = mma3(split8h(v, sa.s), bh[ks], acc[b]); }
+                    for (int ks = 0; ks < KSU; ++ks) { float v[8]; rd(ks, v); acc[b] = mma3(split8h(v, sa.s), bh[ks], acc[b]); }
 #endif
                 }
 #pragma unroll
@@ -757,21 +761,21 @@ template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct T
                 // the vector ALU idle during the six: 384 cycles per k-step measured at one wave per SIMD (hidden 128).
                 Split3 cur = ldsplit(0);
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
+                for (int ks = 0; ks < KSU; ++ks) {
                     Split3 nxt = cur;
-                    if (ks + 1 < KS) nxt = ldsplit(ks + 1);
+                    if (ks + 1 < KSU) nxt = ldsplit(ks + 1);
                     acc[b] = mfma_bf16(cur.h, bs[ks].l, acc[b]);        // small pieces first
                     acc[b] = mfma_bf16(cur.l, bs[ks].h, acc[b]);
                     acc[b] = mfma_bf16(cur.m, bs[ks].m, acc[b]);
                     acc[b] = mfma_bf16(cur.h, bs[ks].m, acc[b]);
                     acc[b] = mfma_bf16(cur.m, bs[ks].h, acc[b]);
                     acc[b] = mfma_bf16(cur.h, bs[ks].h, acc[b]);
-                    if (ks + 1 < KS) mfma_gap_pattern<2, 8>();
+                    if (ks + 1 < KSU) mfma_gap_pattern<2, 8>();
                     cur = nxt;
                 }
 #else
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
+                for (int ks = 0; ks < KSU; ++ks) {
                     const Split3 as = ldsplit(ks);
                     acc[b] = mfma_bf16(as.h, bs[ks].l, acc[b]);         // small pieces first
                     acc[b] = mfma_bf16(as.l, bs[ks].h, acc[b]);
@@ -837,9 +841,9 @@ template <int C, bool TRANS, bool F16_ = (TRANS && GADAPT_SPLIT_F16_T)> struct T
             for (int r = 0; r < 16; ++r) ocol[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * K::LD] = acc[b][r] * binv;
         }
     }
-    __device__ __forceinline__ void run(const float* in_tile, float* out_tile) {
+    template <int KSU = KS> __device__ __forceinline__ void run(const float* in_tile, float* out_tile) {
         f32x16 acc[BPW];
-        accumulate(in_tile, acc);
+        accumulate<KSU>(in_tile, acc);
         store(out_tile, acc);
     }
     // out == in: every wave reads its operand rows before any wave overwrites them (two workgroup barriers inside)
@@ -1522,7 +1526,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
         int dmax;
         if constexpr (K::RING == 3) {
             if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, p.p0);
-            if constexpr (K::MFMA) gemm.run(xs, ps);
+            if constexpr (K::MFMA) gemm.template run<(XC && GADAPT_XC_ONE_KSTEP) ? 1 : (C >= 16 ? C / 16 : 1)>(xs, ps);
             GADAPT_STAMP(p.stamps, tslot + 1);
             win = sr.meta.w != 0;
             xr.template commit_sel<XC>(slab_ptr(t + dir), p.n_nodes, tid);
@@ -1549,7 +1553,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, ((C >= GADAPT_ONE_WAVE_C && GADAPT_FWD_
                 __syncthreads();                                // in place: every wave has read its operand rows
                 gemm.store_presplit(ps, acc);
                 __syncthreads();
-            } else if constexpr (K::MFMA) { gemm.run(xs, ps); __syncthreads(); }
+            } else if constexpr (K::MFMA) { gemm.template run<(XC && GADAPT_XC_ONE_KSTEP) ? 1 : (C >= 16 ? C / 16 : 1)>(xs, ps); __syncthreads(); }
             GADAPT_STAMP(p.stamps, tslot + 1);
         }
         GADAPT_STAMP(p.stamps, tslot + 2);
