@@ -1971,6 +1971,8 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                     for (int e = 0; e < 8; ++e) bv[0][e] = xs[(n0 + e) * K::LD + cb0 * 32 + r31];
 #pragma unroll
                     for (int b = 0; b < DPW; ++b) {
+                        // compact layer input: x is zero beyond column 3, so only column block 0 of dA gets anything
+                        if (XC && GADAPT_XC_ONE_KSTEP && cb0 + b > 0) continue;
                         if (b + 1 < DPW) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) bv[(b + 1) & 1][e] = xs[(n0 + e) * K::LD + (cb0 + b + 1) * 32 + r31];
