@@ -9,12 +9,11 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wall -Wno-u
 
 all: $(LIB)
 
-$(LIB): $(CSRC)/gadapt_kernels.hip $(CSRC)/gadapt_wide.inc $(CSRC)/gadapt_sparse.inc $(CSRC)/csr_build.cpp include/gadapt_hip.h
+$(LIB): $(CSRC)/gadapt_kernels.hip $(wildcard $(CSRC)/*.inc) $(CSRC)/csr_build.cpp include/gadapt_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/gadapt_kernels.hip $(CSRC)/csr_build.cpp
 
-resources: $(CSRC)/gadapt_kernels.hip include/gadapt_hip.h
-	$(HIPCC) $(HIPFLAGS) -c -o /dev/null $(CSRC)/gadapt_kernels.hip -Rpass-analysis=kernel-resource-usage 2>&1 | \
-	  grep -E "Function Name|VGPRs:|AGPRs|SGPRs:|Occupancy|LDS Size|ScratchSize" | paste - - - - - - - | sed 's/remark: [^:]*:[0-9]*:[0-9]*: //g'
+resources:
+	python3 tools/resources.py
 
 clean:
 	rm -f $(LIB)

@@ -3198,15 +3198,16 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     ProfScope prof(2, st, g_cols ? 1 : 0);
     if constexpr (CAN_MOVE_DA) {
         if (da_in_s) {
-            // same grid as the target pass: the slab holds one row per workgroup of either
-            static_assert(GADAPT_BWD_S_MAX_BLOCKS == GADAPT_BWD_T_MAX_BLOCKS, "slab rows = workgroups of the pass that flushes them");
+            // the grid EXPRESSION of the target pass (resident_blocks_bwd_t: what gadapt_backward_slab_rows sizes the slab with),
+            // not the source pass's own: at hidden 32 the two differ (256 against 512 workgroups) and the slab holds one row per
+            // workgroup of the pass that flushes it
             constexpr int lds_sd = K::lds_bytes(2, 3);
             if (g_cols) {
                 allow_lds(grand_bwd_source_kernel<C, true, true>, lds_sd);
-                hipLaunchKernelGGL((grand_bwd_source_kernel<C, true, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_sd, st, ps);
+                hipLaunchKernelGGL((grand_bwd_source_kernel<C, true, true>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_sd, st, ps);
             } else {
                 allow_lds(grand_bwd_source_kernel<C, false, true>, lds_sd);
-                hipLaunchKernelGGL((grand_bwd_source_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd<C>(GADAPT_BWD_S_MAX_BLOCKS))), dim3(K::NT), lds_sd, st, ps);
+                hipLaunchKernelGGL((grand_bwd_source_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_sd, st, ps);
             }
             return check_launch("grand_bwd_source_kernel");
         }

@@ -67,8 +67,23 @@ def _fp_weight(n: int, device) -> torch.Tensor:
     return w
 
 
+# splitmix64 constants as signed int64 (torch integer arithmetic wraps around)
+_FP_GOLD, _FP_M1, _FP_M2 = -7046029254386353131, -4658895280553007687, -7723592293110705685
+
+
+def _fp_mix(v: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """Position-dependent NON-LINEAR mix of every element (splitmix64 finaliser of v_i + (i+1) * golden ratio).  A linear
+    checksum pair (sum of v_i * (i+1), sum of v_i) collides on structured edits - e.g. flipping the diagonal of one grid quad,
+    (a, a+n+1) -> (a+1, a+n) in place in both directions, keeps both sums - and would hand back a stale CSR."""
+    z = v + w * _FP_GOLD
+    z = (z ^ (z >> 30)) * _FP_M1
+    z = (z ^ (z >> 27)) * _FP_M2
+    return z ^ (z >> 31)
+
+
 def content_fingerprint(tensors) -> Tuple:
-    """Order-sensitive checksums (int64 wrap-around arithmetic) of integer / bool tensors, on the device they live on.
+    """Order-sensitive checksums (int64 wrap-around arithmetic) of integer / bool tensors, on the device they live on: the sum
+    of a per-element, position-dependent 64-bit hash (`_fp_mix`) and the plain sum.
 
     Memoised per tensor OBJECT (weak reference + version counter + data pointer): a batch object fed again - every step
     of a hipGraph-free training loop over `DeviceMeshLoader`, every call of a rollout - costs a dictionary lookup; a new
@@ -88,10 +103,7 @@ def content_fingerprint(tensors) -> Tuple:
             if n == 0:
                 sums.append(torch.zeros(2, dtype=torch.int64, device=v.device))
                 continue
-            w = _fp_weight(n, v.device)
-            # two checksums without [n]-sized temporaries: an order-sensitive weighted sum and the plain sum
-            weighted = torch.dot(v, w) if v.device.type == 'cpu' else (v * w).sum()   # integer dot exists on the CPU only
-            sums.append(torch.stack([weighted, v.sum()]))
+            sums.append(torch.stack([_fp_mix(v, _fp_weight(n, v.device)).sum(), v.sum()]))
         by_dev = {}
         for k, s_ in zip(todo, sums):
             by_dev.setdefault(str(s_.device), []).append((k, s_))

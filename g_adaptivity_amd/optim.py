@@ -35,6 +35,14 @@ class FlatAdam:
     hands that memory to the kernel as the gradient bucket: no per-parameter accumulate kernels, no zero fill.
     Any other situation (gradients accumulated over several backward calls, parameters from elsewhere) is
     handled by gathering the gradients into an own bucket first.
+
+    Restriction against `torch.optim.Adam` (which keeps a step count and moments PER parameter and simply skips a parameter
+    whose `.grad` is None on a given step): one flat bucket shares ONE step count.  A parameter that drops out of the
+    gradient set (e.g. `zero_grad(set_to_none=True)` plus a branch that does not use it this step) is dropped from the
+    bucket with its moments, and its return raises `RuntimeError` instead of silently giving it another parameter's bias
+    correction.  Every parameter the reference's `GNN` trains (`lin_query/lin_key` weights and biases, `steps`,
+    `sm_temp_a`, the CNN extractors) receives a gradient on every step, so the reference's loop never meets this; a model
+    with conditionally used parameters needs `torch.optim.Adam` (or one FlatAdam per always-together parameter set).
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,

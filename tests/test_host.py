@@ -295,3 +295,29 @@ def test_mlp_baseline_model():
     x = torch.tanh(x + 0.1 * m.fc2(x))
     assert out.shape == (72, 8) and torch.allclose(out, x, atol=1e-7)
     assert set(m.state_dict()) == {'enc.weight', 'fc1.weight', 'fc1.bias', 'fc2.weight', 'fc2.bias'}
+
+
+def test_fingerprint_separates_diagonal_flip():
+    """flipping the diagonal of ONE grid quad in place - (a, a+n+1) -> (a+1, a+n), both directions - keeps every linear
+    checksum (sum of v_i, sum of v_i * (i+1)) because both endpoint pairs sum to 2a+n+1; the cache key must still change."""
+    from g_adaptivity_amd.graph import content_fingerprint
+    n, a = 8, 10
+    base = square_mesh(n).edge_index.clone()
+    # make sure the quad's (a, a+n+1) diagonal is present in both directions, in place
+    ei = base.clone()
+    pos_fw = ((ei[0] == a + 1) & (ei[1] == a + n)).nonzero()
+    pos_bw = ((ei[0] == a + n) & (ei[1] == a + 1)).nonzero()
+    assert len(pos_fw) == 1 and len(pos_bw) == 1, "left-diagonal triangulation: (a+1, a+n) is an edge"
+    flipped = ei.clone()
+    flipped[:, pos_fw[0, 0]] = torch.tensor([a, a + n + 1])
+    flipped[:, pos_bw[0, 0]] = torch.tensor([a + n + 1, a])
+    # the linear checksums really do collide (this is the case the old key missed)
+    w = torch.arange(1, ei.numel() + 1)
+    assert int((ei.reshape(-1) * w).sum()) == int((flipped.reshape(-1) * w).sum()) and int(ei.sum()) == int(flipped.sum())
+    assert not torch.equal(ei, flipped)
+    assert content_fingerprint([ei]) != content_fingerprint([flipped])
+    # and equal content in a fresh tensor object gives an equal key
+    assert content_fingerprint([ei]) == content_fingerprint([ei.clone()])
+    # an order change of the same edge set is a different key as well (summation order follows the caller's edge order)
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(0))
+    assert content_fingerprint([ei]) != content_fingerprint([ei[:, perm].contiguous()])

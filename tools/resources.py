@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel register / scratch report of the hot kernels (hipcc -Rpass-analysis=kernel-resource-usage).
+"""Per-kernel register / scratch report of the hot kernels (hipcc -Rpass-analysis=kernel-resource-usage); `make resources`.
 
     python tools/resources.py [extra hipcc flags]
 """
@@ -20,10 +20,14 @@ for line in out.splitlines():
     t = m.group(1).strip()
     if t.startswith("Function Name:"):
         cur, rec = t.split(":", 1)[1].strip(), {}
+        try:                                                 # demangled: the template arguments tell the instantiations apart
+            cur = subprocess.run(["c++filt", cur], capture_output=True, text=True).stdout.strip().split("(")[0] or cur
+        except OSError:
+            pass
     elif cur and ":" in t:
         k, v = t.rsplit(":", 1)
         rec[k.strip()] = v.strip()
         if k.strip().startswith("LDS Size") and ("grand_" in cur or "wide" in cur):
-            print("%-58s VGPR %4s  AGPR %3s  scratch %5s  spill %4s  waves/SIMD %s" % (
+            print("%-78s VGPR %4s  AGPR %3s  scratch %5s  spill %4s  waves/SIMD %s" % (
                 cur, rec.get("VGPRs"), rec.get("AGPRs"), rec.get("ScratchSize [bytes/lane]"), rec.get("VGPRs Spill"),
                 rec.get("Occupancy [waves/SIMD]")))
