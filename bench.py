@@ -35,6 +35,11 @@ WORKLOADS = {
     # not a BASELINE.json shape: the other hidden sizes of the fused kernels on the metric mesh batch (tuning runs)
     'poisson2d_64x64_b32_L4_C32': dict(n=64, batch=32, layers=4, hidden=32, conv='GRAND_plus', f=True, uu=True),
     'poisson2d_64x64_b32_L4_C8': dict(n=64, batch=32, layers=4, hidden=8, conv='GRAND_plus', f=True, uu=True),
+    # the metric mesh batch through the other trainable paths of the operator surface:
+    # learn_step=True (GNN.py:179-180,288-289: the SUMS instantiations of the target pass + the d dt reduction) and
+    # conv_type='GAT_plus' (GRAND_plus.py:386-416: the generic CSR primitives of gadapt_sparse.inc)
+    'poisson2d_64x64_b32_L4_C64_learn_step': dict(n=64, batch=32, layers=4, hidden=64, conv='GRAND_plus', f=True, uu=True, learn_step=True),
+    'poisson2d_64x64_b32_L4_C64_GAT_plus': dict(n=64, batch=32, layers=4, hidden=64, conv='GAT_plus', f=True, uu=True),
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X fp32 matrix (= vector) peak, SURVEY.md §8(d)
@@ -68,6 +73,29 @@ def load_pmc(workload):
         return json.load(open(path)).get(workload, {})
     except Exception:
         return {}
+
+
+def load_profile_avg_us(workload, kernel, variant):
+    """Average duration (us) of this kernel variant in the committed rocprofv3 --kernel-trace --stats summary of this workload
+    (profiles/<round>_<workload>_rocprofv3_kernel_stats.csv, newest round first); (None, None) when there is none.  The kernel
+    name carries the variant as template arguments (tools/make_pmc_json.py has the same mapping)."""
+    import csv, glob
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        from make_pmc_json import name as kname, variant as kvariant
+    except Exception:
+        return None, None
+    # rNN_bench_<workload>_... = bench.py itself under rocprofv3 (tools/bench_all.sh); rNN_<workload>_... = tools/profile_step.py
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_bench_{workload}_rocprofv3_kernel_stats.csv')), reverse=True) + \
+            sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_{workload}_rocprofv3_kernel_stats.csv')), reverse=True)
+    for path in paths:
+        tot, calls = 0.0, 0
+        for row in csv.DictReader(open(path)):
+            if kname(row['Name']) == kernel and (kvariant(row['Name']) or 'dense') == variant:
+                tot += float(row['TotalDurationNs']); calls += int(row['Calls'])
+        if calls:
+            return tot / calls / 1e3, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def main():
@@ -116,7 +144,7 @@ def main():
     w = WORKLOADS[args.workload]
     opt = hot_path_opt(mesh_dims=[w['n'], w['n']], hidden_dim=w['hidden'], num_layers=w['layers'], conv_type=w['conv'],
                        gnn_inc_feat_f=w['f'], gnn_inc_feat_uu=w['uu'], device=str(dev), loss_type='mesh_loss',
-                       show_mesh_evol_plots='False', compact_slots=not args.dense_slots)
+                       show_mesh_evol_plots='False', compact_slots=not args.dense_slots, learn_step=bool(w.get('learn_step', False)))
     ds = MeshDataset([w['n'], w['n']], w['batch'], seed=rank)        # every rank owns its own shard of meshes
     data = collate(ds.samples).to(dev)
     target = data.x_phys
@@ -253,10 +281,14 @@ def main():
                 groups.setdefault(vbuf[k], []).append(col[len(col) // 2])
             variants = {}
             for v, meds in sorted(groups.items()):
-                avg_ms = max(sum(meds) / len(meds) - event_overhead_ms, 1e-6)   # minus the dispatch share of the event pair
+                # priced with the RAW event-pair median: an event pair also times the dispatch of the launch it brackets, so
+                # this is an upper bound of the kernel's own duration (conservative for the roofline).  The calibrated dispatch
+                # share is reported beside it (`net_us`), never subtracted from what prices `frac`.
+                raw_ms = max(sum(meds) / len(meds), 1e-6)
                 by = algorithmic_bytes(name, n_nodes, n_edges, w['hidden'], v)
-                variants[VARIANT_NAMES.get(v, str(v))] = {'launches_per_step': len(meds), 'avg_us': round(avg_ms * 1e3, 2),
-                                                          'alg_bytes_per_launch': by, 'achieved_GBs': round(by / (avg_ms * 1e-3) / 1e9, 1)}
+                variants[VARIANT_NAMES.get(v, str(v))] = {'launches_per_step': len(meds), 'avg_us': round(raw_ms * 1e3, 2),
+                                                          'net_us': round(max(raw_ms - event_overhead_ms, 1e-6) * 1e3, 2),
+                                                          'alg_bytes_per_launch': by, 'achieved_GBs': round(by / (raw_ms * 1e-3) / 1e9, 1)}
             tot = sum(v['avg_us'] * v['launches_per_step'] for v in variants.values())
             kernels[name] = {'launches_per_step': per_step, 'avg_us': round(tot / per_step, 2), 'variants': variants}
         lib.gadapt_profile_reset()
@@ -270,11 +302,18 @@ def main():
             ent = pmc.get(f'{dom}:{dvar}', pmc.get(dom))
             if isinstance(ent, dict):
                 traffic = ent.get('traffic_bytes')
+            prof_us, prof_file = load_profile_avg_us(args.workload, dom, dvar)
             roofline = {'kernel': dom, 'variant': dvar, 'bound': 'hbm', 'achieved': kd['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(kd['achieved_GBs'] / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                        'traffic_note': 'HBM-side bytes per launch of this kernel variant, (2 FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes',
+                        'traffic_note': 'fabric-side bytes per launch of this kernel variant, (2 FETCH_SIZE + WRITE_SIZE) KiB, read from the '
+                                        'committed profiles/pmc.json (separate rocprofv3 --pmc passes, tools/profile_all.sh); not measured in this run',
                         'avg_launch_us': kd['avg_us'], 'alg_bytes_per_launch': kd['alg_bytes_per_launch'],
-                        'event_pair_overhead_us': round(event_overhead_ms * 1e3, 2)}
+                        'duration_note': 'avg_launch_us = raw HIP-event-pair median on the launch stream (includes the dispatch share of the '
+                                         'pair); frac = alg_bytes_per_launch / avg_launch_us / peak',
+                        'event_pair_overhead_us': round(event_overhead_ms * 1e3, 2), 'avg_launch_us_net_of_overhead': kd['net_us'],
+                        # the same quantity from the committed rocprofv3 --kernel-trace --stats summary of this workload
+                        'profile': None if prof_us is None else {'file': prof_file, 'avg_us': round(prof_us, 2),
+                                                                 'frac': round(kd['alg_bytes_per_launch'] / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
 
     # ---- secondary roofline: the projections, priced as the reference formulation's GEMM flops
     # (12 N C^2 per layer: Q, K forward + dX, dW backward) against the fp32 matrix peak, whole step
@@ -293,15 +332,20 @@ def main():
                 measured[kname] = u
                 t = kd['avg_us'] * kd['launches_per_step']
                 wsum, tsum = wsum + u * t, tsum + t
-        roofline_mfma = {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
-                         'flops_per_mesh': gemm_flops_per_mesh,
-                         'measured': {'matrix_pipe_busy_frac': measured,
-                                      'hot_kernels_time_weighted': round(wsum / tsum, 4) if tsum else None,
+        tw = round(wsum / tsum, 4) if tsum else None
+        # frac = MEASURED matrix-pipe utilisation of the hot kernels (time-weighted over a step's launches); the reference
+        # formulation's GEMM flops against the fp32 matrix peak are reported under their own name - they are not a utilisation
+        # (the kernels execute 8 N C^2 per layer on the bf16 / f16 pipes, not 12 N C^2 in fp32).
+        roofline_mfma = {'bound': 'mfma', 'frac': tw, 'unit': 'fraction of matrix-pipe cycles busy',
+                         'measured': {'matrix_pipe_busy_frac': measured, 'hot_kernels_time_weighted': tw,
                                       'source': 'profiles/pmc.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), '
-                                                'v_mfma_f32_32x32x16_bf16 = 32 busy cycles each'},
-                         'note': 'algorithmic GEMM flops of the reference formulation x meshes/s per GPU; the kernels '
-                                 'execute 8 N C^2 per layer (composite A = Wk^T Wq) on the bf16 matrix cores, 3-piece split'}
+                                                'committed rocprofv3 --pmc passes (not measured in this run)'},
+                         'reference_flops_vs_fp32_peak': round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
+                         'reference_flops': {'achieved_TFLOPs': round(tf, 2), 'peak_TFLOPs': FP32_MATRIX_PEAK_TFLOPS,
+                                             'flops_per_mesh': gemm_flops_per_mesh,
+                                             'note': 'SURVEY.md 8(d): 12 N C^2 L GEMM flops of the reference formulation x meshes/s per GPU '
+                                                     'against the fp32 matrix peak; the kernels execute 8 N C^2 per layer (composite '
+                                                     'A = Wk^T Wq) as split bf16 / f16 products'}}
 
     # ---- CPU baseline: the oracle on the host cores, same workload, bounded sample.  A quarter of the batch per step (the
     # cost is linear in the meshes), a short sweep over thread counts (index_add_ / scatter ops stop scaling early), then

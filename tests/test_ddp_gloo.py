@@ -1,6 +1,11 @@
-"""N > 1 path on CPU (gloo, world_size 2): shard the mesh batch by rank, all-reduce ONE flat gradient bucket,
+"""N > 1 path on CPU (gloo, world_size 2 and 8): shard the mesh batch by rank, all-reduce ONE flat gradient bucket,
 and check the averaged bucket equals the full-batch gradient.  Compute on the ranks is the CPU oracle (tests
-may use it); what is under test is the sharding and the bucket/all-reduce logic of g_adaptivity_amd.optim."""
+may use it); what is under test is the sharding and the bucket/all-reduce logic of g_adaptivity_amd.optim.
+
+World size 8 runs BASELINE config 3's partition - 256 meshes of 64x64 nodes, 32 per rank (hidden 8, 2 layers: the sharding does
+not depend on the width and the CPU oracle stays quick) - and an uneven 250-mesh split (31 / 32 per rank), each with both
+reductions: 'mean' for the mean-reduced mesh loss (run_GNN.py:106) and 'sum' for the modular pseudo-loss, a SUM over the nodes
+(run_GNN.py:118), which must come out un-scaled."""
 import os
 import socket
 
@@ -87,3 +92,119 @@ def test_shard_range_partitions():
         spans = [shard_range(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# world size 8: BASELINE config 3's partition (256 meshes -> 32 per rank) and an uneven one (250 -> 31 / 32)
+# ---------------------------------------------------------------------------------------------------------------
+W8_MESH, W8_HIDDEN, W8_LAYERS = [64, 64], 8, 2
+
+
+def _w8_model_and_data(n_meshes):
+    opt = hot_path_opt(mesh_dims=W8_MESH, hidden_dim=W8_HIDDEN, num_layers=W8_LAYERS)
+    ds = MeshDataset(W8_MESH, n_meshes, seed=0)
+    torch.manual_seed(0)
+    return OracleGNN(ds, opt), ds
+
+
+def _w8_grads(model, ds, idx, kind):
+    """kind 'mesh': F.mse_loss, mean-reduced (run_GNN.py:106).  kind 'modular': sum(x_phys * x_grads) with an externally
+    supplied per-node field standing in for the FEM gradients (run_GNN.py:117-118,123) - here the mesh coordinates."""
+    data = collate([ds.samples[i] for i in idx])
+    model.zero_grad()
+    out = model(data)
+    loss = F.mse_loss(out, data.x_phys) if kind == 'mesh' else (out * data.x_comp.detach()).sum()
+    loss.backward()
+    return int(data.x_comp.shape[0])
+
+
+def _w8_worker(rank, world, port, n_meshes, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model, ds = _w8_model_and_data(n_meshes)
+    lo, hi = shard_range(len(ds), rank, world)
+    res = {'span': (lo, hi)}
+    for kind, reduce_op in (('mesh', 'mean'), ('modular', 'sum')):
+        nodes = _w8_grads(model, ds, range(lo, hi), kind)
+        optim = FlatAdam(model.parameters(), lr=1e-3, reduce_op=reduce_op)
+        optim._build()
+        assert optim.grad_bucket.numel() == 2 * (W8_HIDDEN * W8_HIDDEN + W8_HIDDEN)
+        local = optim.grad_bucket.clone()
+        n = optim.all_reduce()
+        assert n == world
+        # what the fused Adam kernel is handed: the summed bucket and the scale step() folds in (1/world for 'mean', 1 for 'sum')
+        scale = 1.0 / n if optim.reduce_op == 'mean' else 1.0
+        res[kind] = (optim.grad_bucket.clone() * scale, local, nodes)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {k: (v if k == 'span' else (v[1], v[2])) for k, v in res.items()})
+    if rank == 0:
+        out.put({'reduced': {k: res[k][0] for k in ('mesh', 'modular')}, 'per_rank': gathered})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_w8(n_meshes):
+    world, port = 8, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_w8_worker, args=(r, world, port, n_meshes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = q.get(timeout=300)
+    except Exception:
+        got = None
+    ok = got is not None
+    for p in procs:
+        p.join(timeout=120)
+        if p.is_alive():
+            p.kill()
+            ok = False
+        ok = ok and p.exitcode == 0
+    return got if ok else None
+
+
+def _close(a, b, rel=2e-4):
+    """normwise: the small entries of these gradients are remainders of cancelling sums (fp32 summation order differs between
+    a shard-wise and a full-batch run)"""
+    return (a - b).norm().item() <= rel * b.norm().item()
+
+
+def _flat_grad(model):
+    return torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+
+
+import pytest   # noqa: E402
+
+
+@pytest.mark.parametrize("n_meshes", [256, 250], ids=['cfg3-256-even', '250-uneven'])
+def test_eight_rank_partition_of_config_3(n_meshes):
+    got = _run_w8(n_meshes) or _run_w8(n_meshes)           # one retry: the rendezvous port is picked, released and re-bound
+    assert got is not None, "eight-rank gloo run failed twice"
+    spans = [g['span'] for g in got['per_rank']]
+    assert spans[0][0] == 0 and spans[-1][1] == n_meshes and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    sizes = [h - l for l, h in spans]
+    assert sizes == ([32] * 8 if n_meshes == 256 else [32, 32, 31, 31, 31, 31, 31, 31])
+    model, ds = _w8_model_and_data(n_meshes)
+    # modular pseudo-loss, reduce_op='sum': the un-scaled sum of the rank gradients IS the full-batch gradient, even or not
+    _w8_grads(model, ds, range(n_meshes), 'modular')
+    full_sum = _flat_grad(model)
+    red = got['reduced']['modular']
+    assert _close(red, full_sum)
+    assert _close(red, sum(g['modular'][0] for g in got['per_rank']), 1e-5)
+    # mean-reduced mesh loss, reduce_op='mean': bucket / world
+    _w8_grads(model, ds, range(n_meshes), 'mesh')
+    full_mean = _flat_grad(model)
+    red = got['reduced']['mesh']
+    if n_meshes == 256:                                    # equal shards: mean of shard means = full-batch mean
+        assert _close(red, full_mean)
+    else:
+        # uneven shards: 1/world averages the SHARD means (what DDP does too); the full-batch mean is the node-weighted
+        # combination of the same rank gradients, and the two differ by at most the relative spread of the shard sizes
+        nodes = [g['mesh'][1] for g in got['per_rank']]
+        weighted = sum(g['mesh'][0] * (n / sum(nodes)) for g, n in zip(got['per_rank'], nodes))
+        assert _close(weighted, full_mean)
+        assert _close(red, sum(g['mesh'][0] for g in got['per_rank']) / 8, 1e-5)
+        spread = (max(nodes) - min(nodes)) / min(nodes)
+        assert (red - full_mean).norm() <= 2 * spread * full_mean.norm()

@@ -179,6 +179,39 @@ def test_two_rank_step_equals_full_batch_step(gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("capture_allreduce", [False, True], ids=['eager-collective', 'capture-allreduce-falls-back'])
+def test_bench_two_ranks_rehearsal(gpu_device, capture_allreduce):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), rehearsed on the ONE
+    GPU of the test box: GADAPT_BENCH_SHARE_GPU=1 maps both ranks onto it and GADAPT_BENCH_BACKEND=gloo carries the collectives
+    (RCCL needs a GPU per rank).  Both N > 1 launch modes run: forward + loss + backward as a hipGraph (thread_local capture mode)
+    followed by the eager all-reduce + device-stepped Adam, and GADAPT_BENCH_CAPTURE_ALLREDUCE=1, where the collective is
+    captured too - which gloo cannot do, so this leg exercises the fallback to eager launches.  One JSON line, n_gpus 2,
+    finite numbers, weak scaling (64 meshes per step)."""
+    import math
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GADAPT_BENCH_SHARE_GPU='1', GADAPT_BENCH_BACKEND='gloo')
+    if capture_allreduce:
+        env['GADAPT_BENCH_CAPTURE_ALLREDUCE'] = '1'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2'],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 5 and d['warmup'] == 2 and d['scaling'] == 'weak'
+    assert d['config']['global_batch'] == 64 and d['config']['parallelism'] == 'dp2'
+    assert math.isfinite(d['value']) and d['value'] > 0 and math.isfinite(d['ms_per_step']) and d['ms_per_step'] > 0
+    assert d['value'] == pytest.approx(64 / (d['ms_per_step'] * 1e-3), rel=1e-3)
+    assert d['cpu_baseline'] is None                        # rank 0 at N = 1 only
+    assert d['roofline'] is not None and math.isfinite(d['roofline']['frac'])
+    if capture_allreduce:
+        assert d['config']['launch'] in ('hipgraph+allreduce+adam', 'eager'), d['config']['launch']
+    else:
+        assert d['config']['launch'] == 'hipgraph, then allreduce+adam', d['config']['launch']
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hidden", [16, 64])
 def test_mixed_size_batch_parity(gpu_device, hidden):
     """`data_type='randg_mix'`: batches of 9x9 + 12x12 + 7x7 meshes from `Mixed_DataLoader` (excluded keys in `batch_dict`)

@@ -1,0 +1,72 @@
+"""Evidence hygiene: every `roofline*` field of the committed bench line can be recomputed from tracked files
+under profiles/ alone, and the two counter summaries come from one pass set.  No GPU."""
+import csv
+import glob
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, 'profiles')
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+
+def test_traffic_json_is_the_traffic_column_of_pmc_json():
+    pmc = json.load(open(os.path.join(PROF, 'pmc.json')))
+    traffic = json.load(open(os.path.join(PROF, 'traffic.json')))
+    assert set(pmc) == set(traffic)
+    for wl, kernels in pmc.items():
+        want = {k: r['traffic_bytes'] for k, r in kernels.items() if 'traffic_bytes' in r}
+        assert traffic[wl] == want, wl
+
+
+def _latest_bench_line():
+    """(path, parsed line) of the newest committed default-workload bench line that carries the round-3 fields."""
+    for path in sorted(glob.glob(os.path.join(PROF, 'r*_bench.json')), reverse=True):
+        txt = open(path).read().strip()
+        if not txt:
+            continue
+        line = json.loads(txt.splitlines()[-1])
+        if isinstance(line.get('roofline'), dict) and 'profile' in line['roofline']:
+            return path, line
+    return None, None
+
+
+def test_bench_line_roofline_is_reproducible_from_profiles():
+    path, line = _latest_bench_line()
+    if line is None:
+        pytest.skip("no committed bench line with the round-3 roofline fields yet")
+    from make_pmc_json import name as kname, variant as kvariant
+    rf = line['roofline']
+    wl = line['config']['workload']
+    # frac follows from the line's own raw duration and byte count ...
+    assert rf['frac'] == pytest.approx(rf['alg_bytes_per_launch'] / (rf['avg_launch_us'] * 1e-6) / 8e12, rel=2e-3)
+    assert rf['avg_launch_us'] >= rf['avg_launch_us_net_of_overhead']          # nothing subtracted from what prices frac
+    # ... the byte count from SURVEY.md 8(d) ...
+    import bench
+    n, b = bench.WORKLOADS[wl]['n'], bench.WORKLOADS[wl]['batch']
+    n_nodes = n * n * b
+    assert rf['alg_bytes_per_launch'] in {bench.algorithmic_bytes(rf['kernel'], n_nodes, e, bench.WORKLOADS[wl]['hidden'],
+                                                                  {'dense': 0, 'compact_g': 1, 'compact_x': 2}[rf['variant']])
+                                          for e in (23564 * b,)} or n != 64
+    # ... the committed rocprofv3 summary gives the same duration (the event pair adds its dispatch share: <= 12 % above, never below)
+    prof = rf['profile']
+    assert prof is not None, "no committed rocprofv3 kernel stats for the bench workload"
+    tot = calls = 0
+    for row in csv.DictReader(open(os.path.join(ROOT, prof['file']))):
+        if kname(row['Name']) == rf['kernel'] and (kvariant(row['Name']) or 'dense') == rf['variant']:
+            tot += float(row['TotalDurationNs']); calls += int(row['Calls'])
+    assert calls > 0
+    csv_us = tot / calls / 1e3
+    assert prof['avg_us'] == pytest.approx(csv_us, rel=1e-3)
+    assert prof['frac'] == pytest.approx(rf['alg_bytes_per_launch'] / (csv_us * 1e-6) / 8e12, rel=2e-3)
+    assert rf['frac'] <= prof['frac'] * 1.03, "the line's frac may not exceed what the rocprofv3 summary supports"
+    assert rf['frac'] >= prof['frac'] * 0.85
+    # traffic is the committed counter summary's entry for that kernel variant
+    pmc = json.load(open(os.path.join(PROF, 'pmc.json')))[wl]
+    assert rf['traffic'] == pmc[f"{rf['kernel']}:{rf['variant']}"]['traffic_bytes']
+    # the matrix-pipe figure is the measured one
+    rm = line['roofline_mfma']
+    assert rm['frac'] == rm['measured']['hot_kernels_time_weighted'] and 'reference_flops_vs_fp32_peak' in rm

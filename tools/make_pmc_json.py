@@ -13,12 +13,12 @@ Per workload and hot kernel (and per variant where the kernel name tells them ap
   wait_frac       SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of wave time parked at s_waitcnt / s_barrier
   l2_hit          TCC_HIT / (TCC_HIT + TCC_MISS)
     python tools/make_pmc_json.py gpurun_out/prof_<tag> <workload> [profiles/pmc.json]
+Also (re)writes traffic.json next to the output: the `traffic_bytes` column of pmc.json alone, per workload and kernel[:variant] -
+ONE pass set feeds both files (tests/test_profiles.py checks that they agree).
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-root, workload = sys.argv[1], sys.argv[2]
-out = sys.argv[3] if len(sys.argv) > 3 else 'profiles/pmc.json'
 N_SIMD, N_XCD = 1024, 8
 
 
@@ -44,42 +44,51 @@ def variant(n):
     return None
 
 
-acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(root, 'pmc*', '**', '*counter_collection.csv'), recursive=True):
-    for row in csv.DictReader(open(f)):
-        kn = row.get('Kernel_Name', '')
-        k = name(kn)
-        if not k:
-            continue
-        acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
-        v = variant(kn)
-        if v:
-            acc[k + ':' + v][row['Counter_Name']].append(float(row['Counter_Value']))
-res = {}
-for k, c in sorted(acc.items()):
-    m = {n: sum(v) / len(v) for n, v in c.items()}
-    r = {}
-    if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
-        r['traffic_bytes'] = int((2 * m['FETCH_SIZE'] + m['WRITE_SIZE']) * 1024)
-        r['fetch_kib'], r['write_kib'] = round(m['FETCH_SIZE'], 1), round(m['WRITE_SIZE'], 1)
-    if 'GRBM_GUI_ACTIVE' in m:
-        cyc = m['GRBM_GUI_ACTIVE'] / N_XCD
-        r['kernel_cycles'] = round(cyc)
-        if 'SQ_VALU_MFMA_BUSY_CYCLES' in m:
-            r['mfma_util'] = round(m['SQ_VALU_MFMA_BUSY_CYCLES'] / (N_SIMD * cyc), 4)
-            r['mfma_insts'] = round(m.get('SQ_INSTS_MFMA', 0))
-        if 'SQ_ACTIVE_INST_VALU' in m:
-            r['valu_util'] = round(4 * m['SQ_ACTIVE_INST_VALU'] / (N_SIMD * cyc), 4)
-    if 'SQ_WAIT_ANY' in m and 'SQ_WAVE_CYCLES' in m:
-        r['wait_frac'] = round(m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES'], 4)
-        r['issue_stall_frac'] = round(m.get('SQ_WAIT_INST_ANY', 0) / m['SQ_WAVE_CYCLES'], 4)
-    if 'TCC_HIT_sum' in m and 'TCC_MISS_sum' in m:
-        r['l2_hit'] = round(m['TCC_HIT_sum'] / max(m['TCC_HIT_sum'] + m['TCC_MISS_sum'], 1), 4)
-    if 'SQ_LDS_BANK_CONFLICT' in m and 'SQ_LDS_IDX_ACTIVE' in m:
-        r['lds_conflict_frac'] = round(m['SQ_LDS_BANK_CONFLICT'] / max(m['SQ_LDS_IDX_ACTIVE'], 1), 4)
-    res[k] = r
-data = json.load(open(out)) if os.path.exists(out) else {}
-data[workload] = res
-json.dump(data, open(out, 'w'), indent=1, sort_keys=True)
-for k, r in res.items():
-    print(workload, k, r)
+def main():
+    root, workload = sys.argv[1], sys.argv[2]
+    out = sys.argv[3] if len(sys.argv) > 3 else 'profiles/pmc.json'
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(root, 'pmc*', '**', '*counter_collection.csv'), recursive=True):
+        for row in csv.DictReader(open(f)):
+            kn = row.get('Kernel_Name', '')
+            k = name(kn)
+            if not k:
+                continue
+            acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
+            v = variant(kn)
+            if v:
+                acc[k + ':' + v][row['Counter_Name']].append(float(row['Counter_Value']))
+    res = {}
+    for k, c in sorted(acc.items()):
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        r = {}
+        if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
+            r['traffic_bytes'] = int((2 * m['FETCH_SIZE'] + m['WRITE_SIZE']) * 1024)
+            r['fetch_kib'], r['write_kib'] = round(m['FETCH_SIZE'], 1), round(m['WRITE_SIZE'], 1)
+        if 'GRBM_GUI_ACTIVE' in m:
+            cyc = m['GRBM_GUI_ACTIVE'] / N_XCD
+            r['kernel_cycles'] = round(cyc)
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in m:
+                r['mfma_util'] = round(m['SQ_VALU_MFMA_BUSY_CYCLES'] / (N_SIMD * cyc), 4)
+                r['mfma_insts'] = round(m.get('SQ_INSTS_MFMA', 0))
+            if 'SQ_ACTIVE_INST_VALU' in m:
+                r['valu_util'] = round(4 * m['SQ_ACTIVE_INST_VALU'] / (N_SIMD * cyc), 4)
+        if 'SQ_WAIT_ANY' in m and 'SQ_WAVE_CYCLES' in m:
+            r['wait_frac'] = round(m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES'], 4)
+            r['issue_stall_frac'] = round(m.get('SQ_WAIT_INST_ANY', 0) / m['SQ_WAVE_CYCLES'], 4)
+        if 'TCC_HIT_sum' in m and 'TCC_MISS_sum' in m:
+            r['l2_hit'] = round(m['TCC_HIT_sum'] / max(m['TCC_HIT_sum'] + m['TCC_MISS_sum'], 1), 4)
+        if 'SQ_LDS_BANK_CONFLICT' in m and 'SQ_LDS_IDX_ACTIVE' in m:
+            r['lds_conflict_frac'] = round(m['SQ_LDS_BANK_CONFLICT'] / max(m['SQ_LDS_IDX_ACTIVE'], 1), 4)
+        res[k] = r
+    data = json.load(open(out)) if os.path.exists(out) else {}
+    data[workload] = res
+    json.dump(data, open(out, 'w'), indent=1, sort_keys=True)
+    traffic = {wl: {k: r['traffic_bytes'] for k, r in ks.items() if 'traffic_bytes' in r} for wl, ks in data.items()}
+    json.dump(traffic, open(os.path.join(os.path.dirname(out) or '.', 'traffic.json'), 'w'), indent=1, sort_keys=True)
+    for k, r in res.items():
+        print(workload, k, r)
+
+
+if __name__ == '__main__':
+    main()
