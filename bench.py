@@ -142,6 +142,8 @@ def main():
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # the step is captured on a side stream by design
 
     w = WORKLOADS[args.workload]
+    if w['conv'] not in ('GRAND', 'GRAND_plus'):
+        args.no_graph = True                                          # generic-primitive convs: timed as eager launches
     opt = hot_path_opt(mesh_dims=[w['n'], w['n']], hidden_dim=w['hidden'], num_layers=w['layers'], conv_type=w['conv'],
                        gnn_inc_feat_f=w['f'], gnn_inc_feat_uu=w['uu'], device=str(dev), loss_type='mesh_loss',
                        show_mesh_evol_plots='False', compact_slots=not args.dense_slots, learn_step=bool(w.get('learn_step', False)))
@@ -156,7 +158,12 @@ def main():
     # the device as well: no host-side value changes from step to step) follow it on the same stream.
     # GADAPT_BENCH_CAPTURE_ALLREDUCE=1 also captures the collective and Adam in the graph (RCCL collectives are stream-
     # capturable); off by default because it cannot be rehearsed on a one-GPU box, and a capture that fails falls back.
-    capture_all = world == 1 or os.environ.get('GADAPT_BENCH_CAPTURE_ALLREDUCE') == '1'
+    capture_all = world == 1 or (os.environ.get('GADAPT_BENCH_CAPTURE_ALLREDUCE') == '1' and backend == 'nccl')
+    if world > 1 and os.environ.get('GADAPT_BENCH_CAPTURE_ALLREDUCE') == '1' and backend != 'nccl' and rank == 0:
+        # only RCCL collectives can be stream-captured; a capture that a synchronising collective invalidates is NOT recoverable
+        # in-process on this ROCm (every later launch of the thread fails with hipErrorStreamCaptureInvalidated: measured with
+        # tools/capture_recovery_probe.py), so it is never attempted
+        print(f"[bench] GADAPT_BENCH_CAPTURE_ALLREDUCE=1 ignored: backend '{backend}' cannot be captured", file=sys.stderr)
     optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=True)
 
     # loss.backward() with the root gradient handed over instead of created per step (g_adaptivity_amd.unit_gradient: same
@@ -208,7 +215,11 @@ def main():
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
             graph = None
             capture_all = world == 1
-            torch.cuda.synchronize()
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            _native.clear_error()                                     # the invalidated capture left HIP's per-thread last error set
 
     def step():
         if graph is not None:

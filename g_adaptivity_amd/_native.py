@@ -32,6 +32,7 @@ PROTOTYPES = {
     'gadapt_supported_hidden_dim': (_I, [_I]),
     'gadapt_last_error': (C.c_char_p, []),
     'gadapt_abi_version': (_I, []),
+    'gadapt_clear_error': (_I, []),
     'gadapt_csr_build_host': (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P]),
     'gadapt_tile_meta_host': (_I, [_P, _P, _L, _I, _P]),
     'gadapt_ell_build_host': (_I, [_P, _P, _L, _P, _P]),
@@ -55,7 +56,7 @@ PROTOTYPES = {
     'gadapt_layer_backward': (_I, [_G, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     'gadapt_slab_reduce': (_I, [_P, _I, _P, _P, _P, _I, _P]),
     'gadapt_block_forward': (_I, [_G, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _I, _P]),
-    'gadapt_block_backward': (_I, [_G, _P, _I, _P, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'gadapt_block_backward': (_I, [_G, _P, _I, _P, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     'gadapt_mesh_loss_seed': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
     'gadapt_pad_columns': (_I, [_P, _P, _L, _I, _I, _P]),
     'gadapt_adam_step': (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
@@ -97,6 +98,11 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = lib().gadapt_last_error().decode() or f"error {rc}"
         raise NativeError(f"{what}: {msg} (code {rc})")
+
+
+def clear_error() -> int:
+    """Drop a stale per-thread error (see gadapt_clear_error): call after recovering from a failed hipGraph capture."""
+    return int(lib().gadapt_clear_error())
 
 
 def ptr(t):

@@ -153,7 +153,8 @@ static int check_launch(const char* what) {
     return GADAPT_OK;
 }
 extern "C" const char* gadapt_last_error(void) { return g_err; }
-extern "C" int gadapt_abi_version(void) { return 3; }
+extern "C" int gadapt_abi_version(void) { return 4; }
+extern "C" int gadapt_clear_error(void) { g_err[0] = 0; return (int)hipGetLastError(); }
 extern "C" int gadapt_supported_hidden_dim(int c) {
     return c == 4 || c == 8 || c == 16 || c == 32 || c == 64 || c == 128;
 }
@@ -1592,10 +1593,11 @@ struct BwdTArgs {
     const float* x_in; const float* g_in; const float* alpha;
     const float* A; const float* lp;
     const int32_t* rowptr; const int32_t* col; const int32_t* tpos; const int32_t* meta;
-    float2* edge_ws; float* dxd; float* slab; float* sums_out;
+    float2* edge_ws; float* dxd; float* slab; float* sums_out;   // sums_out: d dt of this layer (one float)
     int n_nodes, n_tiles, accumulate, residual_only, n_edges;
     unsigned long long* stamps;
     int g_cols;                                                 // GC kernels: g_in is [N,g_cols] (zero beyond), else unused
+    float* sums_sc_out;                                         // d score_scale of this layer (one float); set with sums_out
 };
 
 template <int NROWS, int NV> struct TBuf {
@@ -1604,7 +1606,7 @@ template <int NROWS, int NV> struct TBuf {
     int deg, el0;
 };
 
-// SUMS: also reduce d/d(dt) and d/d(score_scale) (learn_step / learnable temperature).  A separate instantiation:
+// SUMS: 1 = also reduce d/d(dt) (learn_step), 2 = d/d(dt) and d/d(score_scale) (learnable temperature).  Separate instantiations:
 // hipcc otherwise sinks the per-edge log terms behind the pipeline and keeps dozens of registers alive for them.
 //
 // Rolling window like the forward: a workgroup walks consecutive tiles with slabs t-1, t, t+1 of x in an LDS ring,
@@ -1616,7 +1618,7 @@ template <int NROWS, int NV> struct TBuf {
 // DA: this launch accumulates the weight-gradient partials (dA, dp0).  false when a source pass follows that does it
 // instead (dA = sum_i dP_i x_i^T = sum_j x_j y_j^T with y_j = sum_i ds_ij x_i, the vector the source pass forms anyway;
 // dp0 = sum_j sigma_j x_j): the target pass then has no dA phase, no accumulators and no slab flush.
-template <int C, bool SUMS, bool GC = false, bool XC = false, bool DA = true>
+template <int C, int SUMS, bool GC = false, bool XC = false, bool DA = true>
 __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD_T)) void grand_bwd_target_kernel(BwdTArgs p) {
     static_assert(DA || (!SUMS && !XC), "only the plain variants hand dA to the source pass");
     using K = Cfg<C>;
@@ -1667,15 +1669,19 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
     float sum_ddt = 0.f, sum_dsc = 0.f;
     V gk[K::ITERS];                                             // (base - dt) g_i of this lane's node slots, for the epilogue
 
-    auto finish = [&](int li, int i, int it, const V& gi, const V& m, const V& dP) __attribute__((always_inline)) {
+    // Dg (SUMS): sum_k alpha_ik <g_i, x_k> of this node (group-uniform)
+    auto finish = [&](int li, int i, int it, const V& gi, float Dg, const V& dP) __attribute__((always_inline)) {
         if (i < p.n_nodes) {
             if constexpr (SUMS) {
-                // d dt = sum_i <g_i, m_i - x_i>   (GNN.py:288-289 learn_step); every lane adds its channels
+                // d dt = sum_i <g_i, m_i - x_i>   (GNN.py:288-289 learn_step) with <g_i, m_i> = sum_k alpha_ik <g_i, x_k> = Dg, which
+                // the softmax backward has anyway: no aggregated row m_i is formed (it cost 8 registers and 48 fmas per node slot
+                // and made these instantiations spill).  One lane of the group adds Dg, every lane its channels of -<g_i, x_i>.
                 const V xi = lds_vec<C>(xs, li, sub);
+                float own = (sub == 0) ? Dg : 0.f;
 #pragma unroll
                 for (int q = 0; q < K::NV; ++q)
-                    sum_ddt += gi.v[q].x * (m.v[q].x - xi.v[q].x) + gi.v[q].y * (m.v[q].y - xi.v[q].y) +
-                               gi.v[q].z * (m.v[q].z - xi.v[q].z) + gi.v[q].w * (m.v[q].w - xi.v[q].w);
+                    own -= gi.v[q].x * xi.v[q].x + gi.v[q].y * xi.v[q].y + gi.v[q].z * xi.v[q].z + gi.v[q].w * xi.v[q].w;
+                sum_ddt += own;
             }
             if constexpr (DA) {
 #pragma unroll
@@ -1690,6 +1696,9 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         }
         lds_put<C>(ds, li, sub, dP);                            // over g_i: only this lane group reads that row
     };
+    // SUMS instantiations take the edge dot products with g_i itself and fold dt into the score scale afterwards
+    // (d alpha_ik = dt <g_i, x_k>): Dg above is then free, and dt = 0 needs no special case
+    const float scl = SUMS ? sc * dt : sc;
 
     // WIN (compile time): gathers from the LDS ring (col holds ring offsets) or from HBM/L2; see the forward kernel
     auto fetch = [&](auto& b, int node0, int it, auto win_tag) __attribute__((always_inline)) {
@@ -1720,6 +1729,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         V dm;
 #pragma unroll
         for (int q = 0; q < K::NV; ++q) {
+            if constexpr (SUMS) { dm.v[q] = gi.v[q]; continue; }
             dm.v[q].x = dt * gi.v[q].x; dm.v[q].y = dt * gi.v[q].y; dm.v[q].z = dt * gi.v[q].z; dm.v[q].w = dt * gi.v[q].w;
         }
         float a[DM], da[DM];
@@ -1733,62 +1743,67 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         float D = 0.f;
 #pragma unroll
         for (int k = 0; k < DM; ++k) D = fmaf(a[k], da[k], D);
-        V dP, m; dP.zero(); m.zero();
+        V dP; dP.zero();
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
-            const float dsp = a[k] * (da[k] - D);                   // d(score'), score' = sc * <P_i,x_j>
-            da[k] = dsp * sc;                                       // reuse: d<P_i,x_j>
+            const float dsp = a[k] * (da[k] - D);                   // d(score') [/ dt: SUMS], score' = sc * <P_i,x_j>
+            da[k] = dsp * scl;                                      // reuse: d<P_i,x_j>
             vaxpy(dP, da[k], b.r[k]);
-            if constexpr (SUMS) {
-                vaxpy(m, a[k], b.r[k]);
-                if (a[k] > 0.f) sum_dsc = fmaf(dsp, __logf(a[k]), sum_dsc);
-            }
         }
-        if constexpr (XC) {
+        // per-edge scratch for the source pass, one edge per lane of the group; SUMS: the same lane adds its edge's term of
+        // d/d(score_scale) = (1/sc) sum_e d(score')_e log alpha_e  (the softmax backward sums to zero per target, so the
+        // log-partition term drops out) - one log per lane and node slot instead of DM group-uniform ones
+        if constexpr (XC && SUMS < 2) {
         } else if constexpr (K::LPN >= DM) {
             const float am = pick(a, sub), dm_ = pick(da, sub);
+            if constexpr (SUMS > 1) { if (sub < deg && am > 0.f) sum_dsc = fmaf(dm_, __logf(am), sum_dsc); }
+            if constexpr (!XC) {
 #ifdef GADAPT_ABL_EDGEWS_LINEAR
-            if (sub < deg) p.edge_ws[csr.ebase + e0 + sub] = make_float2(am * dt, dm_);
+                if (sub < deg) p.edge_ws[csr.ebase + e0 + sub] = make_float2(am * dt, dm_);
 #elif !defined(GADAPT_ABL_NO_EDGEWS)
-            if (sub < deg) p.edge_ws[csr.ext[e0 + sub]] = make_float2(am * dt, dm_);
+                if (sub < deg) p.edge_ws[csr.ext[e0 + sub]] = make_float2(am * dt, dm_);
 #endif
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < DM; ++k)
-                if (k < deg && (k % K::LPN) == sub) p.edge_ws[csr.ext[e0 + k]] = make_float2(a[k] * dt, da[k]);
+                if (k < deg && (k % K::LPN) == sub) {
+                    if constexpr (!XC) p.edge_ws[csr.ext[e0 + k]] = make_float2(a[k] * dt, da[k]);
+                    if constexpr (SUMS > 1) { if (a[k] > 0.f) sum_dsc = fmaf(da[k], __logf(a[k]), sum_dsc); }
+                }
         }
-        finish(li, i, it, gi, m, dP);
+        finish(li, i, it, gi, D, dP);
     };
 
     auto slow_node = [&](int node0, int it) __attribute__((always_inline)) {
         const int li = it * K::SLOTS + slot;
         const int i = node0 + li;
-        V dP, m; dP.zero(); m.zero();
+        V dP; dP.zero();
+        float D = 0.f;
         const V gi = lds_vec<C>(ds, li, sub);
         if (i < p.n_nodes) {
             V dm;
 #pragma unroll
             for (int q = 0; q < K::NV; ++q) {
+                if constexpr (SUMS) { dm.v[q] = gi.v[q]; continue; }
                 dm.v[q].x = dt * gi.v[q].x; dm.v[q].y = dt * gi.v[q].y; dm.v[q].z = dt * gi.v[q].z; dm.v[q].w = dt * gi.v[q].w;
             }
             const int e0 = p.rowptr[i], deg = p.rowptr[i + 1] - e0;
-            float D = 0.f;
             for (int k = 0; k < deg; ++k)
                 D = fmaf(p.alpha[e0 + k], group_sum<K::LPN>(vdot(dm, ld_xsel<C, XC>(p.x_in, p.col[e0 + k], sub))), D);
             for (int k = 0; k < deg; ++k) {
                 const V v = ld_xsel<C, XC>(p.x_in, p.col[e0 + k], sub);
                 const float ak = p.alpha[e0 + k];
                 const float dsp = ak * (group_sum<K::LPN>(vdot(dm, v)) - D);
-                const float dss = dsp * sc;
+                const float dss = dsp * scl;
                 vaxpy(dP, dss, v);
-                if constexpr (SUMS) {
-                    vaxpy(m, ak, v);
-                    if (ak > 0.f) sum_dsc = fmaf(dsp, __logf(ak), sum_dsc);
+                if ((k % K::LPN) == sub) {
+                    if constexpr (!XC) p.edge_ws[p.tpos[e0 + k]] = make_float2(ak * dt, dss);
+                    if constexpr (SUMS > 1) { if (ak > 0.f) sum_dsc = fmaf(dss, __logf(ak), sum_dsc); }
                 }
-                if (!XC && (k % K::LPN) == sub) p.edge_ws[p.tpos[e0 + k]] = make_float2(ak * dt, dss);
             }
         }
-        finish(li, i, it, gi, m, dP);
+        finish(li, i, it, gi, D, dP);
     };
 
     // dxd rows of a finished tile leave the registers only after the NEXT tile's staging: vmcnt is in-order and hipcc
@@ -2141,15 +2156,13 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
         __syncthreads();
     }
     {   // dp0 and the two scalars: tree over the node slots.  Thread (slot, sub) holds channels 4*(sub+q*LPN)+comp.
-        constexpr int W = 4 * K::NV + 2;
+        constexpr int W = 4 * K::NV;
         float* red = xs;                                        // [NT][W], spans into the dP tile for small C
 #pragma unroll
         for (int q = 0; q < K::NV; ++q) {
             red[tid * W + 4 * q + 0] = dp0acc.v[q].x; red[tid * W + 4 * q + 1] = dp0acc.v[q].y;
             red[tid * W + 4 * q + 2] = dp0acc.v[q].z; red[tid * W + 4 * q + 3] = dp0acc.v[q].w;
         }
-        red[tid * W + 4 * K::NV] = sum_ddt;
-        red[tid * W + 4 * K::NV + 1] = (sub == 0) ? sum_dsc : 0.f;   // d(score) sums are group-uniform: count once
         __syncthreads();
         if (tid < C) {
             const int c4 = tid / 4, comp = tid % 4;
@@ -2159,11 +2172,21 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             if (p.accumulate) v += row[C * C + tid];
             row[C * C + tid] = v;
         }
-        if (SUMS && p.sums_out && tid < 2) {
-            float v = 0.f;
-            for (int s = 0; s < K::NT; ++s) v += red[s * W + 4 * K::NV + tid];
-            if (tid == 1) v = v / sc;                           // d/d(score_scale) = sum d(score') * <P,x>
-            atomicAdd(p.sums_out + tid, v);
+        if constexpr (SUMS != 0) {
+            // the two scalars: butterfly inside each wave, then the wave sums in order (a serial walk over the NT threads'
+            // values by two threads was 256 dependent LDS reads at the tail of every workgroup: +3.6 us per launch)
+            float v0 = sum_ddt, v1 = sum_dsc;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_xor(v0, off, 64); if (SUMS > 1) v1 += __shfl_xor(v1, off, 64); }
+            __syncthreads();                                    // the dp0 tree has read red[]
+            if (lane == 0) { red[2 * wave] = v0; red[2 * wave + 1] = v1; }
+            __syncthreads();
+            if (p.sums_out && tid < (SUMS > 1 ? 2 : 1)) {
+                float v = 0.f;
+                for (int w_ = 0; w_ < K::NW; ++w_) v += red[2 * w_ + tid];
+                if (tid == 1) v = v / (sc * sc);                // d/d(score_scale) = sum d(score') <P,x> = (1/sc) sum d(score') log alpha; the terms carry one more sc
+                atomicAdd(tid == 0 ? p.sums_out : p.sums_sc_out, v);
+            }
         }
     }
 }
@@ -3124,14 +3147,15 @@ extern "C" int gadapt_debug_set_fused_backward(int on) { g_fused_bwd.store(on ? 
 #endif
 template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha,
                                        const float* a, const float* p0, const float* lp, float* edge_ws, float* dxd, float* slab,
-                                       int accumulate, float* sums_out, float* g_out, int residual_only, int g_cols, int x_cols, hipStream_t st) {
+                                       int accumulate, float* sums_out, float* g_out, int residual_only, int g_cols, int x_cols, hipStream_t st, float* sums_sc_out) {
     using K = Cfg<C>;
     const int n_tiles = (g->n_nodes + K::TM - 1) / K::TM;
-    if (g_cols < 0 || g_cols > 4 || (g_cols && sums_out)) return fail(GADAPT_E_BADARG, "compact upstream gradient: 1..4 columns, without d dt / d scale sums");
-    if ((x_cols != 0 && x_cols != 4) || (x_cols && (sums_out || g_cols || g_out)))
-        return fail(GADAPT_E_BADARG, "compact layer input: 4 columns, layer 0 of a block of >= 2 layers, no d x0 / d dt / d scale");
+    if (g_cols < 0 || g_cols > 4) return fail(GADAPT_E_BADARG, "compact upstream gradient: 1..4 columns");
+    if ((x_cols != 0 && x_cols != 4) || (x_cols && (g_cols || g_out)))
+        return fail(GADAPT_E_BADARG, "compact layer input: 4 columns, layer 0 of a block of >= 2 layers, no d x0");
     BwdTArgs pt{x_in, g_in, alpha, a, lp, g->rowptr_t, g->col_t, g->tpos_s, meta_for<K::TM>(g->meta_t), reinterpret_cast<float2*>(edge_ws), dxd, slab, sums_out,
                 g->n_nodes, n_tiles, accumulate, residual_only, g->n_edges, nullptr, g_cols};
+    pt.sums_sc_out = sums_sc_out;
 #ifdef GADAPT_STAMPS
     pt.stamps = g_stamp_buf ? g_stamp_buf + 1024 * 32 : nullptr;
 #endif
@@ -3174,15 +3198,20 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
             }
         }
         if (da_in_s) {
+        } else if (sums_out) {
+            // SUMS instantiations: 1 = d dt only (learn_step), 2 = d dt and d score_scale; each with the compact variants
+            auto go = [&](auto kern) { allow_lds(kern, lds_t); hipLaunchKernelGGL(kern, dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt); };
+            if (sums_sc_out) {
+                if (x_cols) go(grand_bwd_target_kernel<C, 2, false, true>); else if (g_cols) go(grand_bwd_target_kernel<C, 2, true>); else go(grand_bwd_target_kernel<C, 2>);
+            } else {
+                if (x_cols) go(grand_bwd_target_kernel<C, 1, false, true>); else if (g_cols) go(grand_bwd_target_kernel<C, 1, true>); else go(grand_bwd_target_kernel<C, 1>);
+            }
         } else if (x_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, false, true>, lds_t);
             hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else if (g_cols) {
             allow_lds(grand_bwd_target_kernel<C, false, true>, lds_t);
             hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
-        } else if (sums_out) {
-            allow_lds(grand_bwd_target_kernel<C, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, true>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else {
             allow_lds(grand_bwd_target_kernel<C, false>, lds_t);
             hipLaunchKernelGGL((grand_bwd_target_kernel<C, false>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
@@ -3302,7 +3331,8 @@ extern "C" int gadapt_layer_backward(const gadapt_graph* g, const float* x_in, c
     if (!g->tpos_s || (g_out && (!g->rowptr_s || !g->col_s))) return fail(GADAPT_E_BADARG, "layer_backward: source CSR missing");
     if (g_out == g_in || g_out == dxd_ws) return fail(GADAPT_E_BADARG, "layer_backward: g_out aliases an input");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, residual_only, 0, 0, st));
+    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, residual_only, 0, 0, st,
+                                        sums_out ? sums_out + 1 : nullptr));   // {d dt, d score_scale} side by side
 }
 
 extern "C" int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch, float* d_a, float* d_p0, int c, void* stream) {
@@ -3500,18 +3530,18 @@ extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_
 
 static int layer_backward_cols(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha, const float* a,
                                const float* p0, const float* layer_params, float* edge_ws, float* dxd_ws, float* slab, int accumulate,
-                               float* sums_out, float* g_out, int g_cols, int x_cols, int c, hipStream_t st) {
-    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, 0, g_cols, x_cols, st));
+                               float* sums_out, float* sums_sc_out, float* g_out, int g_cols, int x_cols, int c, hipStream_t st) {
+    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, 0, g_cols, x_cols, st, sums_sc_out));
 }
 extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all, const float* g_top, int g_top_cols, int n_layers,
                                      const float* a, int64_t a_stride, const float* p0, int64_t p0_stride, const float* layer_params,
-                                     float* g_ws, float* dxd_ws, float* edge_ws, float* slab, float* d_layer_params, float* d_x0,
+                                     float* g_ws, float* dxd_ws, float* edge_ws, float* slab, float* d_layer_params, int want_d_scale, float* d_x0,
                                      int c, void* stream) {
     if (int rc = check_graph(g, c)) return rc;
     if (!x_all || !alpha_all || !g_top || n_layers <= 0 || !a || !p0 || !layer_params || !g_ws || !dxd_ws || !edge_ws || !slab)
         return fail(GADAPT_E_BADARG, "block_backward: bad argument");
-    if (x0_cols != 0 && (x0_cols != 4 || n_layers < 2 || c < 8 || d_x0 || d_layer_params))
-        return fail(GADAPT_E_BADARG, "block_backward: compact x0 needs 4 columns, >= 2 layers, hidden >= 8, no d_x0 / d_layer_params");
+    if (x0_cols != 0 && (x0_cols != 4 || n_layers < 2 || c < 8 || d_x0))
+        return fail(GADAPT_E_BADARG, "block_backward: compact x0 needs 4 columns, >= 2 layers, hidden >= 8, no d_x0");
     const size_t nc = (size_t)g->n_nodes * c;
     const bool shared = (a_stride == 0);
     const int64_t slab_floats = gadapt_backward_slab_floats(g->n_nodes, c);
@@ -3521,20 +3551,14 @@ extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, 
         float* g_next = (l == 0) ? d_x0 : g_ws + ((n_layers - 1 - l) & 1) * nc;
         float* slab_l = shared ? slab : slab + (size_t)l * slab_floats;
         const int accumulate = (shared && l != n_layers - 1) ? 1 : 0;
-        int rc;
-        if (l == 0 && x0_cols) {                                    // compact layer-0 input [N,4]; no d x0 (checked in launch_bwd)
-            rc = layer_backward_cols(g, x_all, g_cur, alpha_all, a, p0, layer_params, edge_ws, dxd_ws, slab_l, accumulate,
-                                     d_layer_params, g_next, 0, x0_cols, c, static_cast<hipStream_t>(stream));
-        } else if (l == n_layers - 1 && g_top_cols > 0) {           // compact upstream gradient [N,g_top_cols]
-            if (!g->tpos_s || (g_next && (!g->rowptr_s || !g->col_s))) return fail(GADAPT_E_BADARG, "block_backward: source CSR missing");
-            rc = layer_backward_cols(g, x_all + l * nc, g_cur, alpha_all + (size_t)l * g->n_edges, a + l * a_stride, p0 + l * p0_stride,
-                                     layer_params + 2 * l, edge_ws, dxd_ws, slab_l, accumulate,
-                                     d_layer_params ? d_layer_params + 2 * l : nullptr, g_next, g_top_cols, 0, c, static_cast<hipStream_t>(stream));
-        } else {
-            rc = gadapt_layer_backward(g, x_all + l * nc, g_cur, alpha_all + (size_t)l * g->n_edges, a + l * a_stride, p0 + l * p0_stride,
-                                       layer_params + 2 * l, edge_ws, dxd_ws, slab_l, accumulate,
-                                       d_layer_params ? d_layer_params + 2 * l : nullptr, g_next, 0, c, stream);
-        }
+        float* d_dt = d_layer_params ? d_layer_params + l : nullptr;                 // [2,L]: d dt row, then d score_scale row
+        float* d_sc = (d_layer_params && want_d_scale) ? d_layer_params + n_layers + l : nullptr;
+        const hipStream_t st = static_cast<hipStream_t>(stream);
+        const int g_cols = (l == n_layers - 1) ? g_top_cols : 0, x_cols = (l == 0) ? x0_cols : 0;
+        if (!g->tpos_s || (g_next && (!g->rowptr_s || !g->col_s))) return fail(GADAPT_E_BADARG, "block_backward: source CSR missing");
+        // compact upstream gradient [N,g_top_cols] (top layer) / compact layer-0 input [N,4] (no d x0: checked in launch_bwd)
+        int rc = layer_backward_cols(g, x_all + l * nc, g_cur, alpha_all + (size_t)l * g->n_edges, a + l * a_stride, p0 + l * p0_stride,
+                                     layer_params + 2 * l, edge_ws, dxd_ws, slab_l, accumulate, d_dt, d_sc, g_next, g_cols, x_cols, c, st);
         if (rc) return rc;
         g_cur = g_next;
     }

@@ -38,23 +38,37 @@ def composite_coeffs(wq, bq, wk):
 
 class _GrandEulerBlock(torch.autograd.Function):
     """x_L = Euler^L(x_0).  Parameters stacked per distinct layer: wq/wk [S,C,C], bq/bk [S,C],
-    S = 1 (share_conv) or L; layer_params [L,2] = (dt, score_scale)."""
+    S = 1 (share_conv) or L; layer_params [L,2] = (dt, score_scale).
+
+    `steps` (trailing inputs, optional): the L one-element step parameters of `learn_step` (`GNN.steps`, GNN.py:179-180) handed
+    over as they are; `layer_params` is then the [L] vector of score scales.  The op packs (dt_l, scale_l) itself (one launch)
+    and returns d dt_l as one-element slices of the SAME flat tensor that carries the weight gradients, laid out
+    [dWq | dbq | dWk | dbk | d dt (L) | d scale (L)]: autograd installs them as `.grad` without copies and `FlatAdam` adopts the
+    whole range as its bucket - the `learn_step` path costs two small launches more than the fixed-step path, not ten."""
 
     @staticmethod
     def forward(ctx, x0, wq, bq, wk, bk, layer_params, graph: MeshGraph, num_layers: int, want_alpha: bool, x_all=None,
-                out_cols=None, x0_cols=0, coeffs=None):
+                out_cols=None, x0_cols=0, coeffs=None, *steps):
         for t, n in ((x0, 'x'), (wq, 'lin_query.weight'), (bq, 'lin_query.bias'), (wk, 'lin_key.weight'),
                      (layer_params, 'layer_params')):
             _require_gpu(t, n)
         n, c = x0.shape
         if x0_cols:                            # x0 = the compact [N,4] identity-encoder output at the start of x_all's slot 0
-            assert x0_cols == 4 and c == 4 and x_all is not None and not ctx.needs_input_grad[0] and not ctx.needs_input_grad[5]
+            assert x0_cols == 4 and c == 4 and x_all is not None and not ctx.needs_input_grad[0]
             c = x_all[0].shape[2]
         if n != graph.num_nodes:
             raise ValueError(f"x has {n} rows but the graph has {graph.num_nodes} nodes")
         if c not in _native.SUPPORTED_HIDDEN:
             raise NotImplementedError(f"hidden_dim={c}: fused kernels are built for {_native.SUPPORTED_HIDDEN}")
         L, S = int(num_layers), wq.shape[0]
+        ctx.n_steps, ctx.step_shapes = len(steps), [tuple(s_.shape) for s_ in steps]
+        if steps:
+            assert len(steps) == L and layer_params.shape == (L,) and all(s_.numel() == 1 for s_ in steps)
+            parts = []
+            for l in range(L):
+                _require_gpu(steps[l], f'steps.{l}')
+                parts += [steps[l].reshape(1), layer_params[l:l + 1]]
+            layer_params = torch.cat(parts).view(L, 2)                     # (dt_l, scale_l) pairs: one launch
         assert S in (1, L) and layer_params.shape == (L, 2)
         dev, st = x0.device, current_stream(x0.device)
         wq, bq, wk = wq.contiguous(), bq.contiguous(), wk.contiguous()
@@ -68,7 +82,7 @@ class _GrandEulerBlock(torch.autograd.Function):
             for s in range(S):
                 check(lib().gadapt_coeffs_forward(ptr(wq[s]), ptr(bq[s]), ptr(wk[s]), ptr(a[s]), ptr(p0[s]), c, st),
                       'gadapt_coeffs_forward')
-        need_grad = any(ctx.needs_input_grad[:6])
+        need_grad = any(ctx.needs_input_grad[:6]) or any(ctx.needs_input_grad[13:])
         if x_all is None:                      # else: caller's [(L+1),N,C] buffer whose slot 0 already holds x0
             x_all = torch.empty(L + 1, n, c, device=dev, dtype=torch.float32)
             x_all[0].copy_(x0)
@@ -103,7 +117,7 @@ class _GrandEulerBlock(torch.autograd.Function):
         g_top = g_top.contiguous()
         g_cols = 0
         if ctx.out_cols is not None:
-            if ctx.out_cols <= 4 and not ctx.needs_input_grad[5]:
+            if ctx.out_cols <= 4:
                 g_cols = int(ctx.out_cols)      # the top layer's kernels read the compact [N,dim] gradient directly
             else:                               # one zero-padding pass instead of autograd's zeros + slice copy
                 g_phys, g_top = g_top, torch.empty(n, c, device=dev, dtype=torch.float32)
@@ -115,16 +129,23 @@ class _GrandEulerBlock(torch.autograd.Function):
         dxd_ws = torch.empty(n, c, device=dev, dtype=torch.float32)
         edge_ws = torch.empty(max(graph.num_edges, 1), 2, device=dev, dtype=torch.float32)
         slab = torch.empty(S, slab_floats, device=dev, dtype=torch.float32)
-        d_lp = torch.zeros(L, 2, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
+        want_lp = ctx.needs_input_grad[5] or any(ctx.needs_input_grad[13:])
+        # one flat tensor [dWq | dbq | dWk | dbk | d dt (L) | d scale (L)]: installed as the parameters' .grad without a copy, it
+        # is the gradient bucket of optim.FlatAdam (one Adam launch, one all-reduce); the 2L tail only when a step / scale
+        # gradient is wanted (the kernels accumulate into it atomically: zeroed here)
+        n_w = S * (2 * c * c + 2 * c)
+        flat = torch.empty(n_w + (2 * L if want_lp else 0), device=dev, dtype=torch.float32)
+        d_lp = None
+        if want_lp:
+            d_lp = flat[n_w:]
+            d_lp.zero_()
         d_x0 = torch.empty(n, c, device=dev, dtype=torch.float32) if need_x0 else None
         check(lib().gadapt_block_backward(graph.c_ref, ptr(x_all), ctx.x0_cols, ptr(alpha), ptr(g_top), g_cols, L,
                                           ptr(a), c * c if S > 1 else 0, ptr(p0), c if S > 1 else 0, ptr(layer_params),
-                                          ptr(g_ws), ptr(dxd_ws), ptr(edge_ws), ptr(slab), ptr(d_lp), ptr(d_x0), c, st),
+                                          ptr(g_ws), ptr(dxd_ws), ptr(edge_ws), ptr(slab), ptr(d_lp), int(bool(ctx.needs_input_grad[5])),
+                                          ptr(d_x0), c, st),
               'gadapt_block_backward')
         scratch = torch.empty(32 * (c * c + c), device=dev, dtype=torch.float32)
-        # one flat tensor [dWq | dbq | dWk | dbk]: installed as the parameters' .grad without a copy, it is the
-        # gradient bucket of optim.FlatAdam (one Adam launch, one all-reduce)
-        flat = torch.empty(S * (2 * c * c + 2 * c), device=dev, dtype=torch.float32)
         cuts = [0, S * c * c, S * (c * c + c), S * (2 * c * c + c), S * (2 * c * c + 2 * c)]
         d_wq, d_wk = flat[cuts[0]:cuts[1]].view(S, c, c), flat[cuts[2]:cuts[3]].view(S, c, c)
         d_bq, d_bk = flat[cuts[1]:cuts[2]].view(S, c), flat[cuts[3]:cuts[4]].view(S, c)
@@ -132,7 +153,12 @@ class _GrandEulerBlock(torch.autograd.Function):
             check(lib().gadapt_slab_reduce_coeffs_backward(ptr(slab[s]), slab_rows, ptr(scratch), ptr(wq[s]), ptr(bq[s]), ptr(wk[s]),
                                                            ptr(d_wq[s]), ptr(d_bq[s]), ptr(d_wk[s]), ptr(d_bk[s]), c, st),
                   'gadapt_slab_reduce_coeffs_backward')
-        return d_x0, d_wq, d_bq, d_wk, d_bk, d_lp, None, None, None, None, None, None, None
+        if ctx.n_steps:                         # layer_params was the [L] scale vector; the steps get their slices of the d dt row
+            d_scales = d_lp[L:] if ctx.needs_input_grad[5] else None
+            d_steps = tuple(d_lp[l:l + 1].view(ctx.step_shapes[l]) if ctx.needs_input_grad[13 + l] else None for l in range(L))
+            return (d_x0, d_wq, d_bq, d_wk, d_bk, d_scales, None, None, None, None, None, None, None) + d_steps
+        d_lp2 = d_lp.view(2, L).t() if ctx.needs_input_grad[5] else None     # [L,2] view of the [2,L] rows
+        return d_x0, d_wq, d_bq, d_wk, d_bk, d_lp2, None, None, None, None, None, None, None
 
 
 class _GrandResidual(torch.autograd.Function):
@@ -194,7 +220,7 @@ def grand_residual(x, wq, bq, wk, bk, scale: torch.Tensor, graph: MeshGraph, wan
 
 def grand_euler_block(x0: torch.Tensor, wq, bq, wk, bk, layer_params: torch.Tensor, graph: MeshGraph,
                       num_layers: int, want_alpha: bool = False, x_all: Optional[torch.Tensor] = None,
-                      out_cols: Optional[int] = None, x0_cols: int = 0, coeffs=None):
+                      out_cols: Optional[int] = None, x0_cols: int = 0, coeffs=None, steps=None):
     """Returns (x_L [N,C], alpha [L,E] in target-CSR order or None).
 
     `x_all` (optional): a contiguous [(L+1),N,C] buffer whose slot 0 IS `x0` (same memory); the
@@ -203,9 +229,12 @@ def grand_euler_block(x0: torch.Tensor, wq, bq, wk, bk, layer_params: torch.Tens
     `x0_cols=4`: `x0` is the compact [N,4] output of the identity encoder (zero-pad, `src/GNN.py:75-82`) stored at the
     start of `x_all`'s slot 0; layer 0 reads it directly and the padded [N,C] matrix is never written.
     `coeffs=(a [S,C,C], p0 [S,C])`: the composite coefficients of exactly these weights when the caller has them already
-    (`encode_features(..., conv=...)` computes them in the encoder's launch)."""
+    (`encode_features(..., conv=...)` computes them in the encoder's launch).
+    `steps`: the L one-element step parameters (`learn_step`); `layer_params` is then the [L] vector of score scales (see
+    `_GrandEulerBlock`)."""
     return _GrandEulerBlock.apply(x0.contiguous(), wq, bq, wk, bk, layer_params, graph, num_layers, want_alpha,
-                                  None if x_all is None else [x_all], out_cols, x0_cols, None if coeffs is None else [coeffs])
+                                  None if x_all is None else [x_all], out_cols, x0_cols, None if coeffs is None else [coeffs],
+                                  *(steps or ()))
 
 
 def score_scale(hidden_dim: int, temperature=None):

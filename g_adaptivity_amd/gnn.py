@@ -147,6 +147,7 @@ class GNN(nn.Module):
         self._graphs: Dict[Tuple, MeshGraph] = {}
         self._dt_const = None
         self._lp_const = None
+        self._sc_const = None
 
     # ------------------------------------------------------------------ graph cache
     def _graph(self, data, num_nodes: int, device) -> MeshGraph:
@@ -180,22 +181,27 @@ class GNN(nn.Module):
         return g
 
     def _layer_params(self, device) -> torch.Tensor:
-        """[L,2] = (dt_l, score_scale_l) on device; differentiable wrt `steps` / `sm_temp_a`."""
+        """[L,2] = (dt_l, score_scale_l) on device; differentiable wrt `sm_temp_a`.  With `learn_step` the [L] score scales
+        alone: the block op takes the step parameters themselves (`steps=`) and packs the pairs (functional._GrandEulerBlock)."""
         L = self.opt['num_layers']
-        learnable = self.opt.get('learn_step') or self.opt.get('softmax_temp_type') == 'learnable_a'
-        if not learnable:
+        learn_a = self.opt.get('softmax_temp_type') == 'learnable_a'
+        if not (self.opt.get('learn_step') or learn_a):
             if self._lp_const is None or self._lp_const.device != device:
                 sc = Fn.score_scale(self.opt['hidden_dim'], self.conv_layers[0]._temperature())
                 self._lp_const = torch.tensor([[float(self.opt['time_step']), sc]] * L, device=device, dtype=torch.float32)
             return self._lp_const
-        if self.opt.get('learn_step'):
-            dts = torch.cat([s.reshape(1) for s in self.steps])
+        if learn_a:
+            scales = torch.stack([layer._scale(device) for layer in self.conv_layers])
         else:
-            if self._dt_const is None or self._dt_const.device != device or self._dt_const.numel() != L:
-                self._dt_const = torch.full((L,), float(self.opt['time_step']), device=device)
-            dts = self._dt_const
-        scales = torch.stack([layer._scale(device) for layer in self.conv_layers])
-        return torch.stack([dts, scales], dim=1)
+            if self._sc_const is None or self._sc_const.device != device or self._sc_const.numel() != L:
+                sc = [float(layer._scale(device)) for layer in self.conv_layers]      # constants: read once
+                self._sc_const = torch.tensor(sc, device=device, dtype=torch.float32)
+            scales = self._sc_const
+        if self.opt.get('learn_step'):
+            return scales
+        if self._dt_const is None or self._dt_const.device != device or self._dt_const.numel() != L:
+            self._dt_const = torch.full((L,), float(self.opt['time_step']), device=device)
+        return torch.stack([self._dt_const, scales], dim=1)
 
     def _enc_is_zero_pad(self) -> bool:
         """True when the frozen encoder weight is the identity zero-pad eye(C, F) that `get_enc('identity')` installs
@@ -272,7 +278,7 @@ class GNN(nn.Module):
             else:
                 out0 = None
             learnable = o.get('learn_step') or o.get('softmax_temp_type') == 'learnable_a'
-            if (o.get('compact_slots', True) and native_in and x_all is not None and not learnable and o['num_layers'] >= 2 and o['hidden_dim'] >= 8
+            if (o.get('compact_slots', True) and native_in and x_all is not None and o['num_layers'] >= 2 and o['hidden_dim'] >= 8
                     and self.enc.weight.shape[1] <= 4 and self._enc_is_zero_pad()):
                 # identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the compact [N,4] features, the padded
                 # [N,C] matrix is never written (nor read back by the layer-0 backward)
@@ -309,7 +315,8 @@ class GNN(nn.Module):
             x, alpha = Fn.grand_euler_block(x, wq, bq, wk, bk, self._layer_params(dev), graph,
                                             o['num_layers'], want_alpha=store, x_all=x_all,
                                             out_cols=self.dim if (isinstance(self.dec, nn.Identity) and o.get('compact_slots', True)) else None,
-                                            x0_cols=x0_cols, coeffs=coeffs)
+                                            x0_cols=x0_cols, coeffs=coeffs,
+                                            steps=list(self.steps) if o.get('learn_step') else None)
             sliced = isinstance(self.dec, nn.Identity) and o.get('compact_slots', True)
             if store:                                                      # GRAND_plus.py:253-256, :381
                 for l, layer in enumerate(self.conv_layers):

@@ -47,6 +47,11 @@ extern "C" {
 int  gadapt_supported_hidden_dim(int c);
 const char* gadapt_last_error(void);
 int  gadapt_abi_version(void);
+/* Forget a pending error of the calling thread: the message of gadapt_last_error() and HIP's own sticky per-thread last error
+ * (hipGetLastError).  For callers that recover from a failure that did not come through this library - e.g. a hipGraph capture
+ * that was invalidated: every later launch check would otherwise report that stale error once.  Returns the HIP error code that
+ * was pending (0: none). */
+int  gadapt_clear_error(void);
 
 /* ------------------------------------------------------------------ graph
  * Replaces the per-forward edge bookkeeping of PyG's MessagePassing.propagate
@@ -180,17 +185,19 @@ int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_cols, int n
 
 /* Backward of the block.  g_top = dL/dx_all[L] (not modified): [N,C] when g_top_cols = 0, or the compact [N,g_top_cols]
  * (1..4 columns, zero beyond: the backward of x_phys = x[:, :dim], GNN.py:299, without materialising the padded
- * matrix; not together with d_layer_params).  x0_cols as in gadapt_block_forward (then d_x0 and d_layer_params
- * must be NULL).  g_ws: 2*N*C floats,
+ * matrix).  x0_cols as in gadapt_block_forward (then d_x0 must be NULL).  g_ws: 2*N*C floats,
  * dxd_ws: N*C, edge_ws: 2*E, slab: n_slots*gadapt_backward_slab_floats(N,c) with
- * n_slots = 1 (shared weights) or L.  d_layer_params (nullable) [L,2] accumulates.
+ * n_slots = 1 (shared weights) or L.  d_layer_params (nullable) [2,L] accumulates (atomically): row 0 = d dt_l (learn_step,
+ * GNN.py:179-180,288-289), row 1 = d score_scale_l - two contiguous rows, so a caller can hand out the d dt row as the
+ * gradients of L one-element step parameters laid side by side.  want_d_scale = 0: only row 0 is accumulated (learn_step with a
+ * fixed temperature: the per-edge log terms of d score_scale are not computed).
  * d_x0 (nullable) [N,C] receives dL/dx_all[0]. */
 int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all,
                           const float* g_top, int g_top_cols, int n_layers,
                           const float* a, int64_t a_stride, const float* p0, int64_t p0_stride,
                           const float* layer_params,
                           float* g_ws, float* dxd_ws, float* edge_ws, float* slab,
-                          float* d_layer_params, float* d_x0, int c, void* stream);
+                          float* d_layer_params, int want_d_scale, float* d_x0, int c, void* stream);
 
 /* ------------------------------------------------------------------ generic message-passing primitives
  * What PyG's MessagePassing.propagate / utils.softmax do with index_select + scatter, per CSR row, for the conv variants

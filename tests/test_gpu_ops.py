@@ -285,6 +285,38 @@ def test_encode_features_equals_concat_then_linear(gpu_device, with_f, with_uu):
 
 
 @pytest.mark.gpu
+def test_learn_step_gradients_ride_in_the_flat_tensor(gpu_device):
+    """`learn_step` (GNN.py:179-180,288-289) with shared convs at hidden 64 - the shape of the metric workload: the step
+    gradients come back as one-element slices of the tensor that carries the weight gradients ([dWq|dbq|dWk|dbk|d dt]), so
+    FlatAdam adopts the whole range; compact slots stay on (compact layer-0 input, compact top gradient); values vs the oracle."""
+    from g_adaptivity_amd import mse_loss
+    opt, ds, data, oracle = make_case((16, 16), 3, 64, 4, learn_step=True)
+    with torch.no_grad():
+        for l, s_ in enumerate(oracle.steps):
+            s_.fill_(0.05 + 0.03 * l)                                       # distinct steps per layer
+    model = hip_model_like(oracle, ds, opt, gpu_device)
+    F.mse_loss(oracle(data), data.x_phys).backward()
+    ours = FlatAdam(model.parameters(), lr=1e-3)
+    ours.zero_grad()
+    dd = data.clone().to(gpu_device)
+    mse_loss(model(dd), dd.x_phys).backward()
+    for l in range(4):
+        assert model.steps[l].grad.shape == model.steps[l].shape
+        assert rel_err(model.steps[l].grad, oracle.steps[l].grad)[0] <= 1e-4, (l, model.steps[l].grad, oracle.steps[l].grad)
+    for name in ('lin_query.weight', 'lin_query.bias', 'lin_key.weight'):
+        want = dict(oracle.conv_layers[0].named_parameters())[name].grad
+        got = dict(model.conv_layers[0].named_parameters())[name].grad
+        assert rel_err(got, want)[0] <= 1e-4, name
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) == 4 + 4 and len({g.untyped_storage().data_ptr() for g in grads}) == 1
+    ours.step()
+    assert ours.grad_bucket.untyped_storage().data_ptr() == grads[0].untyped_storage().data_ptr()
+    assert ours.grad_bucket.numel() == 2 * (64 * 64 + 64) + 4
+    g = next(iter(model._graphs.values()))
+    assert model.opt['compact_slots'] and g.num_nodes == 3 * 256
+
+
+@pytest.mark.gpu
 def test_flat_adam_adopts_the_block_gradient_tensor(gpu_device):
     """After backward the four weight gradients are views of one tensor; FlatAdam steps on that memory directly."""
     from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt, mse_loss

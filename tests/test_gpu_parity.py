@@ -39,6 +39,8 @@ CASES = [
     ((12, 12), 2, 16, 3, 'GRAND', {'residual': False, 'non_lin': 'tanh'}),
     ((12, 12), 2, 64, 2, 'GRAND_plus', {'gnn_normalize': True}),
     ((11, 11), 2, 32, 3, 'GRAND_plus', {'learn_step': True, 'share_conv': False}),
+    ((16, 16), 2, 64, 4, 'GRAND_plus', {'learn_step': True}),                           # shared convs, compact slots + d dt sums
+    ((12, 12), 2, 128, 2, 'GRAND', {'learn_step': True}),
     ((17,), 4, 16, 2, 'GRAND_plus', {'fix_boundary': False}),
     # BASELINE config 4 shape: 64x64, 6 layers, hidden 128, GRAND, features [x, y, uu] (two meshes: the oracle stays quick)
     ((64, 64), 2, 128, 6, 'GRAND', {'gnn_inc_feat_f': False, 'noise_factor': 3.0}),
@@ -104,6 +106,11 @@ def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, c
             assert g.wide_deg['t'] == 0
         elif hidden == 64 and len(mesh_dims) == 2 and mesh_dims[0] <= 64 and extra.get('fix_boundary', True):
             assert g.wide_deg['t'] > 0                      # mesh-ordered hidden-64 batch: the wide forward ran
+        if extra.get('learn_step'):                         # d L / d dt_l (GNN.py:288-289): the d dt sums of the target pass
+            for l in range(layers):
+                e64 = rel_err(model.steps[l].grad, o64.steps[l].grad)[0]
+                noise = rel_err(oracle.steps[l].grad, o64.steps[l].grad)[0]
+                assert e64 <= max(GRAD_TOL, 1.5 * noise), f"steps.{l}.grad vs fp64 oracle: {e64:.2e} (fp32 oracle: {noise:.2e})"
     finally:
         _graph_mod.WIDE_MIN_NODES = keep
     nf = extra.get('noise_factor', 1.5)
