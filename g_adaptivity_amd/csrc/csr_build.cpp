@@ -63,23 +63,34 @@ extern "C" int gadapt_tile_meta_host(const int32_t* rowptr, const int32_t* col, 
 }
 
 // ELL-8 copy of one CSR orientation for the wide kernels (see include/gadapt_hip.h): row i -> ell[8i..8i+7], unused
-// entries -1, rows padded to a multiple of 256.  *max_deg_out = the longest row if the orientation qualifies
-// (every row <= 8 entries and every neighbour of node i inside rows [256*(i/256) - 64, 256*(i/256) + 320)), else 0.
+// entries -1, rows padded to a multiple of 256 (rows longer than 8 are cut: such a graph never qualifies).  *max_deg_out = the
+// longest row if the orientation qualifies for the 384-row window (every row <= 8 entries and every neighbour of node i
+// inside rows [256*(i/256) - 64, 256*(i/256) + 320)), else 0.
 extern "C" int gadapt_ell_build_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t* ell_out, int32_t* max_deg_out) {
     if (!rowptr || !col || !ell_out || !max_deg_out || n_nodes <= 0) return GADAPT_E_BADARG;
     const int64_t n_pad = (n_nodes + 255) / 256 * 256;
     for (int64_t k = 0; k < n_pad * 8; ++k) ell_out[k] = -1;
+    for (int64_t i = 0; i < n_nodes; ++i) {
+        const int32_t e0 = rowptr[i], d = rowptr[i + 1] - e0;
+        for (int32_t k = 0; k < d && k < 8; ++k) ell_out[8 * i + k] = col[e0 + k];
+    }
+    return gadapt_wide_window_host(rowptr, col, n_nodes, 64, 8, max_deg_out);
+}
+
+// The wide kernels' locality test for a window of 256 + 2 * halo rows: *max_deg_out = the longest row if every row has at most
+// max_row entries and every neighbour of node i lies in rows [256*(i/256) - halo, 256*(i/256) + 256 + halo), else 0.
+extern "C" int gadapt_wide_window_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int halo, int max_row, int32_t* max_deg_out) {
+    if (!rowptr || !col || !max_deg_out || n_nodes <= 0 || halo < 0 || max_row <= 0) return GADAPT_E_BADARG;
     int32_t longest = 0;
     bool ok = true;
     for (int64_t i = 0; i < n_nodes && ok; ++i) {
         const int32_t e0 = rowptr[i], d = rowptr[i + 1] - e0;
-        if (d > 8) { ok = false; break; }
+        if (d > max_row) { ok = false; break; }
         if (d > longest) longest = d;
-        const int64_t lo = i / 256 * 256 - 64, hi = lo + 384;
+        const int64_t lo = i / 256 * 256 - halo, hi = lo + 256 + 2 * (int64_t)halo;
         for (int32_t k = 0; k < d; ++k) {
             const int32_t j = col[e0 + k];
             if (j < lo || j >= hi) { ok = false; break; }
-            ell_out[8 * i + k] = j;
         }
     }
     *max_deg_out = ok ? longest : 0;

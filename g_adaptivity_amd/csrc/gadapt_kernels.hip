@@ -3070,18 +3070,18 @@ static inline int wide_grid(int n_steps) {
 static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                            const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st) {
     const int n_steps = (g->n_nodes + wide::STEP - 1) / wide::STEP;
-    wide::FwdArgs p{x_in, x_out, a, p0, lp, g->ell_t, g->rowptr_t, alpha_out, g->n_nodes, n_steps, residual_only, g->wide_deg_t, nullptr, x_top4};
+    const bool big = g->wide_deg_t <= 0;                        // 512-row window (meshes with up to 128 nodes per row)
+    wide::FwdArgs p{x_in, x_out, a, p0, lp, g->ell_t, g->rowptr_t, alpha_out, g->n_nodes, n_steps, residual_only,
+                    big ? g->wide_big_deg_t : g->wide_deg_t, nullptr, x_top4};
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
 #endif
     ProfScope prof(0, st, (x_cols ? 2 : 0) | (x_out ? 0 : 4));
-    constexpr int lds = wide::fwd_lds_bytes();
-    if (x_cols) {
-        allow_lds(wide::fwd_kernel<true>, lds);
-        hipLaunchKernelGGL(wide::fwd_kernel<true>, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
+    auto go = [&](auto kern, int lds) { allow_lds(kern, lds); hipLaunchKernelGGL(kern, dim3(wide_grid(n_steps)), dim3(512), lds, st, p); };
+    if (big) {
+        if (x_cols) go(wide::fwd_kernel<true, true>, wide::fwd_lds_bytes<true>()); else go(wide::fwd_kernel<false, true>, wide::fwd_lds_bytes<true>());
     } else {
-        allow_lds(wide::fwd_kernel<false>, lds);
-        hipLaunchKernelGGL(wide::fwd_kernel<false>, dim3(wide_grid(n_steps)), dim3(512), lds, st, p);
+        if (x_cols) go(wide::fwd_kernel<true, false>, wide::fwd_lds_bytes<false>()); else go(wide::fwd_kernel<false, false>, wide::fwd_lds_bytes<false>());
     }
     return check_launch("wide::fwd_kernel");
 }
@@ -3109,7 +3109,7 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
     using K = Cfg<C>;
     if (x_cols != 0 && x_cols != 4) return fail(GADAPT_E_BADARG, "compact layer input: 4 columns");
     if constexpr (C == 64) {
-        if (g->ell_t && g->wide_deg_t > 0 && wide_enabled()) return launch_wide_fwd(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, x_cols, x_top4, st);
+        if (g->ell_t && (g->wide_deg_t > 0 || (g->wide_big_deg_t > 0 && g->wide_big_deg_t <= 7)) && wide_enabled()) return launch_wide_fwd(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, x_cols, x_top4, st);
     }
     FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t), alpha_out, g->n_nodes,
               (g->n_nodes + K::TM - 1) / K::TM, residual_only, g->n_edges, nullptr, x_top4};

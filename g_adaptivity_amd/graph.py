@@ -169,6 +169,13 @@ class MeshGraph:
                 raise _native.NativeError("gadapt_ell_build_host failed")
             ells[tag], wide_deg[tag] = ell.to(self.device), (int(md.value) if (WIDE_KERNELS and n >= WIDE_MIN_NODES) else 0)
         self._ells, self.wide_deg = ells, wide_deg
+        # 512-row window of the wide forward: row-major meshes with up to 128 nodes per mesh row that miss the 384-row one
+        self.wide_big_deg = 0
+        if WIDE_KERNELS and n >= WIDE_MIN_NODES and wide_deg['t'] == 0:
+            md = C.c_int32(0)
+            if _native.lib().gadapt_wide_window_host(rowptr_t.data_ptr(), col_t.data_ptr(), n, 128, 7, C.addressof(md)) != 0:
+                raise _native.NativeError("gadapt_wide_window_host failed")
+            self.wide_big_deg = int(md.value)
         self.edge_index = edge_index                        # as given (original order/device)
         self.rowptr_t, self.col_t, self.eid_t = (t.to(self.device) for t in (rowptr_t, col_t, eid_t))
         self.rowptr_s, self.col_s, self.perm_s, self.tpos_s = (t.to(self.device) for t in (rowptr_s, col_s, perm_s, tpos_s))
@@ -178,7 +185,7 @@ class MeshGraph:
                                     self.tpos_s.data_ptr(),
                                     (C.c_void_p * 3)(*[metas[('t', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]),
                                     (C.c_void_p * 3)(*[metas[('s', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]),
-                                    ells['t'].data_ptr(), ells['s'].data_ptr(), wide_deg['t'], wide_deg['s'])
+                                    ells['t'].data_ptr(), ells['s'].data_ptr(), wide_deg['t'], wide_deg['s'], self.wide_big_deg)
         self.c_ref = C.byref(self.c_struct)
 
     @property

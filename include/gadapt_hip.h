@@ -92,6 +92,8 @@ typedef struct gadapt_graph {
     const int32_t* ell_s;      /* device: out-neighbours (targets), same layout */
     int32_t wide_deg_t;        /* longest in-row if the target orientation qualifies for the wide kernels, else 0 */
     int32_t wide_deg_s;        /* same for the source orientation */
+    int32_t wide_big_deg_t;    /* longest in-row if the target orientation qualifies for the 512-row window of the wide forward
+                                  (gadapt_wide_window_host(halo 128, rows <= 7): meshes with up to 128 nodes per row), else 0 */
 } gadapt_graph;
 
 /* ELL-8 copy of one CSR orientation (host pointers).  The wide kernels (hidden size 64: one wave owns 32 consecutive
@@ -100,6 +102,10 @@ typedef struct gadapt_graph {
  * batches do; any other graph takes the tiled kernels.  ell_out: round_up(N,256)*8 int32; *max_deg_out = longest
  * row when the orientation qualifies, else 0. */
 int gadapt_ell_build_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t* ell_out, int32_t* max_deg_out);
+/* The same locality test for a window of 256 + 2*halo rows and rows of at most max_row entries: *max_deg_out = longest row when
+ * every neighbour of node i lies in rows [256*(i/256) - halo, 256*(i/256) + 256 + halo), else 0.  halo 128 / max_row 7 is what
+ * the wide forward's 512-row window takes (row-major meshes with up to 128 nodes per mesh row: BASELINE config 5). */
+int gadapt_wide_window_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int halo, int max_row, int32_t* max_deg_out);
 
 /* ------------------------------------------------------------------ weights
  * A[o][c] = sum_r Wk[r][o] Wq[r][c],  p0[o] = sum_r Wk[r][o] bq[r].

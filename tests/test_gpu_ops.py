@@ -478,6 +478,37 @@ def test_wide_kernels_match_tiled_kernels(gpu_device, mesh_n, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mesh_n,batch,layers", [(128, 16, 2), (128, 3, 3), (100, 5, 2), (65, 7, 2), (96, 2, 4)],
+                         ids=['128x128-b16', '128x128-b3', '100x100-b5', '65x65-b7', '96x96-b2'])
+def test_wide_forward_512_row_window_matches_tiled_kernels(gpu_device, mesh_n, batch, layers):
+    """Meshes with 65..128 nodes per mesh row (BASELINE config 5: 128x128) miss the wide forward's 384-row window - neighbours
+    sit up to 129 rows away - and take its 512-row variant (256-byte rows, XOR-swizzled chunks): full model, forward + backward,
+    against the tiled kernels on the same inputs.  Covers several steps per workgroup in both walk directions (b16: 1024 steps
+    on 256 workgroups), ragged last steps (100x100, 65x65), the compact layer-0 input and the head-only last output."""
+    from g_adaptivity_amd import graph as graph_mod
+    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=64, num_layers=layers, device=str(gpu_device), show_mesh_evol_plots=True)
+    ds = MeshDataset([mesh_n, mesh_n], batch, seed=5)
+    data = collate(ds.samples).to(gpu_device)
+    res = {}
+    for wide in (True, False):
+        graph_mod.WIDE_KERNELS = wide
+        try:
+            torch.manual_seed(3)
+            model = GNN(ds, opt).to(gpu_device).train()
+            out = model(data)
+            F.mse_loss(out, data.x_phys).backward()
+            torch.cuda.synchronize()
+            g = next(iter(model._graphs.values()))
+            assert g.wide_deg['t'] == 0 and (g.wide_big_deg > 0) == wide
+            lay = model.conv_layers[0]
+            res[wide] = (out.detach().clone(), lay.stored_alpha.detach().clone(), lay.lin_query.weight.grad.clone(), lay.lin_key.weight.grad.clone())
+        finally:
+            graph_mod.WIDE_KERNELS = True
+    for name, a, b, tol in zip(('x_phys', 'alpha (last layer)', 'd lin_query.weight', 'd lin_key.weight'), res[True], res[False], (2e-6, 1e-5, 2e-5, 2e-5)):   # alpha: after 1..3 layers of differently rounded inputs (measured 3.8e-6 .. 4.5e-6)
+        assert rel_err(a, b)[0] <= tol, (name, rel_err(a, b))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mesh_n,batch", [(5, 1), (9, 3), (16, 1), (17, 2), (31, 1), (33, 9), (50, 11), (63, 17), (64, 1), (64, 5)],
                          ids=lambda v: str(v))
 def test_wide_kernels_size_sweep(gpu_device, mesh_n, batch):

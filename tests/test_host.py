@@ -321,3 +321,26 @@ def test_fingerprint_separates_diagonal_flip():
     # an order change of the same edge set is a different key as well (summation order follows the caller's edge order)
     perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(0))
     assert content_fingerprint([ei]) != content_fingerprint([ei[:, perm].contiguous()])
+
+
+def test_wide_window_locality_test():
+    """gadapt_wide_window_host: row-major meshes with up to 64 nodes per mesh row fit the 384-row window (halo 64), 65..128 only
+    the 512-row one (halo 128); a mesh 129 wide fits neither; the ELL copy is complete either way."""
+    import ctypes as C
+    lib = _native.lib()
+    for n, want64, want128 in ((64, True, True), (65, False, True), (128, False, True), (129, False, False)):
+        m = square_mesh(n)
+        d = collate([m]); d.corner_nodes = [m.corner_nodes]
+        ei = prepare_edge_index(d, 2, n, True, False, n * n)
+        g = MeshGraph(ei, n * n, 'cpu')
+        got = {}
+        for halo, rows in ((64, 8), (128, 7)):
+            md = C.c_int32(0)
+            assert lib.gadapt_wide_window_host(g.rowptr_t.data_ptr(), g.col_t.data_ptr(), n * n, halo, rows, C.addressof(md)) == 0
+            got[halo] = md.value
+        assert (got[64] > 0) == want64 and (got[128] > 0) == want128, (n, got)
+        assert got[128] in (0, 6)
+        ell = g._ells['t'].view(-1, 8)[:n * n]
+        deg = (g.rowptr_t[1:] - g.rowptr_t[:-1]).long()
+        assert torch.equal((ell >= 0).sum(1), deg)                              # complete even where the 384-row test fails
+        assert torch.equal(ell[ell >= 0].long(), g.col_t[:int(deg.sum())].long())
