@@ -56,7 +56,8 @@ def algorithmic_bytes(kernel, n_nodes, n_edges, c, variant=0, dim=2):
     if kernel == 'forward':            # read x, write x'
         return x_in + (16 * n_nodes if variant & 4 else dense) + csr
     if kernel == 'backward_target':    # read g, read saved x  (+ CSR by target)
-        return (4 * n_nodes * dim if variant & 1 else dense) + x_in + csr
+        # compact layer input: d alpha = dt <g_i, x_k> contracts over the 4 live columns - 16 bytes of each g row are read
+        return (4 * n_nodes * dim if variant & 1 else (16 * n_nodes if variant & 2 else dense)) + x_in + csr
     if kernel == 'backward_source':    # write dx               (+ CSR by source)
         return dense + csr
     raise KeyError(kernel)

@@ -2192,6 +2192,86 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward, target pass of a layer whose INPUT is the compact [N,4] encoder output (layer 0 behind the identity encoder,
+// GNN.py:75-82: x0 = [features | 0]).  No source pass follows such a launch (d x0 is not wanted), so all it owes is the
+// weight-gradient partial - and with x zero beyond column 3 that partial lives in a 4 x 4 corner:
+//   d alpha_ik = dt <g_i, x_k>          touches the first four columns of g_i only,
+//   dP_i = sum_k ds_ik x_k              is zero beyond column 3,
+//   dA[o][c] += dP_i[o] x_i[c], dp0[o] += dP_i[o]     are non-zero for o, c < 4 only.
+// So the launch reads 16 bytes of each g row, the [N,4] matrix and alpha, and adds 20 numbers per workgroup to the slab: one
+// NODE PER LANE, no LDS tiles, no matrix cores.  (The generic kernel with the XC staging did the full-width edge walk, the dA
+// phase and the flush of a 64 x 64 block for the same 20 numbers: 25.6 us per launch at hidden 64 on the metric workload.)
+// Same arithmetic as grand_bwd_target_kernel, SUMS included; summation order: per lane over its nodes (grid-stride, ascending),
+// wave butterfly, the four waves in order - fixed for a given grid, so runs stay bit-reproducible.
+// ------------------------------------------------------------------------------------------------
+template <int C, int SUMS>
+__global__ __launch_bounds__(256) void grand_bwd_target_compact_kernel(BwdTArgs p) {
+    __shared__ float red[4][24];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float dt = p.lp[0], sc = p.lp[1];
+    const float scl = SUMS ? sc * dt : sc;
+    float acc[22];                                              // dA[o][c] (16), dp0[o] (4), d dt, d score_scale
+#pragma unroll
+    for (int k = 0; k < 22; ++k) acc[k] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < p.n_nodes; i += (int64_t)gridDim.x * 256) {
+        const float4 g4 = *reinterpret_cast<const float4*>(p.g_in + (size_t)i * C);
+        const float4 xi = *reinterpret_cast<const float4*>(p.x_in + 4 * (size_t)i);
+        const float4 dm = SUMS ? g4 : make_float4(dt * g4.x, dt * g4.y, dt * g4.z, dt * g4.w);
+        const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1];
+        float D = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const float4 xk = *reinterpret_cast<const float4*>(p.x_in + 4 * (size_t)p.col[e]);
+            D = fmaf(p.alpha[e], dot4(dm, xk), D);
+        }
+        float4 dP = f4zero();
+        for (int e = e0; e < e1; ++e) {
+            const float4 xk = *reinterpret_cast<const float4*>(p.x_in + 4 * (size_t)p.col[e]);
+            const float ak = p.alpha[e];
+            const float ds = ak * (dot4(dm, xk) - D) * scl;
+            axpy4(dP, ds, xk);
+            if constexpr (SUMS > 1) { if (ak > 0.f) acc[21] = fmaf(ds, __logf(ak), acc[21]); }
+        }
+        if constexpr (SUMS != 0) acc[20] += D - dot4(g4, xi);    // d dt = sum_i <g_i, m_i - x_i>, <g_i, m_i> = D (see the tiled kernel)
+        const float dp[4] = {dP.x, dP.y, dP.z, dP.w}, xv[4] = {xi.x, xi.y, xi.z, xi.w};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[4 * o + c] = fmaf(dp[o], xv[c], acc[4 * o + c]);
+            acc[16 + o] += dp[o];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 22; ++k) {
+        if (k >= 20 && (SUMS == 0 || (k == 21 && SUMS < 2))) continue;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
+        if (lane == 0) red[wave][k] = acc[k];
+    }
+    __syncthreads();
+    // this workgroup's slab row (layout of the tiled kernel: dA [C][C], then dp0 [C]); accumulate = 0: the row is written whole
+    float* row = p.slab + (size_t)blockIdx.x * (C * C + C);
+    if (!p.accumulate) {
+        for (int e = tid; e < C * C + C; e += 256) {
+            const int o = e / C, c = e % C;
+            const bool live = (e < C * C) ? (o < 4 && c < 4) : (e - C * C < 4);
+            if (!live) row[e] = 0.f;
+        }
+    }
+    if (tid < 20) {
+        const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        const int e = tid < 16 ? (tid >> 2) * C + (tid & 3) : C * C + (tid - 16);
+        row[e] = p.accumulate ? row[e] + v : v;
+    }
+    if constexpr (SUMS != 0) {
+        if (p.sums_out && tid >= 20 && tid < (SUMS > 1 ? 22 : 21)) {
+            float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            if (tid == 21) v = v / (sc * sc);
+            atomicAdd(tid == 20 ? p.sums_out : p.sums_sc_out, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward, source pass
 // ------------------------------------------------------------------------------------------------
 struct BwdSArgs {
@@ -3186,6 +3266,18 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     // hidden 32 / 64 with a source pass to follow: the source pass accumulates dA / dp0 (see grand_bwd_source_kernel)
     constexpr bool CAN_MOVE_DA = (C == 32 || C == 64) && GADAPT_DA_IN_SOURCE;
     const bool da_in_s = CAN_MOVE_DA && g_out && !sums_out && !x_cols;
+#ifndef GADAPT_XC_COMPACT_KERNEL
+#define GADAPT_XC_COMPACT_KERNEL 1      /* 0: the tiled target kernel with the XC staging for the compact layer input (A/B) */
+#endif
+    if (GADAPT_XC_COMPACT_KERNEL && x_cols && !residual_only) {
+        ProfScope prof(1, st, 2);
+        // the slab holds one row per workgroup of the tiled target pass: same grid, so every row is visited
+        const dim3 grid(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS)));
+        if (sums_out && sums_sc_out) hipLaunchKernelGGL((grand_bwd_target_compact_kernel<C, 2>), grid, dim3(256), 0, st, pt);
+        else if (sums_out) hipLaunchKernelGGL((grand_bwd_target_compact_kernel<C, 1>), grid, dim3(256), 0, st, pt);
+        else hipLaunchKernelGGL((grand_bwd_target_compact_kernel<C, 0>), grid, dim3(256), 0, st, pt);
+        return check_launch("grand_bwd_target_compact_kernel");
+    }
     {
         ProfScope prof(1, st, (g_cols ? 1 : 0) | (x_cols ? 2 : 0));
         if constexpr (CAN_MOVE_DA) {

@@ -151,7 +151,12 @@ def test_golden_fixtures(gpu_device, path):
         # G4 (64x64, 6 layers, hidden 128, ONE mesh): |grad| ~ 1e-10 after cancellation, both fp32 paths are 2-7e-4 off the fp64
         # result and neither is consistently ahead (tests/test_gpu_parity.py header): 3x the oracle's own error there
         nf = 3.0 if os.path.basename(path).startswith('G4') else 1.5
-        assert rel_err(p.grad[0], want64)[0] <= max(1e-4, nf * noise), (k, rel_err(p.grad[0], want64)[0], noise)
+        # G5 (128x128, 20 layers, ONE mesh): the same kind of remainder (|d_bq| ~ 2e-9); which fp32 summation order lands closer
+        # to fp64 is luck (tools/diag_parity_cfg.py, MI355X: d_wq 5.7e-4 with the wide forward's 512-row window vs 3.2e-5 with the
+        # tiled forward while the fp32 ORACLE is at 5.1e-4; on 64x64 x 20 layers the wide forward is the closer one, 2.9e-6 vs
+        # 7.7e-5) - d_bq measured 1.08e-4 there: floor 1.5e-4 for this fixture, as in tests/test_gpu_parity.py
+        floor = 1.5e-4 if os.path.basename(path).startswith('G5') else 1e-4
+        assert rel_err(p.grad[0], want64)[0] <= max(floor, nf * noise), (k, rel_err(p.grad[0], want64)[0], noise)
 
 
 @pytest.mark.gpu
@@ -504,7 +509,7 @@ def test_wide_forward_512_row_window_matches_tiled_kernels(gpu_device, mesh_n, b
             res[wide] = (out.detach().clone(), lay.stored_alpha.detach().clone(), lay.lin_query.weight.grad.clone(), lay.lin_key.weight.grad.clone())
         finally:
             graph_mod.WIDE_KERNELS = True
-    for name, a, b, tol in zip(('x_phys', 'alpha (last layer)', 'd lin_query.weight', 'd lin_key.weight'), res[True], res[False], (2e-6, 1e-5, 2e-5, 2e-5)):   # alpha: after 1..3 layers of differently rounded inputs (measured 3.8e-6 .. 4.5e-6)
+    for name, a, b, tol in zip(('x_phys', 'alpha (last layer)', 'd lin_query.weight', 'd lin_key.weight'), res[True], res[False], (2e-6, 1e-5, 1e-4, 1e-4)):   # alpha: after 1..3 layers of differently rounded inputs (measured 3.8e-6 .. 4.5e-6); weight gradients: cancelling sums, the 8e-5 of test_wide_kernels_size_sweep (measured 4.7e-5 .. 8.3e-5)
         assert rel_err(a, b)[0] <= tol, (name, rel_err(a, b))
 
 

@@ -82,9 +82,12 @@ def test_rollout_reuses_the_graph_and_hipgraph_replay_equals_eager(gpu_device):
 @pytest.mark.gpu
 def test_compact_encoder_output_equals_dense(gpu_device):
     """Identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the compact [N,4] features and the top layer's backward
-    the compact [N,dim] gradient; both must give exactly what the dense [N,C] matrices give (same kernels, same order)."""
+    the compact [N,dim] gradient.  The forward gives exactly what the dense [N,C] matrices give (same kernels, same order).
+    The weight gradients agree to rounding: layer 0's share is summed by the compact-input target kernel (one node per lane
+    over the 4 live columns) instead of the tiled kernel's per-tile matrix products - the same terms in another order."""
     import copy
     import torch.nn.functional as F
+    from helpers import rel_err
     from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt
     for mesh, hidden in (([24, 24], 64), ([13, 13], 16)):          # wide kernels / tiled kernels
         opt = hot_path_opt(mesh_dims=mesh, hidden_dim=hidden, num_layers=3, device=str(gpu_device))
@@ -97,6 +100,10 @@ def test_compact_encoder_output_equals_dense(gpu_device):
         F.mse_loss(out_c, data.x_phys).backward()
         grads_c = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
         model.zero_grad()
+        out_c2 = model(data)                                        # the compact path itself is bit-reproducible
+        F.mse_loss(out_c2, data.x_phys).backward()
+        assert torch.equal(out_c, out_c2) and all(torch.equal(p.grad, grads_c[k]) for k, p in model.named_parameters() if p.grad is not None)
+        model.zero_grad()
         model._enc_is_zero_pad = lambda: False                      # dense x0 [N,C] through encode + layer 0
         out_d = model(data)
         F.mse_loss(out_d, data.x_phys).backward()
@@ -104,7 +111,7 @@ def test_compact_encoder_output_equals_dense(gpu_device):
         assert torch.equal(out_c, out_d)
         for k, p in model.named_parameters():
             if p.grad is not None:
-                assert torch.equal(p.grad, grads_c[k]), k
+                assert rel_err(p.grad, grads_c[k])[0] <= 2e-6, (k, rel_err(p.grad, grads_c[k]))
         # ... and the fully dense data flow (opt['compact_slots'] = False: padded x0, full x_L, padded top gradient)
         torch.manual_seed(1)
         dense = GNN(ds, dict(opt, compact_slots=False)).to(gpu_device).train()
@@ -115,7 +122,7 @@ def test_compact_encoder_output_equals_dense(gpu_device):
         assert torch.equal(out_c, out_f)
         for k, p in dense.named_parameters():
             if p.grad is not None:
-                assert torch.equal(p.grad, grads_c[k]), k
+                assert rel_err(p.grad, grads_c[k])[0] <= 2e-6, (k, rel_err(p.grad, grads_c[k]))
 
 
 @pytest.mark.gpu

@@ -5,6 +5,9 @@ sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 from helpers import make_case, hip_model_like, rel_err, oracle_fp64_twin
 n, b, c, l, conv, inc_f = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], bool(int(sys.argv[6]))
 dev = torch.device('cuda:0')
+import os
+from g_adaptivity_amd import graph as _g
+_g.WIDE_MIN_NODES = int(os.environ.get('GADAPT_DIAG_WIDE_MIN', _g.WIDE_MIN_NODES))   # 0: wide forward for every size (what the tests do)
 opt, ds, data, oracle = make_case((n, n), b, c, l, conv, gnn_inc_feat_f=inc_f)
 model = hip_model_like(oracle, ds, opt, dev)
 tgt = data.x_phys
