@@ -1598,6 +1598,8 @@ struct BwdTArgs {
     unsigned long long* stamps;
     int g_cols;                                                 // GC kernels: g_in is [N,g_cols] (zero beyond), else unused
     float* sums_sc_out;                                         // d score_scale of this layer (one float); set with sums_out
+    int c;                                                      // hidden size (read by grand_bwd_target_compact_kernel only)
+    int g_stride;                                               // ... and the row pitch of its g_in, in floats
 };
 
 template <int NROWS, int NV> struct TBuf {
@@ -1618,9 +1620,14 @@ template <int NROWS, int NV> struct TBuf {
 // DA: this launch accumulates the weight-gradient partials (dA, dp0).  false when a source pass follows that does it
 // instead (dA = sum_i dP_i x_i^T = sum_j x_j y_j^T with y_j = sum_i ds_ij x_i, the vector the source pass forms anyway;
 // dp0 = sum_j sigma_j x_j): the target pass then has no dA phase, no accumulators and no slab flush.
-template <int C, int SUMS, bool GC = false, bool XC = false, bool DA = true>
+// D4: only columns 0..3 of dxd are wanted (the layer BELOW reads the compact [N,4] encoder output, so its backward contracts
+// d alpha = dt <g_i, x_k> over four columns and the source pass that follows this launch produces just those): dxd is written
+// as [N,4] and dP A[:, :4] is four dot products per node on the vector ALU - no projection phase on the matrix cores, no
+// pre-split copy, two barriers fewer per tile, and the dense dxd matrix (N C floats) is neither written nor read back.
+template <int C, int SUMS, bool GC = false, bool XC = false, bool DA = true, bool D4 = false>
 __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WAVES_BWD_T)) void grand_bwd_target_kernel(BwdTArgs p) {
     static_assert(DA || (!SUMS && !XC), "only the plain variants hand dA to the source pass");
+    static_assert(!D4 || (DA && !XC), "D4: a source pass follows, the weight gradients stay here");
     using K = Cfg<C>;
     using V = Vec<K::NV>;
     extern __shared__ float4 smem4[];
@@ -1639,11 +1646,21 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 
     // PRE: dP A takes dP from a pre-split f16 copy (lds_put_split) made after the edge walk in the window slot of slab t-1,
     // which nothing reads between that barrier and the next tile's commit; dinv = its row scales
-    constexpr bool PRE = K::MFMA && !XC && GADAPT_PRESPLIT_T && K::RING_T == 3 && TileGemm<C, true>::SPLIT && C < GADAPT_BWD_JIT_B_C;
+    constexpr bool PRE = K::MFMA && !XC && !D4 && GADAPT_PRESPLIT_T && K::RING_T == 3 && TileGemm<C, true>::SPLIT && C < GADAPT_BWD_JIT_B_C;
     float dinv[K::ITERS];
     TileGemm<C, true, GADAPT_SPLIT_F16_T || PRE> gemm;          // dxd = dP A
-    float acol[K::MFMA ? 1 : 4][K::MFMA ? 1 : C];               // VALU: A[o][4sub+t]
-    if constexpr (K::MFMA) {
+    float acol[(K::MFMA || D4) ? 1 : 4][(K::MFMA || D4) ? 1 : C];   // VALU: A[o][4sub+t]
+    float a4[D4 ? K::NV : 1][4][4];                             // D4: A[o][c], o = this lane's channels, c = 0..3
+    if constexpr (D4) {
+#pragma unroll
+        for (int q = 0; q < K::NV; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 r = *reinterpret_cast<const float4*>(p.A + (size_t)(4 * (sub + q * K::LPN) + e) * C);
+                a4[q][e][0] = r.x; a4[q][e][1] = r.y; a4[q][e][2] = r.z; a4[q][e][3] = r.w;
+            }
+        if constexpr (K::MFMA) gemm.init(lane, wave);
+    } else if constexpr (K::MFMA) {
         gemm.init(lane, wave);
     } else {
 #pragma unroll
@@ -1690,9 +1707,24 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                 }
             }
         }
+        if constexpr (D4) {
+            // dxd[i][0..3] = (base - dt) g_i[0..3] + sum_o dP_i[o] A[o][0..3]: this lane's channels, then the group
+            float t4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < K::NV; ++q) {
-            gk[it].v[q].x = w1 * gi.v[q].x; gk[it].v[q].y = w1 * gi.v[q].y; gk[it].v[q].z = w1 * gi.v[q].z; gk[it].v[q].w = w1 * gi.v[q].w;
+            for (int q = 0; q < K::NV; ++q) {
+                const float d[4] = {dP.v[q].x, dP.v[q].y, dP.v[q].z, dP.v[q].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t4[c] = fmaf(d[e], a4[q][e][c], t4[c]);
+            }
+            group_sum_n<K::LPN>(t4);
+            gk[it].v[0] = make_float4(fmaf(w1, gi.v[0].x, t4[0]), fmaf(w1, gi.v[0].y, t4[1]), fmaf(w1, gi.v[0].z, t4[2]), fmaf(w1, gi.v[0].w, t4[3]));   // lane sub == 0 holds columns 0..3
+        } else {
+#pragma unroll
+            for (int q = 0; q < K::NV; ++q) {
+                gk[it].v[q].x = w1 * gi.v[q].x; gk[it].v[q].y = w1 * gi.v[q].y; gk[it].v[q].z = w1 * gi.v[q].z; gk[it].v[q].w = w1 * gi.v[q].w;
+            }
         }
         lds_put<C>(ds, li, sub, dP);                            // over g_i: only this lane group reads that row
     };
@@ -1813,7 +1845,9 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 #pragma unroll
         for (int it = 0; it < K::ITERS; ++it) {
             const int i = node0 + it * K::SLOTS + slot;
-            if (i < p.n_nodes) {
+            if constexpr (D4) {
+                if (i < p.n_nodes && sub == 0) *reinterpret_cast<float4*>(p.dxd + 4 * (size_t)i) = gk[it].v[0];
+            } else if (i < p.n_nodes) {
                 if constexpr (GADAPT_T_STREAM) {
 #pragma unroll
                     for (int q = 0; q < K::NV; ++q) st_row4_nt<C>(p.dxd, i, sub + q * K::LPN, gk[it].v[q]);
@@ -1843,7 +1877,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             gr.template issue_sel<XC>(p.x_in, tb * K::TM, p.n_nodes, tid);
         }
         const int4 mreg = csr.metas_issue(tb, dir, p.n_tiles, tid);
-        if constexpr (K::MFMA && RESIDENT_B && !XC) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
+        if constexpr (K::MFMA && RESIDENT_B && !XC && !D4) gemm.load(p.A, nullptr);   // B fragments stay in registers for the whole launch
         csr.metas_commit(mreg, tid);
         if constexpr (K::RING_T == 3) {
             xr.template commit_sel<XC>(slab_ptr(tb - dir), p.n_nodes, tid);
@@ -2052,7 +2086,7 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
             }
             GADAPT_STAMP(p.stamps, tslot + 5);
             // ---- dxd = (base-dt) g + dP A
-            if constexpr (!XC) {
+            if constexpr (!XC && !D4) {
             if constexpr (K::MFMA && !RESIDENT_B) gemm.load(p.A, nullptr);
 #ifndef GADAPT_ABL_NO_GEMM
             if constexpr (PRE) {
@@ -2204,9 +2238,11 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
 // Same arithmetic as grand_bwd_target_kernel, SUMS included; summation order: per lane over its nodes (grid-stride, ascending),
 // wave butterfly, the four waves in order - fixed for a given grid, so runs stay bit-reproducible.
 // ------------------------------------------------------------------------------------------------
-template <int C, int SUMS>
+template <int SUMS>
 __global__ __launch_bounds__(256) void grand_bwd_target_compact_kernel(BwdTArgs p) {
     __shared__ float red[4][24];
+    const int C = p.c;
+    const int gs = p.g_stride;                                  // floats between g rows: C, or 4 when the layer above ran the D4 / source4 pair
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float dt = p.lp[0], sc = p.lp[1];
     const float scl = SUMS ? sc * dt : sc;
@@ -2214,22 +2250,51 @@ __global__ __launch_bounds__(256) void grand_bwd_target_compact_kernel(BwdTArgs 
 #pragma unroll
     for (int k = 0; k < 22; ++k) acc[k] = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < p.n_nodes; i += (int64_t)gridDim.x * 256) {
-        const float4 g4 = *reinterpret_cast<const float4*>(p.g_in + (size_t)i * C);
+        const float4 g4 = *reinterpret_cast<const float4*>(p.g_in + (size_t)i * gs);
         const float4 xi = *reinterpret_cast<const float4*>(p.x_in + 4 * (size_t)i);
         const float4 dm = SUMS ? g4 : make_float4(dt * g4.x, dt * g4.y, dt * g4.z, dt * g4.w);
-        const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1];
+        const int e0 = p.rowptr[i], e1 = p.rowptr[i + 1], deg = e1 - e0;
         float D = 0.f;
-        for (int e = e0; e < e1; ++e) {
-            const float4 xk = *reinterpret_cast<const float4*>(p.x_in + 4 * (size_t)p.col[e]);
-            D = fmaf(p.alpha[e], dot4(dm, xk), D);
-        }
         float4 dP = f4zero();
-        for (int e = e0; e < e1; ++e) {
-            const float4 xk = *reinterpret_cast<const float4*>(p.x_in + 4 * (size_t)p.col[e]);
-            const float ak = p.alpha[e];
-            const float ds = ak * (dot4(dm, xk) - D) * scl;
-            axpy4(dP, ds, xk);
-            if constexpr (SUMS > 1) { if (ak > 0.f) acc[21] = fmaf(ds, __logf(ak), acc[21]); }
+        if (deg <= 8) {
+            // the usual case, three memory round trips per node: (g row head, x row, row bounds) -> (8 column / alpha pairs,
+            // unconditional with clamped indices) -> (8 neighbour rows); a loop over the row would chain them per edge
+            const int last = max(p.n_edges - 1, 0);
+            int cj[8]; float ak[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = min(e0 + k, last);
+                cj[k] = p.col[e];
+                ak[k] = p.alpha[e];
+            }
+            float4 xk[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xk[k] = *reinterpret_cast<const float4*>(p.x_in + 4 * (size_t)cj[k]);
+            float da[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                ak[k] = (k < deg) ? ak[k] : 0.f;
+                da[k] = dot4(dm, xk[k]);
+                D = fmaf(ak[k], da[k], D);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float ds = ak[k] * (da[k] - D) * scl;
+                axpy4(dP, ds, xk[k]);
+                if constexpr (SUMS > 1) { if (ak[k] > 0.f) acc[21] = fmaf(ds, __logf(ak[k]), acc[21]); }
+            }
+        } else {
+            for (int e = e0; e < e1; ++e) {
+                const float4 xk = *reinterpret_cast<const float4*>(p.x_in + 4 * (size_t)p.col[e]);
+                D = fmaf(p.alpha[e], dot4(dm, xk), D);
+            }
+            for (int e = e0; e < e1; ++e) {
+                const float4 xk = *reinterpret_cast<const float4*>(p.x_in + 4 * (size_t)p.col[e]);
+                const float ak = p.alpha[e];
+                const float ds = ak * (dot4(dm, xk) - D) * scl;
+                axpy4(dP, ds, xk);
+                if constexpr (SUMS > 1) { if (ak > 0.f) acc[21] = fmaf(ds, __logf(ak), acc[21]); }
+            }
         }
         if constexpr (SUMS != 0) acc[20] += D - dot4(g4, xi);    // d dt = sum_i <g_i, m_i - x_i>, <g_i, m_i> = D (see the tiled kernel)
         const float dp[4] = {dP.x, dP.y, dP.z, dP.w}, xv[4] = {xi.x, xi.y, xi.z, xi.w};
@@ -3089,6 +3154,132 @@ __global__ __launch_bounds__(256) void adam_step_dev_kernel(float* param, const 
 
 // Workgroups of a launch: a multiple of 8 (XCD groups), at most max_blocks (the resident set) unless that would
 // give a workgroup more than 64 tiles (Cfg::MAXM: its tile metadata must fit the LDS table).
+// ------------------------------------------------------------------------------------------------
+// backward, source pass when only columns 0..3 of g_out are wanted (the layer below reads the compact [N,4] encoder output: see
+// grand_bwd_target_compact_kernel; the target pass before this launch was the D4 variant and left dxd as [N,4]):
+//   g_out[j][c] = dxd[j][c] + sum_i alpha_ij dt g_i[c] + sum_o A[c][o] y_j[o] + sigma_j p0[c],   c = 0..3,
+// with y_j = sum_i ds_ij x_i over the out-edges as in grand_bwd_source_kernel.  Of the g rows only the first 16 bytes are
+// gathered, A y is four dot products per node on the vector ALU (no y tile, no matrix cores, no barrier between edge walk and
+// result), and N C floats of dxd reads and g_out writes become N * 4 each.  GC: the upstream gradient is compact [N,g_cols].
+// ------------------------------------------------------------------------------------------------
+template <int HN_, int NV> struct SBuf4 {
+    static constexpr int N = HN_;
+    float4 g4[HN_];
+    Vec<NV> x[HN_];
+    float2 ev[HN_];
+    float4 d4;
+};
+#ifndef GADAPT_WAVES_BWD_S4
+#define GADAPT_WAVES_BWD_S4 3      /* hidden <= 64: 157..166 registers, three workgroups per CU (the launch uses a grid of 768) */
+#endif
+template <int C, bool GC = false>
+__global__ __launch_bounds__(Cfg<C>::NT, (C > 64 ? 2 : GADAPT_WAVES_BWD_S4)) void grand_bwd_source4_kernel(BwdSArgs p) {
+    using K = Cfg<C>;
+    using V = Vec<K::NV>;
+    extern __shared__ float4 smem4[];
+    using CsrT = TileCsr<C, 2, 0>;                              // aux = {alpha*dt, d<P,x>} per out-edge (source order)
+    CsrT csr;
+    csr.bind(reinterpret_cast<float*>(smem4), p.rowptr, p.col, p.edge_ws, p.meta, p.n_edges);
+    const int tid = threadIdx.x;
+    const int slot = tid / K::LPN, sub = tid % K::LPN;
+    float a4[K::NV][4][4];                                      // A[c][o], o = this lane's channels, c = 0..3
+#pragma unroll
+    for (int q = 0; q < K::NV; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 r = *reinterpret_cast<const float4*>(p.A + (size_t)c * C + 4 * (sub + q * K::LPN));
+            a4[q][0][c] = r.x; a4[q][1][c] = r.y; a4[q][2][c] = r.z; a4[q][3][c] = r.w;
+        }
+    const float4 p04 = *reinterpret_cast<const float4*>(p.p0);
+    auto ld_g4 = [&](int i) __attribute__((always_inline)) {   // columns 0..3 of row i of the upstream gradient (same address in the group)
+        if constexpr (GC) return ld_row4_compact(p.g_in, i, 0, p.g_cols);
+        else return *reinterpret_cast<const float4*>(p.g_in + (size_t)i * C);
+    };
+    // result of one node: the group's sum of the four dot products, lane sub == 0 writes
+    auto finish = [&](int j, const float4& d4, const float4& z4, const V& y, float sig) __attribute__((always_inline)) {
+        float t4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < K::NV; ++q) {
+            const float yv[4] = {y.v[q].x, y.v[q].y, y.v[q].z, y.v[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t4[c] = fmaf(yv[e], a4[q][e][c], t4[c]);
+        }
+        group_sum_n<K::LPN>(t4);
+        if (sub == 0 && j < p.n_nodes) {
+            const float4 o = make_float4(d4.x + z4.x + t4[0] + sig * p04.x, d4.y + z4.y + t4[1] + sig * p04.y,
+                                         d4.z + z4.z + t4[2] + sig * p04.z, d4.w + z4.w + t4[3] + sig * p04.w);
+            *reinterpret_cast<float4*>(p.g_out + 4 * (size_t)j) = o;
+        }
+    };
+    const TileRange tr = tile_range(p.n_tiles);
+    const int tb = tr.t, stp = tr.step;
+    const int n_my = tr.t < tr.t_end ? (tr.t_end - tr.t + tr.step - 1) / tr.step : 0;
+    typename CsrT::Regs sr;
+    csr.load_metas(tb, stp, p.n_tiles, tid);
+    __syncthreads();
+    if (n_my > 0) csr.issue(sr, 0, tb * K::TM, p.n_nodes, tid);
+    for (int k = 0; k < n_my; ++k) {
+        const int t = tb + k * stp;
+        const int node0 = t * K::TM;
+        const int dmax = csr.commit(sr, tid, node0);
+        __syncthreads();
+        csr.issue(sr, k + 1, (t + stp) * K::TM, p.n_nodes, tid);   // unconditional, clamped past the end: lands during this tile
+        if (dmax >= 0) {
+            dispatch_dmax(dmax, [&](auto tag) {
+                constexpr int DM = decltype(tag)::value;
+                constexpr int HN = (DM + 1) / 2;
+                auto fetch = [&](SBuf4<HN, K::NV>& b, int step) __attribute__((always_inline)) {
+                    const int it = step >> 1, half = step & 1;
+                    const int li = it * K::SLOTS + slot;
+                    const int e0 = csr.rp[li] - csr.ebase + half * HN;
+                    const int deg = (node0 + li < p.n_nodes) ? csr.rp[li + 1] - csr.rp[li] : 0;
+#pragma unroll
+                    for (int kk = 0; kk < HN; ++kk) {
+                        const int i = csr.col[e0 + kk];              // past the row end: some valid row, weight 0
+                        b.ev[kk] = *reinterpret_cast<const float2*>(csr.aux + 2 * (e0 + kk));
+                        if (half * HN + kk >= deg) b.ev[kk] = make_float2(0.f, 0.f);
+                        b.g4[kk] = ld_g4(i);
+                        b.x[kk] = ld_vec<C>(p.x_in, i, sub);
+                    }
+                    b.d4 = *reinterpret_cast<const float4*>(p.dxd + 4 * (size_t)min(node0 + li, p.n_nodes - 1));
+                };
+                float4 z4; V y; float sig = 0.f;
+                auto consume = [&](const SBuf4<HN, K::NV>& b, int step) __attribute__((always_inline)) {
+                    const int it = step >> 1, half = step & 1;
+                    if (half == 0) { z4 = f4zero(); y.zero(); sig = 0.f; }
+#pragma unroll
+                    for (int kk = 0; kk < HN; ++kk) { axpy4(z4, b.ev[kk].x, b.g4[kk]); vaxpy(y, b.ev[kk].y, b.x[kk]); sig += b.ev[kk].y; }
+                    if (half == 1) finish(node0 + it * K::SLOTS + slot, b.d4, z4, y, sig);
+                };
+                run_pipeline<2 * K::ITERS, SBuf4<HN, K::NV>>(fetch, consume, [&]() {});
+            });
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < K::ITERS; ++it) {              // any row length, CSR straight from HBM
+                const int j = node0 + it * K::SLOTS + slot;
+                float4 z4 = f4zero(); V y; y.zero();
+                float sig = 0.f;
+                float4 d4 = f4zero();
+                if (j < p.n_nodes) {
+                    d4 = *reinterpret_cast<const float4*>(p.dxd + 4 * (size_t)j);
+                    const int e0 = p.rowptr[j], deg = p.rowptr[j + 1] - e0;
+                    for (int kk = 0; kk < deg; ++kk) {
+                        const int i = p.col[e0 + kk];
+                        const float2 ev = *reinterpret_cast<const float2*>(p.edge_ws + 2 * (size_t)(e0 + kk));
+                        axpy4(z4, ev.x, ld_g4(i));
+                        vaxpy(y, ev.y, ld_vec<C>(p.x_in, i, sub));
+                        sig += ev.y;
+                    }
+                }
+                finish(j, d4, z4, y, sig);
+            }
+        }
+        __syncthreads();                                        // every wave is done with the CSR slice of this tile
+    }
+}
+
 static inline int grid_for(int n_tiles, int max_blocks) {
     int g = (n_tiles + 7) & ~7;
     if (g > max_blocks) g = max_blocks;
@@ -3225,17 +3416,31 @@ extern "C" int gadapt_debug_set_fused_backward(int on) { g_fused_bwd.store(on ? 
 #ifndef GADAPT_BWD_D_MAX_BLOCKS
 #define GADAPT_BWD_D_MAX_BLOCKS 1024
 #endif
+#ifndef GADAPT_BWD_OUT4
+#define GADAPT_BWD_OUT4 1            /* 0: layer 1 above a compact layer 0 runs the dense pair (A/B) */
+#endif
+#ifndef GADAPT_XC_COMPACT_KERNEL
+#define GADAPT_XC_COMPACT_KERNEL 1      /* 0: the tiled target kernel with the XC staging for the compact layer input (A/B) */
+#endif
 template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha,
                                        const float* a, const float* p0, const float* lp, float* edge_ws, float* dxd, float* slab,
-                                       int accumulate, float* sums_out, float* g_out, int residual_only, int g_cols, int x_cols, hipStream_t st, float* sums_sc_out) {
+                                       int accumulate, float* sums_out, float* g_out, int residual_only, int g_cols, int x_cols, hipStream_t st, float* sums_sc_out,
+                                       int out4 = 0, int g_stride = 0) {
+    // out4: only columns 0..3 of g_out are wanted (dxd and g_out are [N,4]: D4 target pass + grand_bwd_source4_kernel).
+    // g_stride: row pitch of g_in in floats for the compact-input launch (0 = C).
     using K = Cfg<C>;
     const int n_tiles = (g->n_nodes + K::TM - 1) / K::TM;
     if (g_cols < 0 || g_cols > 4) return fail(GADAPT_E_BADARG, "compact upstream gradient: 1..4 columns");
     if ((x_cols != 0 && x_cols != 4) || (x_cols && (g_cols || g_out)))
         return fail(GADAPT_E_BADARG, "compact layer input: 4 columns, layer 0 of a block of >= 2 layers, no d x0");
+    if (x_cols && residual_only) return fail(GADAPT_E_BADARG, "compact layer input: Euler-step layers only");
     BwdTArgs pt{x_in, g_in, alpha, a, lp, g->rowptr_t, g->col_t, g->tpos_s, meta_for<K::TM>(g->meta_t), reinterpret_cast<float2*>(edge_ws), dxd, slab, sums_out,
                 g->n_nodes, n_tiles, accumulate, residual_only, g->n_edges, nullptr, g_cols};
     pt.sums_sc_out = sums_sc_out;
+    pt.c = C;
+    pt.g_stride = g_stride ? g_stride : C;
+    if (out4 && (!g_out || x_cols || residual_only || C < 8 || (g_cols && sums_out)))
+        return fail(GADAPT_E_BADARG, "4-column backward: a layer with a gradient to pass on, hidden >= 8, not compact-g with d dt / d scale");
 #ifdef GADAPT_STAMPS
     pt.stamps = g_stamp_buf ? g_stamp_buf + 1024 * 32 : nullptr;
 #endif
@@ -3244,7 +3449,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     if constexpr (C == 32 || C == 64) {
         // dense layer with a gradient to pass on: node pass for D + ONE fused kernel (gadapt_fused_bwd.inc) instead of the
         // target / source pair; D [N] lives at the start of the (otherwise unused) dxd workspace
-        if (fused_bwd_enabled() && !g_cols && !x_cols && !sums_out && g_out && g->rowptr_s && g->col_s && g->perm_s) {
+        if (fused_bwd_enabled() && !g_cols && !x_cols && !sums_out && !out4 && g_out && g->rowptr_s && g->col_s && g->perm_s) {
             {
                 BwdDArgs pd{x_in, g_in, alpha, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t), dxd, g->n_nodes, n_tiles, residual_only, g->n_edges};
                 ProfScope prof(5, st, 0);
@@ -3265,21 +3470,18 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     }
     // hidden 32 / 64 with a source pass to follow: the source pass accumulates dA / dp0 (see grand_bwd_source_kernel)
     constexpr bool CAN_MOVE_DA = (C == 32 || C == 64) && GADAPT_DA_IN_SOURCE;
-    const bool da_in_s = CAN_MOVE_DA && g_out && !sums_out && !x_cols;
-#ifndef GADAPT_XC_COMPACT_KERNEL
-#define GADAPT_XC_COMPACT_KERNEL 1      /* 0: the tiled target kernel with the XC staging for the compact layer input (A/B) */
-#endif
+    const bool da_in_s = CAN_MOVE_DA && g_out && !sums_out && !x_cols && !out4;
     if (GADAPT_XC_COMPACT_KERNEL && x_cols && !residual_only) {
         ProfScope prof(1, st, 2);
         // the slab holds one row per workgroup of the tiled target pass: same grid, so every row is visited
         const dim3 grid(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS)));
-        if (sums_out && sums_sc_out) hipLaunchKernelGGL((grand_bwd_target_compact_kernel<C, 2>), grid, dim3(256), 0, st, pt);
-        else if (sums_out) hipLaunchKernelGGL((grand_bwd_target_compact_kernel<C, 1>), grid, dim3(256), 0, st, pt);
-        else hipLaunchKernelGGL((grand_bwd_target_compact_kernel<C, 0>), grid, dim3(256), 0, st, pt);
+        if (sums_out && sums_sc_out) hipLaunchKernelGGL((grand_bwd_target_compact_kernel<2>), grid, dim3(256), 0, st, pt);
+        else if (sums_out) hipLaunchKernelGGL((grand_bwd_target_compact_kernel<1>), grid, dim3(256), 0, st, pt);
+        else hipLaunchKernelGGL((grand_bwd_target_compact_kernel<0>), grid, dim3(256), 0, st, pt);
         return check_launch("grand_bwd_target_compact_kernel");
     }
     {
-        ProfScope prof(1, st, (g_cols ? 1 : 0) | (x_cols ? 2 : 0));
+        ProfScope prof(1, st, (g_cols ? 1 : 0) | (x_cols ? 2 : 0) | (out4 ? 8 : 0));
         if constexpr (CAN_MOVE_DA) {
             if (da_in_s && g_cols) {
                 allow_lds(grand_bwd_target_kernel<C, false, true, false, false>, lds_t);
@@ -3290,23 +3492,27 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
             }
         }
         if (da_in_s) {
-        } else if (sums_out) {
-            // SUMS instantiations: 1 = d dt only (learn_step), 2 = d dt and d score_scale; each with the compact variants
-            auto go = [&](auto kern) { allow_lds(kern, lds_t); hipLaunchKernelGGL(kern, dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt); };
-            if (sums_sc_out) {
-                if (x_cols) go(grand_bwd_target_kernel<C, 2, false, true>); else if (g_cols) go(grand_bwd_target_kernel<C, 2, true>); else go(grand_bwd_target_kernel<C, 2>);
-            } else {
-                if (x_cols) go(grand_bwd_target_kernel<C, 1, false, true>); else if (g_cols) go(grand_bwd_target_kernel<C, 1, true>); else go(grand_bwd_target_kernel<C, 1>);
-            }
-        } else if (x_cols) {
-            allow_lds(grand_bwd_target_kernel<C, false, false, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
-        } else if (g_cols) {
-            allow_lds(grand_bwd_target_kernel<C, false, true>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, true>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
         } else {
-            allow_lds(grand_bwd_target_kernel<C, false>, lds_t);
-            hipLaunchKernelGGL((grand_bwd_target_kernel<C, false>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
+            // instantiations: SUMS 0 / 1 (d dt: learn_step) / 2 (d dt and d score_scale), each plain, with the compact upstream
+            // gradient (GC), with the compact layer input on the tiled kernel (XC: only when the compact-input kernel is compiled
+            // out) and - hidden >= 8 - with the 4-column dxd (D4)
+            auto go = [&](auto kern) { allow_lds(kern, lds_t); hipLaunchKernelGGL(kern, dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt); };
+            auto pick = [&](auto sums_tag) {
+                constexpr int S = decltype(sums_tag)::value;
+                if (x_cols) {
+                    if constexpr (!GADAPT_XC_COMPACT_KERNEL) go(grand_bwd_target_kernel<C, S, false, true>);
+                } else if (out4) {
+                    if constexpr (C >= 8) {
+                        if (!g_cols) go(grand_bwd_target_kernel<C, S, false, false, true, true>);
+                        else if constexpr (S == 0) go(grand_bwd_target_kernel<C, 0, true, false, true, true>);   // GC + D4 + SUMS: not built (gadapt_block_backward)
+                    }
+                } else if (g_cols) {
+                    go(grand_bwd_target_kernel<C, S, true>);
+                } else {
+                    go(grand_bwd_target_kernel<C, S>);
+                }
+            };
+            if (sums_out && sums_sc_out) pick(IntTag<2>{}); else if (sums_out) pick(IntTag<1>{}); else pick(IntTag<0>{});
         }
         rc = check_launch("grand_bwd_target_kernel");
     }
@@ -3316,7 +3522,21 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
 #ifdef GADAPT_STAMPS
     ps.stamps = g_stamp_buf ? g_stamp_buf + 2 * 1024 * 32 : nullptr;
 #endif
-    ProfScope prof(2, st, g_cols ? 1 : 0);
+    ProfScope prof(2, st, (g_cols ? 1 : 0) | (out4 ? 8 : 0));
+    if constexpr (C >= 8) {
+        if (out4) {
+            constexpr int lds_4 = K::lds_bytes(2, 0);
+            constexpr int res4 = (C > 64 || K::NT != 256) ? 512 : 256 * GADAPT_WAVES_BWD_S4;   // resident workgroups: waves per SIMD x 256 CUs
+            if (g_cols) {
+                allow_lds(grand_bwd_source4_kernel<C, true>, lds_4);
+                hipLaunchKernelGGL((grand_bwd_source4_kernel<C, true>), dim3(grid_for(n_tiles, res4)), dim3(K::NT), lds_4, st, ps);
+            } else {
+                allow_lds(grand_bwd_source4_kernel<C, false>, lds_4);
+                hipLaunchKernelGGL((grand_bwd_source4_kernel<C, false>), dim3(grid_for(n_tiles, res4)), dim3(K::NT), lds_4, st, ps);
+            }
+            return check_launch("grand_bwd_source4_kernel");
+        }
+    }
     if constexpr (CAN_MOVE_DA) {
         if (da_in_s) {
             // the grid EXPRESSION of the target pass (resident_blocks_bwd_t: what gadapt_backward_slab_rows sizes the slab with),
@@ -3622,8 +3842,10 @@ extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_
 
 static int layer_backward_cols(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha, const float* a,
                                const float* p0, const float* layer_params, float* edge_ws, float* dxd_ws, float* slab, int accumulate,
-                               float* sums_out, float* sums_sc_out, float* g_out, int g_cols, int x_cols, int c, hipStream_t st) {
-    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, 0, g_cols, x_cols, st, sums_sc_out));
+                               float* sums_out, float* sums_sc_out, float* g_out, int g_cols, int x_cols, int c, hipStream_t st,
+                               int out4, int g_stride) {
+    GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, 0, g_cols, x_cols, st, sums_sc_out,
+                                        out4, g_stride));
 }
 extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all, const float* g_top, int g_top_cols, int n_layers,
                                      const float* a, int64_t a_stride, const float* p0, int64_t p0_stride, const float* layer_params,
@@ -3648,9 +3870,17 @@ extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, 
         const hipStream_t st = static_cast<hipStream_t>(stream);
         const int g_cols = (l == n_layers - 1) ? g_top_cols : 0, x_cols = (l == 0) ? x0_cols : 0;
         if (!g->tpos_s || (g_next && (!g->rowptr_s || !g->col_s))) return fail(GADAPT_E_BADARG, "block_backward: source CSR missing");
-        // compact upstream gradient [N,g_top_cols] (top layer) / compact layer-0 input [N,4] (no d x0: checked in launch_bwd)
+        // compact upstream gradient [N,g_top_cols] (top layer) / compact layer-0 input [N,4] (no d x0: checked in launch_bwd).
+        // Layer 1 above a compact layer 0: that layer's backward contracts over the four live columns of its input, so all it
+        // reads of this layer's g_out are columns 0..3 - this layer runs the 4-column pair (dxd and g_out as [N,4]).
+        // (not for a two-layer block with learnable steps / temperature: layer 1 is then also the top layer, and the SUMS + GC + D4
+        // instantiation spills at hidden 32 - that corner keeps the dense pair)
+        const bool pair4 = GADAPT_BWD_OUT4 && x0_cols && c >= 8 && n_layers >= 2 && !(n_layers == 2 && g_top_cols > 0 && d_layer_params);
+        const int out4 = (pair4 && l == 1) ? 1 : 0;
+        const int g_stride = (pair4 && l == 0) ? 4 : 0;
         int rc = layer_backward_cols(g, x_all + l * nc, g_cur, alpha_all + (size_t)l * g->n_edges, a + l * a_stride, p0 + l * p0_stride,
-                                     layer_params + 2 * l, edge_ws, dxd_ws, slab_l, accumulate, d_dt, d_sc, g_next, g_cols, x_cols, c, st);
+                                     layer_params + 2 * l, edge_ws, dxd_ws, slab_l, accumulate, d_dt, d_sc, g_next, g_cols, x_cols, c, st,
+                                     out4, g_stride);
         if (rc) return rc;
         g_cur = g_next;
     }
