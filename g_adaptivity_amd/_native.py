@@ -43,7 +43,7 @@ PROTOTYPES = {
     'gadapt_encode_linear': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
     'gadapt_encode_features': (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _P]),
     'gadapt_encode_features_coeffs': (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _P]),
-    'gadapt_slab_reduce_coeffs_backward': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'gadapt_slab_reduce_coeffs_backward': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     'gadapt_spmm': (_I, [_G, _I, _P, _P, _P, _I, _F, _P]),
     'gadapt_sddmm': (_I, [_G, _I, _P, _P, _P, _I, _F, _P]),
     'gadapt_edge_softmax_forward': (_I, [_G, _P, _P, _P]),
@@ -59,6 +59,7 @@ PROTOTYPES = {
     'gadapt_slab_reduce': (_I, [_P, _I, _P, _P, _P, _I, _P]),
     'gadapt_block_forward': (_I, [_G, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _I, _P]),
     'gadapt_block_backward': (_I, [_G, _P, _I, _P, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
+    'gadapt_layer_params_reduce': (_I, [_P, _I, _I, _I, _P, _P]),
     'gadapt_mesh_loss_seed': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
     'gadapt_pad_columns': (_I, [_P, _P, _L, _I, _I, _P]),
     'gadapt_adam_step': (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),

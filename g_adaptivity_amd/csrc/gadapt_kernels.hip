@@ -1600,6 +1600,7 @@ struct BwdTArgs {
     float* sums_sc_out;                                         // d score_scale of this layer (one float); set with sums_out
     int c;                                                      // hidden size (read by grand_bwd_target_compact_kernel only)
     int g_stride;                                               // ... and the row pitch of its g_in, in floats
+    int sums_partials;                                          // 1: sums_out / sums_sc_out are per-workgroup arrays [gridDim.x] (written, not added to)
 };
 
 template <int NROWS, int NV> struct TBuf {
@@ -2219,7 +2220,9 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C >= GADAPT_ONE_WAVE_C ? 1 : GADAPT_WA
                 float v = 0.f;
                 for (int w_ = 0; w_ < K::NW; ++w_) v += red[2 * w_ + tid];
                 if (tid == 1) v = v / (sc * sc);                // d/d(score_scale) = sum d(score') <P,x> = (1/sc) sum d(score') log alpha; the terms carry one more sc
-                atomicAdd(tid == 0 ? p.sums_out : p.sums_sc_out, v);
+                float* dst = tid == 0 ? p.sums_out : p.sums_sc_out;
+                if (p.sums_partials) dst[blockIdx.x] = v;       // one slot per workgroup, summed in fixed order by layer_params_reduce_kernel
+                else atomicAdd(dst, v);
             }
         }
     }
@@ -2331,7 +2334,8 @@ __global__ __launch_bounds__(256) void grand_bwd_target_compact_kernel(BwdTArgs 
         if (p.sums_out && tid >= 20 && tid < (SUMS > 1 ? 22 : 21)) {
             float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
             if (tid == 21) v = v / (sc * sc);
-            atomicAdd(tid == 20 ? p.sums_out : p.sums_sc_out, v);
+            float* dst = tid == 20 ? p.sums_out : p.sums_sc_out;
+            if (p.sums_partials) dst[blockIdx.x] = v; else atomicAdd(dst, v);
         }
     }
 }
@@ -2920,7 +2924,43 @@ __global__ void pad_columns_kernel(const float* __restrict__ g_phys, float* __re
 }
 
 // slab [n_rows][row_len] -> part [CHUNKS][row_len]
-__global__ void slab_reduce1_kernel(const float* slab, float* part, int n_rows, int row_len) {
+// d dt_l / d score_scale_l: the per-workgroup partials of the SUMS target-pass launches (gadapt_block_backward) summed in a
+// fixed order - one workgroup per (kind, layer): four interleaved partial sums per thread, wave butterfly, the four waves in
+// order.  Replaces float atomics on one address per layer (512 of them per launch: +5 us on the compact-input launch) and
+// makes the step / temperature gradients bit-reproducible like everything else.
+__device__ __forceinline__ void layer_params_reduce_block(const float* __restrict__ partials, int n_rows, int n_layers, int want_scale,
+                                                          float* __restrict__ out, int slot /* kind * L + l */) {
+    __shared__ float red[4];
+    float v = 0.f;
+    if (slot < n_layers || want_scale) {
+        const float* src = partials + (size_t)slot * n_rows;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        for (int r = threadIdx.x; r < n_rows; r += 1024) {
+            v0 += src[r];
+            if (r + 256 < n_rows) v1 += src[r + 256];
+            if (r + 512 < n_rows) v2 += src[r + 512];
+            if (r + 768 < n_rows) v3 += src[r + 768];
+        }
+        v = (v0 + v1) + (v2 + v3);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[slot] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void layer_params_reduce_kernel(const float* __restrict__ partials, int n_rows, int n_layers, int want_scale,
+                                                                  float* __restrict__ out) {
+    layer_params_reduce_block(partials, n_rows, n_layers, want_scale, out, blockIdx.x);
+}
+// Workgroups past the row's column blocks (blockIdx.x >= nbx, first chunk row only) sum the d dt / d score_scale partials of the
+// same backward instead (lp_*: optional; see layer_params_reduce_block) - they ride in this launch rather than in one of their own.
+__global__ void slab_reduce1_kernel(const float* slab, float* part, int n_rows, int row_len, int nbx = 1 << 30,
+                                    const float* lp_partials = nullptr, int n_layers = 0, int want_scale = 0, float* lp_out = nullptr) {
+    if ((int)blockIdx.x >= nbx) {
+        if (blockIdx.y == 0 && lp_partials) layer_params_reduce_block(lp_partials, n_rows, n_layers, want_scale, lp_out, (int)blockIdx.x - nbx);
+        return;
+    }
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= row_len) return;
     const int per = (n_rows + GADAPT_SLAB_CHUNKS - 1) / GADAPT_SLAB_CHUNKS;
@@ -3425,7 +3465,7 @@ extern "C" int gadapt_debug_set_fused_backward(int on) { g_fused_bwd.store(on ? 
 template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha,
                                        const float* a, const float* p0, const float* lp, float* edge_ws, float* dxd, float* slab,
                                        int accumulate, float* sums_out, float* g_out, int residual_only, int g_cols, int x_cols, hipStream_t st, float* sums_sc_out,
-                                       int out4 = 0, int g_stride = 0) {
+                                       int out4 = 0, int g_stride = 0, int sums_partials = 0) {
     // out4: only columns 0..3 of g_out are wanted (dxd and g_out are [N,4]: D4 target pass + grand_bwd_source4_kernel).
     // g_stride: row pitch of g_in in floats for the compact-input launch (0 = C).
     using K = Cfg<C>;
@@ -3439,6 +3479,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     pt.sums_sc_out = sums_sc_out;
     pt.c = C;
     pt.g_stride = g_stride ? g_stride : C;
+    pt.sums_partials = sums_partials;
     if (out4 && (!g_out || x_cols || residual_only || C < 8 || (g_cols && sums_out)))
         return fail(GADAPT_E_BADARG, "4-column backward: a layer with a gradient to pass on, hidden >= 8, not compact-g with d dt / d scale");
 #ifdef GADAPT_STAMPS
@@ -3647,6 +3688,13 @@ extern "C" int gadapt_layer_backward(const gadapt_graph* g, const float* x_in, c
                                         sums_out ? sums_out + 1 : nullptr));   // {d dt, d score_scale} side by side
 }
 
+extern "C" int gadapt_layer_params_reduce(const float* partials, int n_rows, int n_layers, int want_d_scale, float* d_layer_params, void* stream) {
+    if (!partials || !d_layer_params || n_rows <= 0 || n_layers <= 0) return fail(GADAPT_E_BADARG, "layer_params_reduce: bad argument");
+    hipLaunchKernelGGL(layer_params_reduce_kernel, dim3(2 * n_layers), dim3(256), 0, static_cast<hipStream_t>(stream), partials, n_rows, n_layers,
+                       want_d_scale, d_layer_params);
+    return check_launch("layer_params_reduce_kernel");
+}
+
 extern "C" int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch, float* d_a, float* d_p0, int c, void* stream) {
     if (!slab || n_rows <= 0 || !scratch || !d_a || !d_p0 || !gadapt_supported_hidden_dim(c)) return fail(GADAPT_E_BADARG, "slab_reduce: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -3659,12 +3707,16 @@ extern "C" int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch,
 
 // slab -> d_wq | d_bq | d_wk | d_bk in two launches (first-level partial sums, then second level + chain rule together)
 extern "C" int gadapt_slab_reduce_coeffs_backward(const float* slab, int n_rows, float* scratch, const float* wq, const float* bq,
-                                                  const float* wk, float* d_wq, float* d_bq, float* d_wk, float* d_bk, int c, void* stream) {
+                                                  const float* wk, float* d_wq, float* d_bq, float* d_wk, float* d_bk, int c, void* stream,
+                                                  const float* lp_partials, int n_layers, int want_d_scale, float* d_layer_params) {
     if (!slab || n_rows <= 0 || !scratch || !wq || !bq || !wk || !d_wq || !d_bq || !d_wk || !d_bk || !gadapt_supported_hidden_dim(c))
         return fail(GADAPT_E_BADARG, "slab_reduce_coeffs_backward: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int row_len = c * c + c;
-    hipLaunchKernelGGL(slab_reduce1_kernel, dim3((row_len + 255) / 256, GADAPT_SLAB_CHUNKS), dim3(256), 0, st, slab, scratch, n_rows, row_len);
+    const int nbx = (row_len + 255) / 256;
+    if (lp_partials && (n_layers <= 0 || !d_layer_params)) return fail(GADAPT_E_BADARG, "slab_reduce_coeffs_backward: layer-parameter partials without a destination");
+    hipLaunchKernelGGL(slab_reduce1_kernel, dim3(nbx + (lp_partials ? 2 * n_layers : 0), GADAPT_SLAB_CHUNKS), dim3(256), 0, st, slab, scratch, n_rows, row_len,
+                       nbx, lp_partials, n_layers, want_d_scale, d_layer_params);
     const int lds = (c * (c + 1) + c) * 4;
     int blocks = (2 * c * c + 2 * c + 1023) / 1024;
     if (blocks > 33) blocks = 33;                               // every workgroup repeats the second-level sums
@@ -3845,7 +3897,7 @@ static int layer_backward_cols(const gadapt_graph* g, const float* x_in, const f
                                float* sums_out, float* sums_sc_out, float* g_out, int g_cols, int x_cols, int c, hipStream_t st,
                                int out4, int g_stride) {
     GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, 0, g_cols, x_cols, st, sums_sc_out,
-                                        out4, g_stride));
+                                        out4, g_stride, 1));
 }
 extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all, const float* g_top, int g_top_cols, int n_layers,
                                      const float* a, int64_t a_stride, const float* p0, int64_t p0_stride, const float* layer_params,
@@ -3860,13 +3912,15 @@ extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, 
     const bool shared = (a_stride == 0);
     const int64_t slab_floats = gadapt_backward_slab_floats(g->n_nodes, c);
     if (slab_floats < 0) return (int)slab_floats;
+    const int slab_rows = gadapt_backward_slab_rows(g->n_nodes, c);
     const float* g_cur = g_top;
     for (int l = n_layers - 1; l >= 0; --l) {
         float* g_next = (l == 0) ? d_x0 : g_ws + ((n_layers - 1 - l) & 1) * nc;
         float* slab_l = shared ? slab : slab + (size_t)l * slab_floats;
         const int accumulate = (shared && l != n_layers - 1) ? 1 : 0;
-        float* d_dt = d_layer_params ? d_layer_params + l : nullptr;                 // [2,L]: d dt row, then d score_scale row
-        float* d_sc = (d_layer_params && want_d_scale) ? d_layer_params + n_layers + l : nullptr;
+        // per-workgroup partials [2][L][G] (G = gadapt_backward_slab_rows: the grid of every target-pass launch), d dt block first
+        float* d_dt = d_layer_params ? d_layer_params + (size_t)l * slab_rows : nullptr;
+        float* d_sc = (d_layer_params && want_d_scale) ? d_layer_params + ((size_t)n_layers + l) * slab_rows : nullptr;
         const hipStream_t st = static_cast<hipStream_t>(stream);
         const int g_cols = (l == n_layers - 1) ? g_top_cols : 0, x_cols = (l == 0) ? x0_cols : 0;
         if (!g->tpos_s || (g_next && (!g->rowptr_s || !g->col_s))) return fail(GADAPT_E_BADARG, "block_backward: source CSR missing");

@@ -132,17 +132,17 @@ class _GrandEulerBlock(torch.autograd.Function):
         want_lp = ctx.needs_input_grad[5] or any(ctx.needs_input_grad[13:])
         # one flat tensor [dWq | dbq | dWk | dbk | d dt (L) | d scale (L)]: installed as the parameters' .grad without a copy, it
         # is the gradient bucket of optim.FlatAdam (one Adam launch, one all-reduce); the 2L tail only when a step / scale
-        # gradient is wanted (the kernels accumulate into it atomically: zeroed here)
+        # gradient is wanted (summed from per-workgroup partials by gadapt_layer_params_reduce)
         n_w = S * (2 * c * c + 2 * c)
         flat = torch.empty(n_w + (2 * L if want_lp else 0), device=dev, dtype=torch.float32)
-        d_lp = None
+        d_lp = d_ws = None
         if want_lp:
-            d_lp = flat[n_w:]
-            d_lp.zero_()
+            d_lp = flat[n_w:]                   # [2,L], written whole by gadapt_layer_params_reduce below
+            d_ws = torch.empty(2 * L * slab_rows, device=dev, dtype=torch.float32)   # one slot per (kind, layer, workgroup)
         d_x0 = torch.empty(n, c, device=dev, dtype=torch.float32) if need_x0 else None
         check(lib().gadapt_block_backward(graph.c_ref, ptr(x_all), ctx.x0_cols, ptr(alpha), ptr(g_top), g_cols, L,
                                           ptr(a), c * c if S > 1 else 0, ptr(p0), c if S > 1 else 0, ptr(layer_params),
-                                          ptr(g_ws), ptr(dxd_ws), ptr(edge_ws), ptr(slab), ptr(d_lp), int(bool(ctx.needs_input_grad[5])),
+                                          ptr(g_ws), ptr(dxd_ws), ptr(edge_ws), ptr(slab), ptr(d_ws), int(bool(ctx.needs_input_grad[5])),
                                           ptr(d_x0), c, st),
               'gadapt_block_backward')
         scratch = torch.empty(32 * (c * c + c), device=dev, dtype=torch.float32)
@@ -150,8 +150,11 @@ class _GrandEulerBlock(torch.autograd.Function):
         d_wq, d_wk = flat[cuts[0]:cuts[1]].view(S, c, c), flat[cuts[2]:cuts[3]].view(S, c, c)
         d_bq, d_bk = flat[cuts[1]:cuts[2]].view(S, c), flat[cuts[3]:cuts[4]].view(S, c)
         for s in range(S):                      # slab -> second-level sums + chain rule to the Linear parameters: 2 launches
+            lp_here = want_lp and s == 0       # the d dt / d scale partials are summed by extra workgroups of the first launch
             check(lib().gadapt_slab_reduce_coeffs_backward(ptr(slab[s]), slab_rows, ptr(scratch), ptr(wq[s]), ptr(bq[s]), ptr(wk[s]),
-                                                           ptr(d_wq[s]), ptr(d_bq[s]), ptr(d_wk[s]), ptr(d_bk[s]), c, st),
+                                                           ptr(d_wq[s]), ptr(d_bq[s]), ptr(d_wk[s]), ptr(d_bk[s]), c, st,
+                                                           ptr(d_ws) if lp_here else None, L, int(bool(ctx.needs_input_grad[5])),
+                                                           ptr(d_lp) if lp_here else None),
                   'gadapt_slab_reduce_coeffs_backward')
         if ctx.n_steps:                         # layer_params was the [L] scale vector; the steps get their slices of the d dt row
             d_scales = d_lp[L:] if ctx.needs_input_grad[5] else None

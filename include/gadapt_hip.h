@@ -173,7 +173,11 @@ int gadapt_slab_reduce(const float* slab, int n_rows, float* scratch, float* d_a
  * chain rule share a kernel (d_a / d_p0 only ever exist in LDS).  Same results bit for bit. */
 int gadapt_slab_reduce_coeffs_backward(const float* slab, int n_rows, float* scratch,
                                        const float* wq, const float* bq, const float* wk,
-                                       float* d_wq, float* d_bq, float* d_wk, float* d_bk, int c, void* stream);
+                                       float* d_wq, float* d_bq, float* d_wk, float* d_bk, int c, void* stream,
+                                       const float* lp_partials /*nullable*/, int n_layers, int want_d_scale,
+                                       float* d_layer_params /*nullable*/);
+/* lp_partials (nullable): the [2][L][n_rows] workspace gadapt_block_backward filled - the first launch then also does what
+ * gadapt_layer_params_reduce does (a few extra workgroups instead of a launch of its own). */
 
 /* ------------------------------------------------------------------ L-step Euler block
  * The loop of GNN.py:273-291 with weight sharing (GNN.py:131-141): x_all is
@@ -193,10 +197,10 @@ int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_cols, int n
  * (1..4 columns, zero beyond: the backward of x_phys = x[:, :dim], GNN.py:299, without materialising the padded
  * matrix).  x0_cols as in gadapt_block_forward (then d_x0 must be NULL).  g_ws: 2*N*C floats,
  * dxd_ws: N*C, edge_ws: 2*E, slab: n_slots*gadapt_backward_slab_floats(N,c) with
- * n_slots = 1 (shared weights) or L.  d_layer_params (nullable) [2,L] accumulates (atomically): row 0 = d dt_l (learn_step,
- * GNN.py:179-180,288-289), row 1 = d score_scale_l - two contiguous rows, so a caller can hand out the d dt row as the
- * gradients of L one-element step parameters laid side by side.  want_d_scale = 0: only row 0 is accumulated (learn_step with a
- * fixed temperature: the per-edge log terms of d score_scale are not computed).
+ * n_slots = 1 (shared weights) or L.  d_layer_params (nullable): WORKSPACE of 2 * L * gadapt_backward_slab_rows(N,c) floats -
+ * every target-pass workgroup writes its partial of d dt_l (learn_step, GNN.py:179-180,288-289) and, when want_d_scale != 0, of
+ * d score_scale_l into its own slot; gadapt_layer_params_reduce then sums them in a fixed order (no float atomics: the step and
+ * temperature gradients are bit-reproducible).  want_d_scale = 0: the per-edge log terms of d score_scale are not computed.
  * d_x0 (nullable) [N,C] receives dL/dx_all[0]. */
 int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all,
                           const float* g_top, int g_top_cols, int n_layers,
@@ -204,6 +208,10 @@ int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols
                           const float* layer_params,
                           float* g_ws, float* dxd_ws, float* edge_ws, float* slab,
                           float* d_layer_params, int want_d_scale, float* d_x0, int c, void* stream);
+/* partials: the workspace gadapt_block_backward filled ([2][L][n_rows], n_rows = gadapt_backward_slab_rows).  d_layer_params
+ * [2,L]: row 0 = d dt_l, row 1 = d score_scale_l (zeros when want_d_scale = 0) - two contiguous rows, so a caller can hand out
+ * the d dt row as the gradients of L one-element step parameters laid side by side. */
+int gadapt_layer_params_reduce(const float* partials, int n_rows, int n_layers, int want_d_scale, float* d_layer_params, void* stream);
 
 /* ------------------------------------------------------------------ generic message-passing primitives
  * What PyG's MessagePassing.propagate / utils.softmax do with index_select + scatter, per CSR row, for the conv variants

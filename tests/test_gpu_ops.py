@@ -319,6 +319,15 @@ def test_learn_step_gradients_ride_in_the_flat_tensor(gpu_device):
     assert ours.grad_bucket.numel() == 2 * (64 * 64 + 64) + 4
     g = next(iter(model._graphs.values()))
     assert model.opt['compact_slots'] and g.num_nodes == 3 * 256
+    # the step gradients are summed from per-workgroup partials in a fixed order (no float atomics): bit-reproducible
+    first = [model.steps[l].grad.clone() for l in range(4)]
+    ours.zero_grad()
+    mse_loss(model(dd), dd.x_phys).backward()
+    # (the Adam step in between moved the weights: compare against a third run from the same state instead)
+    second = [model.steps[l].grad.clone() for l in range(4)]
+    ours.zero_grad()
+    mse_loss(model(dd), dd.x_phys).backward()
+    assert all(torch.equal(a, model.steps[l].grad) for l, a in enumerate(second)) and not all(torch.equal(a, b) for a, b in zip(first, second))
 
 
 @pytest.mark.gpu

@@ -44,13 +44,13 @@ def test_bench_line_roofline_is_reproducible_from_profiles():
     # frac follows from the line's own raw duration and byte count ...
     assert rf['frac'] == pytest.approx(rf['alg_bytes_per_launch'] / (rf['avg_launch_us'] * 1e-6) / 8e12, rel=2e-3)
     assert rf['avg_launch_us'] >= rf['avg_launch_us_net_of_overhead']          # nothing subtracted from what prices frac
-    # ... the byte count from SURVEY.md 8(d) ...
+    # ... the byte count from SURVEY.md 8(d): 8 N C + 4 (E + N + 1) for a dense target-pass launch of the metric workload ...
     import bench
-    n, b = bench.WORKLOADS[wl]['n'], bench.WORKLOADS[wl]['batch']
-    n_nodes = n * n * b
-    assert rf['alg_bytes_per_launch'] in {bench.algorithmic_bytes(rf['kernel'], n_nodes, e, bench.WORKLOADS[wl]['hidden'],
-                                                                  {'dense': 0, 'compact_g': 1, 'compact_x': 2}[rf['variant']])
-                                          for e in (23564 * b,)} or n != 64
+    w = bench.WORKLOADS[wl]
+    assert rf['kernel'] == 'backward_target' and rf['variant'] == 'dense'
+    if wl == 'poisson2d_64x64_b32_L4_C64':
+        n_nodes, n_edges = 32 * 4096, 32 * 23564                              # n = 64 -> N = 4096, E = 23 564 per mesh
+        assert rf['alg_bytes_per_launch'] == bench.algorithmic_bytes('backward_target', n_nodes, n_edges, w['hidden'], 0) == 70649348
     # ... the committed rocprofv3 summary gives the same duration (the event pair adds its dispatch share: <= 12 % above, never below)
     prof = rf['profile']
     assert prof is not None, "no committed rocprofv3 kernel stats for the bench workload"

@@ -1,12 +1,29 @@
+#!/bin/bash
+# GPU box, repo root: the round's bench lines and the rocprofv3 kernel statistics of the same commands.
+#   bash tools/bench_all.sh <tag>      (after tools/profile_all.sh <tag>, which refreshes profiles/pmc.json on the box)
+# Order matters: bench.py under rocprofv3 runs FIRST and its kernel-stats csv is copied into profiles/ of this checkout, so the
+# plain bench runs that follow quote the duration of the committed summary beside their own (roofline.profile).
 set -o pipefail
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
-python bench.py --steps 200 --warmup 20 2>gpurun_out/bench_err.log | tail -1 > gpurun_out/r02_bench.json
+TAG=${1:-r03}
+OUT=gpurun_out
+DEF=poisson2d_64x64_b32_L4_C64
+for WL in $DEF poisson2d_32x32_b32_L4_C64 burgers2d_64x64_b32_L6_C128 euler20_128x128_b16_C64; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench_$WL -- python3 bench.py --workload $WL --steps 50 --warmup 10 --no-cpu-baseline \
+      > $OUT/${TAG}_bench_${WL}_under_rocprofv3.json 2> $OUT/prof_bench_$WL.log
+  f=$(find $OUT/prof_bench_$WL -name '*kernel_stats.csv' | head -1)
+  if [ -n "$f" ]; then cp "$f" profiles/${TAG}_bench_${WL}_rocprofv3_kernel_stats.csv; cp "$f" $OUT/${TAG}_bench_${WL}_rocprofv3_kernel_stats.csv; fi
+  echo "rocprof bench $WL done"
+done
+python bench.py --steps 200 --warmup 20 2>$OUT/bench_err.log | tail -1 > $OUT/${TAG}_bench.json
 echo "bench default done"
-for WL in poisson2d_32x32_b32_L4_C64 burgers2d_64x64_b32_L6_C128 euler20_128x128_b16_C64; do
-  python bench.py --workload $WL --steps 50 --warmup 10 2>>gpurun_out/bench_err.log | tail -1 > gpurun_out/r02_bench_$WL.json
+for WL in poisson2d_32x32_b32_L4_C64 burgers2d_64x64_b32_L6_C128 euler20_128x128_b16_C64 poisson2d_64x64_b32_L4_C64_learn_step poisson2d_64x64_b32_L4_C64_GAT_plus; do
+  python bench.py --workload $WL --steps 50 --warmup 10 2>>$OUT/bench_err.log | tail -1 > $OUT/${TAG}_bench_$WL.json
   echo "bench $WL done"
 done
-python bench.py --dense-slots --steps 100 --warmup 10 --no-cpu-baseline 2>>gpurun_out/bench_err.log | tail -1 > gpurun_out/r02_bench_dense_slots.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline > gpurun_out/r02_bench_under_rocprofv3.json 2>gpurun_out/prof_bench.log
-echo "rocprof bench done"
+python bench.py --dense-slots --steps 100 --warmup 10 --no-cpu-baseline 2>>$OUT/bench_err.log | tail -1 > $OUT/${TAG}_bench_dense_slots.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench_gat -- python3 bench.py --workload poisson2d_64x64_b32_L4_C64_GAT_plus --steps 20 --warmup 5 --no-cpu-baseline \
+    > $OUT/${TAG}_bench_GAT_plus_under_rocprofv3.json 2> $OUT/prof_bench_gat.log
+f=$(find $OUT/prof_bench_gat -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/${TAG}_bench_poisson2d_64x64_b32_L4_C64_GAT_plus_rocprofv3_kernel_stats.csv
+echo "all done"

@@ -24,19 +24,26 @@ N_SIMD, N_XCD = 1024, 8
 
 def name(n):
     if 'grand_fwd' in n or 'wide::fwd' in n: return 'forward'
-    if "bwd_target" in n: return "backward_target"
-    if 'bwd_source' in n: return 'backward_source'
+    if "bwd_target" in n: return "backward_target"          # grand_bwd_target_kernel<...>, grand_bwd_target_compact_kernel<SUMS>
+    if 'bwd_source' in n: return 'backward_source'          # grand_bwd_source_kernel<...>, grand_bwd_source4_kernel<C, GC>
     return None
 
 
 def variant(n):
+    """Variant names of bench.py (VARIANT_NAMES) from the template arguments in the kernel name; None = dense / not told apart."""
     try:
         a = n[n.index('<') + 1:n.index('>')].replace(' ', '').split(',')
     except ValueError:
         return None
-    if 'bwd_target' in n:
-        a += ['false'] * (4 - len(a))
-        return 'compact_x' if a[3] == 'true' else 'compact_g' if a[2] == 'true' else 'dense'
+    if 'bwd_target_compact' in n:
+        return 'compact_x'
+    if 'bwd_target' in n:                                   # <C, SUMS, GC, XC, DA, D4>
+        a += ['false'] * (6 - len(a))
+        if a[3] == 'true': return 'compact_x'
+        if a[5] == 'true': return 'compact_g+out4' if a[2] == 'true' else 'out4'
+        return 'compact_g' if a[2] == 'true' else 'dense'
+    if 'bwd_source4' in n:                                  # <C, GC>
+        return 'compact_g+out4' if len(a) > 1 and a[1] == 'true' else 'out4'
     if 'bwd_source' in n:
         return 'compact_g' if len(a) > 1 and a[1] == 'true' else 'dense'
     if 'wide::fwd' in n:
