@@ -3320,8 +3320,6 @@ __global__ __launch_bounds__(Cfg<C>::NT, (C > 64 ? 2 : GADAPT_WAVES_BWD_S4)) voi
     }
 }
 
-#include "gadapt_target3.inc"
-
 static inline int grid_for(int n_tiles, int max_blocks) {
     int g = (n_tiles + 7) & ~7;
     if (g > max_blocks) g = max_blocks;
@@ -3413,21 +3411,8 @@ template <int C> static constexpr int resident_blocks_bwd(int two_per_cu_default
 // ... and the target pass at hidden 32 (128-row tiles: ring + dP tile + slices = 87 KB of LDS) fits one workgroup per CU too
 // (hipOccupancyMaxActiveBlocksPerMultiprocessor: forward / target / source = 2 / 1 / 2 at hidden 32, 2 / 2 / 2 at 64,
 // 2 / 1 / 1 at 128, 3 / 3 / 3 at 8).
-template <int C> static constexpr int resident_blocks_bwd_t_tiled(int two_per_cu_default) {
+template <int C> static constexpr int resident_blocks_bwd_t(int two_per_cu_default) {
     return (C == 32 && GADAPT_BWD_ONE_PER_CU) ? 256 : resident_blocks_bwd<C>(two_per_cu_default);
-}
-// Hidden 64: the three-workgroups-per-CU target pass (gadapt_target3.inc) unless GADAPT_T3=0 in the environment (A/B runs and
-// the tests of the windowed kernel).  Its grid - 768 - is also the slab's row count, so the choice is made once per process.
-#ifndef GADAPT_T3
-#define GADAPT_T3 1
-#endif
-static bool target3_enabled() {
-    static const bool on = [] { const char* e = getenv("GADAPT_T3"); return GADAPT_T3 && !(e && e[0] == '0'); }();
-    return on;
-}
-template <int C> static int resident_blocks_bwd_t(int two_per_cu_default) {
-    if (C == 64 && target3_enabled()) return 768;
-    return resident_blocks_bwd_t_tiled<C>(two_per_cu_default);
 }
 
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
@@ -3547,22 +3532,7 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
                 hipLaunchKernelGGL((grand_bwd_target_kernel<C, false, false, false, false>), dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_t, st, pt);
             }
         }
-        bool t3_done = false;
-        if constexpr (C == 64) {
-            if (target3_enabled() && !x_cols && !da_in_s) {
-                constexpr int lds3 = target3_lds_bytes();
-                auto go3 = [&](auto kern) { allow_lds(kern, lds3); hipLaunchKernelGGL(kern, dim3(grid_for(n_tiles, 768)), dim3(256), lds3, st, pt); };
-                auto pick3 = [&](auto sums_tag) {
-                    constexpr int S = decltype(sums_tag)::value;
-                    if (out4) { if (!g_cols) go3(grand_bwd_target3_kernel<S, false, true>); else if constexpr (S == 0) go3(grand_bwd_target3_kernel<0, true, true>); }
-                    else if (g_cols) go3(grand_bwd_target3_kernel<S, true, false>);
-                    else go3(grand_bwd_target3_kernel<S, false, false>);
-                };
-                if (sums_out && sums_sc_out) pick3(IntTag<2>{}); else if (sums_out) pick3(IntTag<1>{}); else pick3(IntTag<0>{});
-                t3_done = true;
-            }
-        }
-        if (da_in_s || t3_done) {
+        if (da_in_s) {
         } else {
             // instantiations: SUMS 0 / 1 (d dt: learn_step) / 2 (d dt and d score_scale), each plain, with the compact upstream
             // gradient (GC), with the compact layer input on the tiled kernel (XC: only when the compact-input kernel is compiled
