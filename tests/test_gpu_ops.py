@@ -290,6 +290,52 @@ def test_encode_features_equals_concat_then_linear(gpu_device, with_f, with_uu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,L", [(64, 3), (64, 2), (16, 3), (128, 2), (8, 4)], ids=lambda v: str(v))
+@pytest.mark.parametrize("kind", ["random_long_rows", "ragged_mesh"])
+def test_compact_input_block_on_any_graph(gpu_device, C, L, kind):
+    """The block op with the compact [N,4] layer-0 input through the C-ABI on graphs the model never builds: rows with more than
+    8 in- and out-edges and isolated nodes (the loop paths of grand_bwd_target_compact_kernel and grand_bwd_source4_kernel, the
+    slow tiles of the D4 target pass), N not a multiple of any tile.  Against the same op on the zero-padded dense [N,C] input:
+    forward bit-identical, weight gradients to rounding; the top gradient is compact too (out_cols = 2)."""
+    if kind == "random_long_rows":
+        n = 1500
+        ei = _random_graph(n, 15 * n, 21)
+        ei = ei[:, ei[1] % 7 != 3]                                  # isolated targets
+    else:
+        from oracle.pyg_restatement import masked_edge_index
+        ds = MeshDataset([19, 19], 3, seed=2)
+        ei, n = masked_edge_index(collate(ds.samples), 2, 19), 3 * 361
+    graph = MeshGraph(ei, n, gpu_device)
+    gen = torch.Generator().manual_seed(5)
+    feats = torch.rand(n, 4, generator=gen).to(gpu_device)
+    wq, bq, wk, bk = [w.to(gpu_device).unsqueeze(0) for w in _random_layer(C, 31)]
+    lp = torch.tensor([[0.1, 1.0 / math.sqrt(C)]] * L, device=gpu_device)
+    tgt = torch.rand(n, 2, generator=gen).to(gpu_device)
+
+    def run(compact):
+        ps = [t.clone().requires_grad_(True) for t in (wq, bq, wk, bk)]
+        x_all = torch.zeros(L + 1, n, C, device=gpu_device)
+        if compact:
+            x0 = x_all[0].view(-1)[:4 * n].view(n, 4)
+            x0.copy_(feats)
+            out, _ = Fn.grand_euler_block(x0, *ps, lp, graph, L, x_all=x_all, out_cols=2, x0_cols=4)
+        else:
+            x_all[0][:, :4] = feats
+            out, _ = Fn.grand_euler_block(x_all[0], *ps, lp, graph, L, x_all=x_all, out_cols=2)
+        F.mse_loss(out, tgt).backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), [p_.grad.clone() for p_ in ps[:3]]
+
+    out_c, g_c = run(True)
+    out_d, g_d = run(False)
+    assert torch.equal(out_c, out_d)
+    for name, a, b in zip(('d lin_query.weight', 'd lin_query.bias', 'd lin_key.weight'), g_c, g_d):
+        assert rel_err(a, b)[0] <= 5e-6, (name, rel_err(a, b))
+    out_c2, g_c2 = run(True)                                        # bit-reproducible
+    assert torch.equal(out_c, out_c2) and all(torch.equal(a, b) for a, b in zip(g_c, g_c2))
+
+
+@pytest.mark.gpu
 def test_learn_step_gradients_ride_in_the_flat_tensor(gpu_device):
     """`learn_step` (GNN.py:179-180,288-289) with shared convs at hidden 64 - the shape of the metric workload: the step
     gradients come back as one-element slices of the tensor that carries the weight gradients ([dWq|dbq|dWk|dbk|d dt]), so
