@@ -31,26 +31,30 @@ class _AttentionDiffusionBase(nn.Module):
             if in_channels[0] != in_channels[1]:
                 raise NotImplementedError("bipartite in_channels are not used by the reference's get_conv")
             in_channels = in_channels[0]
-        if heads != 1:
-            raise NotImplementedError("heads != 1: get_conv always passes heads=1 (src/GNN.py:116-118)")
-        if root_weight or beta:
-            raise NotImplementedError("root_weight/beta: get_conv passes root_weight=False (src/GNN.py:118-119)")
         if edge_dim is not None:
-            raise NotImplementedError("edge_dim: get_conv passes edge_dim=None (src/GNN.py:119)")
-        if dropout:
-            raise NotImplementedError("attention dropout: get_conv passes dropout=0.0 (src/GNN.py:118)")
-        if in_channels != out_channels:
-            raise NotImplementedError("identity value map needs in_channels == out_channels (src/GRAND_plus.py:150)")
+            raise NotImplementedError("edge_dim: get_conv passes edge_dim=None (src/GNN.py:119); per-edge key / value terms "
+                                      "(src/GRAND_plus.py:271-277,338-340) are not built")
+        if in_channels != heads * out_channels:
+            # value = Identity(x).view(-1, H, C) (GRAND_plus.py:150,227): the view needs in_channels == H C
+            raise NotImplementedError(f"identity value map needs in_channels == heads * out_channels (src/GRAND_plus.py:150,227): "
+                                      f"{in_channels} != {heads} * {out_channels}")
+        if heads > 1 and not concat:
+            raise ValueError("heads > 1 with concat=False: the reference's `out - x` (src/GRAND_plus.py:267) subtracts [N, H C] from "
+                             "[N, C] - a shape error there too")
         self.opt = opt
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
-        self.concat, self.beta, self.root_weight = concat, False, False
-        self.dropout, self.edge_dim = 0.0, None
+        self.root_weight = bool(root_weight)
+        self.concat, self.beta = concat, bool(beta and root_weight)        # GRAND_plus.py:137
+        self.dropout, self.edge_dim = float(dropout), None
         self.lin_key = nn.Linear(in_channels, heads * out_channels)        # GRAND_plus.py:146
         self.lin_query = nn.Linear(in_channels, heads * out_channels)      # GRAND_plus.py:147
         self.lin_value = nn.Identity()                                     # GRAND_plus.py:150
-        self.lin_skip = nn.Linear(in_channels, out_channels, bias=skip_bias)   # allocated, unused (GRAND_plus.py:178)
+        skip_out = heads * out_channels if concat else out_channels        # GRAND_plus.py:168-181
+        self.lin_skip = nn.Linear(in_channels, skip_out, bias=skip_bias)   # used only with root_weight (GRAND_plus.py:244-250)
         self.lin_edge = None
-        self.lin_beta = None
+        self.lin_beta = nn.Linear(3 * skip_out, 1, bias=False) if self.beta else None
+        # the fused kernels carry what get_conv builds: one head, no root term, no attention dropout
+        self._general = heads > 1 or self.root_weight or self.dropout > 0.0
         self._alpha = None
         self._stored = None            # (graph, alpha in target-CSR order) of the last call
         self.stored_ei = None
@@ -63,6 +67,8 @@ class _AttentionDiffusionBase(nn.Module):
         if self._stored is None:
             return None
         graph, alpha_t = self._stored
+        if alpha_t.dim() == 2:                                             # [H, E] of the general path -> [E, H]
+            return graph.alpha_to_edge_order(alpha_t[:, :graph.num_edges]).t().contiguous()
         return graph.alpha_to_edge_order(alpha_t[:graph.num_edges]).unsqueeze(-1)
 
     @stored_alpha.setter
@@ -73,6 +79,8 @@ class _AttentionDiffusionBase(nn.Module):
         self.lin_key.reset_parameters()
         self.lin_query.reset_parameters()
         self.lin_skip.reset_parameters()
+        if self.lin_beta is not None:
+            self.lin_beta.reset_parameters()
 
     def _temperature(self):
         return None
@@ -88,6 +96,8 @@ class _AttentionDiffusionBase(nn.Module):
         primitives (Q/K projections as dense GEMMs, sddmm -> edge softmax -> spmm in HIP)."""
         if graph is None:
             graph = graph_for(edge_index, x.shape[0], x.device)
+        if self._general:
+            return self._residual_general(x, graph, edge_weight)
         if edge_weight is None and x.shape[1] in SUPPORTED_HIDDEN:
             res, alpha_t = Fn.grand_residual(x, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
                                              self.lin_key.bias, self._scale(x.device), graph, want_alpha)
@@ -96,6 +106,44 @@ class _AttentionDiffusionBase(nn.Module):
         k = torch.nn.functional.linear(x, self.lin_key.weight, self.lin_key.bias)          # GRAND_plus.py:226
         m, alpha_t = Sp.attention_aggregate(graph, q, k, x, self._scale(x.device), edge_weight)
         return m - x, alpha_t, graph
+
+    def _head_temperature(self, h: int):
+        t = self._temperature()
+        if torch.is_tensor(t) and t.numel() > 1:
+            return t.reshape(-1)[h]
+        return t
+
+    def _residual_general(self, x, graph: MeshGraph, edge_weight: Optional[torch.Tensor]):
+        """The constructor options get_conv never passes (`src/GRAND_plus.py:114-183,239-250,336`): H heads over slices of x
+        (value = Identity(x).view(-1, H, C)), concatenation of the heads, `root_weight` / `beta`, attention dropout.  Per head the
+        generic primitives (sddmm -> edge softmax -> spmm in HIP); projections, skip and gate are dense torch GEMMs."""
+        n, hd, c = x.shape[0], self.heads, self.out_channels
+        q = torch.nn.functional.linear(x, self.lin_query.weight, self.lin_query.bias).view(n, hd, c)    # GRAND_plus.py:225
+        k = torch.nn.functional.linear(x, self.lin_key.weight, self.lin_key.bias).view(n, hd, c)        # :226
+        v = x.view(n, hd, c)                                                                            # :227
+        outs, alphas = [], []
+        for h in range(hd):
+            scale = 1.0 / math.sqrt(c)
+            t = self._head_temperature(h)
+            s_ = Sp.sddmm(graph, q[:, h].contiguous(), k[:, h].contiguous()) * scale                    # :279
+            if edge_weight is not None:
+                s_ = s_ * edge_weight                                                                   # :324
+            if t is not None:
+                s_ = s_ / t                                                                             # :326-329
+            a = Sp.edge_softmax(graph, s_)                                                              # :333
+            alphas.append(a)
+            a = torch.nn.functional.dropout(a, p=self.dropout, training=self.training)                  # :336
+            outs.append(Sp.spmm(graph, a, v[:, h].contiguous()))                                        # :338-343, aggr='add'
+        out = torch.cat(outs, dim=1) if self.concat else outs[0]                                        # :239-242 (mean over ONE head)
+        if self.root_weight:                                                                            # :244-250
+            x_r = self.lin_skip(x)
+            if self.lin_beta is not None:
+                beta = self.lin_beta(torch.cat([out, x_r, out - x_r], dim=-1)).sigmoid()
+                out = beta * x_r + (1 - beta) * out
+            else:
+                out = out + x_r
+        alpha_t = alphas[0] if hd == 1 else torch.stack(alphas)
+        return out - x, alpha_t, graph                                                                  # :267
 
     def __repr__(self):
         return f'{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})'
@@ -127,7 +175,7 @@ class GRAND_plusConv(_AttentionDiffusionBase):
         if t == 'fixed':
             return float(self.opt['softmax_temp'])                         # GRAND_plus.py:326-327
         if t == 'learnable_a':
-            return self.sm_temp_a.reshape(())                              # GRAND_plus.py:328-329
+            return self.sm_temp_a.reshape(()) if self.heads == 1 else self.sm_temp_a     # GRAND_plus.py:328-329 ([1,H,1]: one per head)
         return None
 
     def forward(self, x, edge_index, global_features=None, mesh=None, edge_attr=None,
@@ -151,10 +199,11 @@ class GRAND_plusConv(_AttentionDiffusionBase):
         if store:
             self.stored_ei, self._stored = edge_index, (graph, alpha_t)
         if isinstance(return_attention_weights, bool):                     # GRAND_plus.py:259-262
-            alpha = graph.alpha_to_edge_order(alpha_t[:graph.num_edges]).unsqueeze(-1)
+            alpha = (graph.alpha_to_edge_order(alpha_t[:, :graph.num_edges]).t().contiguous() if alpha_t.dim() == 2
+                     else graph.alpha_to_edge_order(alpha_t[:graph.num_edges]).unsqueeze(-1))
             c = self.out_channels
-            query = torch.nn.functional.linear(x, self.lin_query.weight, self.lin_query.bias).view(-1, 1, c)
-            key = torch.nn.functional.linear(x, self.lin_key.weight, self.lin_key.bias).view(-1, 1, c)
+            query = torch.nn.functional.linear(x, self.lin_query.weight, self.lin_query.bias).view(-1, self.heads, c)
+            key = torch.nn.functional.linear(x, self.lin_key.weight, self.lin_key.bias).view(-1, self.heads, c)
             return res, (edge_index, (alpha, query, key))
         return res
 

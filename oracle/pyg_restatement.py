@@ -91,6 +91,44 @@ def grand_residual(x, edge_index, w_query, b_query, w_key, b_key,
     return res
 
 
+def grand_plus_general(x, edge_index, w_query, b_query, w_key, b_key, heads: int = 1, concat: bool = True,
+                       w_skip=None, b_skip=None, w_beta=None, temperature=None, dropout_mask=None,
+                       return_attention: bool = False):
+    """`GRAND_plusConv.forward` with the constructor options `get_conv` never passes (`src/GRAND_plus.py:114-183,204-267,
+    269-343`): H heads (value = Identity(x).view(-1, H, C): needs in_channels = H C), concat / mean over the heads,
+    `root_weight` (`w_skip`, `b_skip` given: `lin_skip`), `beta` (`w_beta` given: `lin_beta`), attention dropout as an explicit
+    per-edge, per-head mask of 0 / 1/(1-p) factors (`dropout_mask [E,H]`: what F.dropout multiplies with, :336).
+    `temperature`: scalar or [1,H,1] (`sm_temp_a`).  Returns out - x (:267)."""
+    n = x.shape[0]
+    c = w_query.shape[0] // heads
+    src, dst = edge_index[0], edge_index[1]
+    query = F.linear(x, w_query, b_query).view(-1, heads, c)     # :225
+    key = F.linear(x, w_key, b_key).view(-1, heads, c)           # :226
+    value = x.view(-1, heads, c)                                 # :150,:227
+    alpha = (query.index_select(0, dst) * key.index_select(0, src)).sum(dim=-1) / math.sqrt(c)     # [E,H] :279
+    if temperature is not None:
+        t = temperature if not torch.is_tensor(temperature) else (temperature.squeeze(2) if temperature.dim() == 3 else temperature)
+        alpha = alpha / t                                        # :35-37,:326-329 (sm_temp_a.squeeze(2): [1,H])
+    alpha = pyg_softmax(alpha, dst, n)                           # :333
+    kept = alpha
+    if dropout_mask is not None:
+        alpha = alpha * dropout_mask                             # :336
+    msg = value.index_select(0, src) * alpha.view(-1, heads, 1)  # :342
+    out = torch.zeros(n, heads, c, dtype=x.dtype, device=x.device).index_add_(0, dst, msg)
+    out = out.view(-1, heads * c) if concat else out.mean(dim=1) # :239-242
+    if w_skip is not None:                                       # root_weight :244-250
+        x_r = F.linear(x, w_skip, b_skip)
+        if w_beta is not None:
+            beta = F.linear(torch.cat([out, x_r, out - x_r], dim=-1), w_beta).sigmoid()
+            out = beta * x_r + (1 - beta) * out
+        else:
+            out = out + x_r
+    res = out - x                                                # :267
+    if return_attention:
+        return res, (kept, query, key)
+    return res
+
+
 def transformer_conv(x, edge_index, w_query, b_query, w_key, b_key, w_value, b_value, w_skip, b_skip):
     """PyG 2.4.0 `TransformerConv(in, out, heads=1)` with its defaults (concat=True, beta=False, dropout=0, edge_dim=None,
     bias=True, root_weight=True) - what `get_conv(opt, 'TRANS', ...)` builds (`src/GNN.py:112-113`); same op sequence as

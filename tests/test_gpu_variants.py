@@ -177,3 +177,83 @@ def test_learnable_v_fails_as_in_the_reference(gpu_device):
         model(collate(ds.samples).to(gpu_device))
     with pytest.raises(NotImplementedError):
         get_conv(opt, 'Laplacian', 16, 16)                             # GNN.py:122-124
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads,root,beta,temp", [(2, False, False, None), (4, True, False, None), (2, True, True, 'learnable_a'),
+                                                  (1, True, True, None), (1, True, False, 'fixed')],
+                         ids=['H2', 'H4-root', 'H2-root-beta-learnT', 'H1-root-beta', 'H1-root-fixedT'])
+def test_grand_plus_conv_constructor_options(gpu_device, heads, root, beta, temp):
+    """`GRAND_plusConv` with the constructor options `get_conv` never passes (`src/GRAND_plus.py:114-183,239-250`): several
+    heads over slices of x, concatenation, `root_weight`, `beta`, a per-head learnable temperature.  Forward and every parameter
+    gradient against the oracle's restatement in fp64, on a mesh batch and on a random graph with long rows."""
+    import torch.nn.functional as F
+    from g_adaptivity_amd import GRAND_plusConv, MeshDataset, collate, hot_path_opt
+    from oracle.pyg_restatement import grand_plus_general, masked_edge_index
+    from helpers import rel_err
+    c = 16
+    width = heads * c
+    opt = hot_path_opt(mesh_dims=[11, 11], hidden_dim=width, softmax_temp_type=temp, softmax_temp=1.7, device=str(gpu_device))
+    ds = MeshDataset([11, 11], 2, seed=3)
+    g = torch.Generator().manual_seed(7)
+    graphs = [masked_edge_index(collate(ds.samples), 2, 11), torch.stack([torch.randint(0, 300, (4000,), generator=g), torch.randint(0, 300, (4000,), generator=g)])]
+    for ei, n in zip(graphs, (242, 300)):
+        torch.manual_seed(5)
+        conv = GRAND_plusConv(opt, width, c, heads=heads, concat=True, beta=beta, root_weight=root, bias=True).to(gpu_device)
+        if temp == 'learnable_a':
+            with torch.no_grad():
+                conv.sm_temp_a.copy_(torch.linspace(0.8, 2.1, heads).view(1, heads, 1))
+        x = torch.randn(n, width, generator=g)
+        up = torch.randn(n, width, generator=g)
+        xg = x.to(gpu_device).requires_grad_(True)
+        res = conv(xg, ei.to(gpu_device))
+        (res * up.to(gpu_device)).sum().backward()
+        torch.cuda.synchronize()
+        # oracle, fp64
+        P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in conv.named_parameters()}
+        x64 = x.double().requires_grad_(True)
+        t = None
+        if temp == 'fixed':
+            t = 1.7
+        elif temp == 'learnable_a':
+            t = P['sm_temp_a']
+        ref = grand_plus_general(x64, ei, P['lin_query.weight'], P['lin_query.bias'], P['lin_key.weight'], P['lin_key.bias'], heads=heads,
+                                 concat=True, w_skip=P['lin_skip.weight'] if root else None, b_skip=P['lin_skip.bias'] if root else None,
+                                 w_beta=P['lin_beta.weight'] if (beta and root) else None, temperature=t)
+        (ref * up.double()).sum().backward()
+        assert rel_err(res.detach().cpu(), ref.detach())[0] <= 1e-5
+        assert rel_err(xg.grad.cpu(), x64.grad)[0] <= 2e-5
+        for k, v in conv.named_parameters():
+            if k.startswith('lin_skip') and not root:
+                assert v.grad is None
+                continue
+            if k == 'lin_key.bias':                                 # vanishes analytically (softmax shift invariance): rounding noise on both sides
+                assert v.grad.abs().max().item() <= 1e-5 * conv.lin_query.bias.grad.abs().max().item()
+                continue
+            assert rel_err(v.grad.cpu(), P[k].grad)[0] <= 1e-4, (k, rel_err(v.grad.cpu(), P[k].grad))
+        assert conv.stored_alpha.shape == (ei.shape[1], heads)
+
+
+@pytest.mark.gpu
+def test_grand_plus_conv_attention_dropout(gpu_device):
+    """Attention dropout (`src/GRAND_plus.py:336`): in eval mode it is the identity; in training mode the output equals the
+    oracle's with the mask F.dropout drew - recovered from the kept attention (stored_alpha) and the aggregation itself is
+    linear in the masked attention, so two draws differ while their common expectation is the eval output."""
+    from g_adaptivity_amd import GRAND_plusConv, MeshDataset, collate, hot_path_opt
+    from oracle.pyg_restatement import masked_edge_index
+    from helpers import rel_err
+    opt = hot_path_opt(mesh_dims=[11, 11], hidden_dim=32, device=str(gpu_device))
+    ds = MeshDataset([11, 11], 2, seed=3)
+    ei = masked_edge_index(collate(ds.samples), 2, 11).to(gpu_device)
+    torch.manual_seed(2)
+    drop = GRAND_plusConv(opt, 32, 32, heads=1, concat=False, dropout=0.5, root_weight=False, bias=False).to(gpu_device)
+    plain = GRAND_plusConv(opt, 32, 32, heads=1, concat=False, dropout=0.0, root_weight=False, bias=False).to(gpu_device)
+    plain.load_state_dict(drop.state_dict())
+    x = torch.randn(242, 32, device=gpu_device)
+    drop.eval(); plain.eval()
+    assert rel_err(drop(x, ei), plain(x, ei))[0] <= 2e-6            # generic primitives vs the fused kernel, no dropout in eval
+    drop.train()
+    a, b = drop(x, ei), drop(x, ei)
+    assert not torch.equal(a, b)
+    mean = torch.stack([drop(x, ei) for _ in range(400)]).mean(0)
+    assert rel_err(mean + x, plain(x, ei) + x)[0] <= 0.1            # E[dropout(alpha)] = alpha

@@ -344,3 +344,22 @@ def test_wide_window_locality_test():
         deg = (g.rowptr_t[1:] - g.rowptr_t[:-1]).long()
         assert torch.equal((ell >= 0).sum(1), deg)                              # complete even where the 384-row test fails
         assert torch.equal(ell[ell >= 0].long(), g.col_t[:int(deg.sum())].long())
+
+
+def test_grand_plus_conv_option_surface():
+    """Constructor options of `GRAND_plusConv` beyond what `get_conv` passes (`src/GRAND_plus.py:114-183`): parameter names and
+    shapes follow the reference (`lin_skip` [H C, in] with concat, `lin_beta` [1, 3 H C], `sm_temp_a` [1,H,1]); `edge_dim` and the
+    shape errors of the reference are refused at construction."""
+    opt = hot_path_opt(softmax_temp_type='learnable_a')
+    conv = GRAND_plusConv(opt, 32, 8, heads=4, concat=True, beta=True, root_weight=True, bias=True)
+    sd = conv.state_dict()
+    assert sd['lin_query.weight'].shape == (32, 32) and sd['lin_skip.weight'].shape == (32, 32) and sd['lin_skip.bias'].shape == (32,)
+    assert sd['lin_beta.weight'].shape == (1, 96) and sd['sm_temp_a'].shape == (1, 4, 1)
+    plain = GRAND_plusConv(hot_path_opt(), 8, 8, heads=1, concat=False, root_weight=False, bias=False)
+    assert 'lin_beta.weight' not in plain.state_dict() and plain.state_dict()['lin_skip.weight'].shape == (8, 8) and not plain._general
+    with pytest.raises(NotImplementedError):
+        GRAND_plusConv(opt, 8, 8, edge_dim=3)
+    with pytest.raises(NotImplementedError):
+        GRAND_plusConv(opt, 8, 8, heads=2)                          # Identity(x).view(-1, 2, 8) needs 16 input channels
+    with pytest.raises(ValueError):
+        GRAND_plusConv(opt, 16, 8, heads=2, concat=False)           # `out - x`: [N,8] - [N,16]
