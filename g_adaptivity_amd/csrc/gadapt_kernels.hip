@@ -3389,10 +3389,15 @@ static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_ou
 #endif
     ProfScope prof(0, st, (x_cols ? 2 : 0) | (x_out ? 0 : 4));
     auto go = [&](auto kern, int lds) { allow_lds(kern, lds); hipLaunchKernelGGL(kern, dim3(wide_grid(n_steps)), dim3(512), lds, st, p); };
+    const bool head = !x_out && !x_cols;                        // head-only output: its own instantiation (aggregates one chunk)
     if (big) {
-        if (x_cols) go(wide::fwd_kernel<true, true>, wide::fwd_lds_bytes<true>()); else go(wide::fwd_kernel<false, true>, wide::fwd_lds_bytes<true>());
+        if (x_cols) go(wide::fwd_kernel<true, true>, wide::fwd_lds_bytes<true>());
+        else if (head) go(wide::fwd_kernel<false, true, true>, wide::fwd_lds_bytes<true>());
+        else go(wide::fwd_kernel<false, true>, wide::fwd_lds_bytes<true>());
     } else {
-        if (x_cols) go(wide::fwd_kernel<true, false>, wide::fwd_lds_bytes<false>()); else go(wide::fwd_kernel<false, false>, wide::fwd_lds_bytes<false>());
+        if (x_cols) go(wide::fwd_kernel<true, false>, wide::fwd_lds_bytes<false>());
+        else if (head) go(wide::fwd_kernel<false, false, true>, wide::fwd_lds_bytes<false>());
+        else go(wide::fwd_kernel<false, false>, wide::fwd_lds_bytes<false>());
     }
     return check_launch("wide::fwd_kernel");
 }

@@ -46,8 +46,9 @@ def variant(n):
         return 'compact_g+out4' if len(a) > 1 and a[1] == 'true' else 'out4'
     if 'bwd_source' in n:
         return 'compact_g' if len(a) > 1 and a[1] == 'true' else 'dense'
-    if 'wide::fwd' in n:
-        return 'compact_x' if a[0] == 'true' else None            # head-only output is a runtime argument: not in the name
+    if 'wide::fwd' in n:                                    # <XC, BIG, HEAD>
+        a += ['false'] * (3 - len(a))
+        return 'compact_x' if a[0] == 'true' else 'head_only_out' if a[2] == 'true' else None
     return None
 
 
