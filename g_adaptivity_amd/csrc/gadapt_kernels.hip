@@ -13,6 +13,12 @@
 // (fp32 accuracy, C >= 32) and on the VALU for C < 32.  Hidden 64 on row-major mesh batches runs the wide forward
 // kernel of gadapt_wide.inc instead of grand_fwd_kernel.
 //
+// Round 3 added the kernels of the two bottom backward layers behind the identity (zero-pad) encoder:
+//   grand_bwd_target_compact_kernel  layer 0 on the compact [N,4] input: the 4 x 4 corner of dA, one node per lane
+//   grand_bwd_target_kernel<..,D4>   the layer above it: dxd as [N,4], dP A[:, :4] on the vector ALU, no projection phase
+//   grand_bwd_source4_kernel         ... and its source pass: g_out as [N,4], three waves per SIMD
+// and the per-workgroup partial sums of d dt / d score_scale (layer_params_reduce_block: no float atomics).
+//
 // Arithmetic follows /root/reference/src/GRAND_plus.py:225-343 and src/GNN.py:273-291 in the
 // (A, p0) formulation described in include/gadapt_hip.h.
 
