@@ -55,6 +55,7 @@ CASES = [
     # The other BASELINE configs at their FULL sizes (the fp64 oracle takes 8 / 16 / 56 s on the GPU box's host cores): config 3's
     # per-GPU shard = the metric workload, config 4, config 5
     ((64, 64), 32, 64, 4, 'GRAND_plus', {}),
+    ((64, 64), 32, 64, 4, 'GRAND_plus', {'learn_step': True}),       # the metric workload with learnable steps: SUMS kernels at full size
     ((64, 64), 32, 128, 6, 'GRAND', {'gnn_inc_feat_f': False, 'noise_factor': 3.0}),
     ((128, 128), 16, 64, 20, 'GRAND_plus', {}),
 ]
