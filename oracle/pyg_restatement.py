@@ -294,11 +294,15 @@ class _QKVS(nn.Module):
 class _QK(nn.Module):
     """Parameter holder with the reference's state_dict names (`src/GRAND_plus.py:146-147,178`)."""
 
-    def __init__(self, c: int):
+    def __init__(self, c: int, learnable_a: bool = False):
         super().__init__()
         self.lin_key = nn.Linear(c, c)
         self.lin_query = nn.Linear(c, c)
         self.lin_skip = nn.Linear(c, c, bias=False)           # allocated, never used (root_weight=False)
+        if learnable_a:
+            # `src/GRAND_plus.py:152-154`: Parameter(torch.Tensor(1, heads, 1)), never initialised there; ones is the defined
+            # start value used on both sides of the parity tests (they load this state_dict into the HIP model)
+            self.sm_temp_a = nn.Parameter(torch.ones(1, 1, 1))
 
 
 def _glorot_(t: torch.Tensor) -> torch.Tensor:
@@ -389,18 +393,23 @@ class OracleGNN(nn.Module):
         self.enc = nn.Linear(in_dim, c, bias=False)
         self.enc.weight.data = identity_encoder_weight(in_dim, c)
         self.enc.weight.requires_grad = False
+        make = _QK_
+        if opt.get('softmax_temp_type') == 'learnable_a' and opt['conv_type'] == 'GRAND_plus':     # GRAND_plus.py:152-154
+            make = lambda c_: _QK(c_, learnable_a=True)                                           # noqa: E731
         if opt['share_conv']:
-            shared = _QK_(c)
+            shared = make(c)
             self.conv_layers = nn.ModuleList([shared for _ in range(opt['num_layers'])])     # :131-141
         else:
-            self.conv_layers = nn.ModuleList([_QK_(c) for _ in range(opt['num_layers'])])
+            self.conv_layers = nn.ModuleList([make(c) for _ in range(opt['num_layers'])])
         if opt.get('learn_step'):
             self.steps = nn.ParameterList([nn.Parameter(torch.tensor([opt['time_step']]))
                                            for _ in range(opt['num_layers'])])              # :179-180
         self.end_MLmodel = None
 
-    def temperature(self):
+    def temperature(self, layer=None):
         t = self.opt.get('softmax_temp_type')
+        if t == 'learnable_a' and layer is not None and hasattr(layer, 'sm_temp_a'):
+            return layer.sm_temp_a.squeeze(2)                                              # GRAND_plus.py:328-329: [1,H]
         return self.opt['softmax_temp'] if t == 'fixed' else None
 
     def forward(self, data, return_all: bool = False):
@@ -440,7 +449,7 @@ class OracleGNN(nn.Module):
                     area = triangle_edge_area_sum(x, self.dataset.mesh.coordinates.cell_node_map().values, edge_index)
                 res, (alpha, _, _) = grand_residual(x, edge_index, layer.lin_query.weight, layer.lin_query.bias,
                                                     layer.lin_key.weight, layer.lin_key.bias,
-                                                    self.temperature(), return_attention=True, edge_area_sum=area)
+                                                    self.temperature(layer), return_attention=True, edge_area_sum=area)
             if not (opt['residual'] and opt['conv_type'] == 'GRAND_plus'):
                 res = F.dropout(res, opt.get('dropout', 0.0), training=self.training)      # :285 / :295
                 res = _NONLIN[opt['non_lin']](res)                                         # :286 / :296

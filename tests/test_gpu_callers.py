@@ -98,6 +98,7 @@ def test_graph_cache_is_keyed_on_content(gpu_device):
     assert rel_err(out_s, oracle(one))[0] <= 1e-5 and single.corner_nodes is kept
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 def test_flat_adam_state_dict_param_groups_and_gradient_set_changes(gpu_device):
     torch.manual_seed(0)
@@ -157,6 +158,7 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 def test_two_rank_step_equals_full_batch_step(gpu_device):
     """Two ranks (fresh child processes sharing the one GPU of the test box, gloo for the collective - RCCL needs a GPU
@@ -178,6 +180,7 @@ def test_two_rank_step_equals_full_batch_step(gpu_device):
     assert d['ranks_identical'] is True          # replicas stay bit-identical after the reduce
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("capture_allreduce", [False, True], ids=['eager-collective', 'capture-allreduce-requested'])
 def test_bench_two_ranks_rehearsal(gpu_device, capture_allreduce):
@@ -270,6 +273,7 @@ def test_unit_gradient_is_plain_backward(gpu_device):
     assert unit_gradient(gpu_device) is unit_gradient(gpu_device) and float(unit_gradient(gpu_device)) == 1.0
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 def test_allreduce_flat_on_a_caller_owned_communicator(gpu_device):
     """`gadapt_allreduce_flat` with a communicator the caller created itself (RCCL through ctypes, one rank - what a one-GPU

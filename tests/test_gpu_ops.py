@@ -159,6 +159,7 @@ def test_golden_fixtures(gpu_device, path):
         assert rel_err(p.grad[0], want64)[0] <= max(floor, nf * noise), (k, rel_err(p.grad[0], want64)[0], noise)
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("capturable", [False, True], ids=['host-step', 'device-step'])
 def test_flat_adam_matches_torch_adam(gpu_device, capturable):
@@ -181,6 +182,7 @@ def test_flat_adam_matches_torch_adam(gpu_device, capturable):
     assert ours.grad_bucket.numel() == 64 * 64 + 64
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 def test_mesh_loss_seed_kernel(gpu_device):
     from g_adaptivity_amd._native import check, current_stream, lib, ptr
@@ -204,6 +206,7 @@ FULL_SIZES = [(64, 32, 64, 4, 'GRAND_plus', True),        # the metric workload 
 FULL_IDS = ['cfg3-64x64-b32-C64-L4', 'cfg2-32x32-b32-C64-L4', 'cfg4-64x64-b32-C128-L6-GRAND', 'cfg5-128x128-b16-C64-L20']
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,B,C,L,conv,inc_f", FULL_SIZES, ids=FULL_IDS)
 def test_full_size_properties(gpu_device, n, B, C, L, conv, inc_f):
@@ -251,6 +254,7 @@ def test_full_size_properties(gpu_device, n, B, C, L, conv, inc_f):
         assert rel_err(a[:, col], b[:, col])[0] <= 1e-5
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize('l1', [False, True])
 def test_native_loss_matches_torch(gpu_device, l1):
@@ -271,6 +275,7 @@ def test_native_loss_matches_torch(gpu_device, l1):
     assert torch.equal(again, ours.detach())                # fixed summation order: bit-identical repeats
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize('with_f,with_uu', [(True, True), (True, False), (False, True), (False, False)])
 def test_encode_features_equals_concat_then_linear(gpu_device, with_f, with_uu):
@@ -452,6 +457,7 @@ def test_mixed_window_tiles(gpu_device, C):
         assert rel_err(got, want)[0] <= 1e-4, rel_err(got, want)
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,B,C,L,conv,inc_f", FULL_SIZES, ids=FULL_IDS)
 def test_full_size_backward_properties(gpu_device, n, B, C, L, conv, inc_f):
@@ -513,6 +519,7 @@ def _conv_run(gpu_device, ei, x, up, layer, wide):
         graph_mod.WIDE_KERNELS = old
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("mesh_n,batch", [(64, 32), (40, 45), (23, 7)], ids=['64x64-b32', '40x40-b45', '23x23-b7'])
 def test_wide_kernels_match_tiled_kernels(gpu_device, mesh_n, batch):
@@ -537,6 +544,7 @@ def test_wide_kernels_match_tiled_kernels(gpu_device, mesh_n, batch):
         assert rel_err(a, b)[0] <= tol, (name, rel_err(a, b))
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("mesh_n,batch,layers", [(128, 16, 2), (128, 3, 3), (100, 5, 2), (65, 7, 2), (96, 2, 4)],
                          ids=['128x128-b16', '128x128-b3', '100x100-b5', '65x65-b7', '96x96-b2'])
@@ -568,6 +576,7 @@ def test_wide_forward_512_row_window_matches_tiled_kernels(gpu_device, mesh_n, b
         assert rel_err(a, b)[0] <= tol, (name, rel_err(a, b))
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("mesh_n,batch", [(5, 1), (9, 3), (16, 1), (17, 2), (31, 1), (33, 9), (50, 11), (63, 17), (64, 1), (64, 5)],
                          ids=lambda v: str(v))
@@ -597,6 +606,7 @@ def test_wide_kernels_size_sweep(gpu_device, mesh_n, batch):
         assert rel_err(a, b)[0] <= tol, rel_err(a, b)
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("mesh_n,batch", [(9, 3), (17, 2), (33, 9), (63, 5), (64, 3)], ids=lambda v: str(v))
 def test_source_window_size_sweep(gpu_device, mesh_n, batch):
@@ -627,6 +637,7 @@ def test_source_window_size_sweep(gpu_device, mesh_n, batch):
         assert rel_err(a, b)[0] <= 1e-6, rel_err(a, b)
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 def test_wide_kernels_ragged_rows(gpu_device):
     """Rows of 0, 1, 7 and 8 in-edges inside the window (the ELL-8 limit), next to the mesh's 2..6: a node without
@@ -658,6 +669,7 @@ def test_wide_kernels_ragged_rows(gpu_device):
         assert rel_err(a, b)[0] <= tol, (name, rel_err(a, b))
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 def test_wide_kernels_rebase_large_scores(gpu_device):
     """The wide forward takes softmax weights relative to the first score of a row and re-bases when a later score
@@ -679,6 +691,7 @@ def test_wide_kernels_rebase_large_scores(gpu_device):
     assert rel_err(res, ref)[0] <= 2e-5, rel_err(res, ref)
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("mesh_n,batch,hidden", [(16, 3, 64), (24, 2, 32), (64, 8, 64)], ids=['16x16-C64', '24x24-C32', '64x64-b8-C64'])
 def test_fused_backward_matches_two_pass(gpu_device, mesh_n, batch, hidden):
@@ -686,6 +699,9 @@ def test_fused_backward_matches_two_pass(gpu_device, mesh_n, batch, hidden):
     default because it measured slower) against the target / source pair: same gradients up to fp32 reassociation, on mesh
     batches and on a random graph with long rows and isolated nodes (loop paths of both edge walks)."""
     from g_adaptivity_amd._native import lib
+    if lib().gadapt_debug_set_fused_backward(1) != 0:
+        pytest.skip("library built without -DGADAPT_WITH_FUSED_BWD (`make FUSED_BWD=1`): the fused dense backward is not in the default build")
+    lib().gadapt_debug_set_fused_backward(0)
     opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=hidden, num_layers=4, device=str(gpu_device), show_mesh_evol_plots='False')
     ds = MeshDataset([mesh_n, mesh_n], batch, seed=9)
     data = collate(ds.samples).to(gpu_device)

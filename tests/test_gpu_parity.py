@@ -41,6 +41,15 @@ CASES = [
     ((11, 11), 2, 32, 3, 'GRAND_plus', {'learn_step': True, 'share_conv': False}),
     ((16, 16), 2, 64, 4, 'GRAND_plus', {'learn_step': True}),                           # shared convs, compact slots + d dt sums
     ((12, 12), 2, 128, 2, 'GRAND', {'learn_step': True}),
+    # learnable temperature sm_temp_a (GRAND_plus.py:152-154,328-329) through the fused block: compact slots + the SUMS = 2
+    # instantiations (per-workgroup d score_scale partials, compact layer-0 kernel, 4-column and compact-gradient variants) - ADVICE r3
+    ((16, 16), 2, 64, 2, 'GRAND_plus', {'softmax_temp_type': 'learnable_a'}),
+    ((16, 16), 2, 64, 4, 'GRAND_plus', {'softmax_temp_type': 'learnable_a'}),
+    ((14, 14), 3, 32, 3, 'GRAND_plus', {'softmax_temp_type': 'learnable_a', 'share_conv': False}),
+    ((16, 16), 2, 64, 4, 'GRAND_plus', {'learn_step': True, 'softmax_temp_type': 'learnable_a'}),
+    ((12, 12), 2, 32, 2, 'GRAND_plus', {'learn_step': True, 'softmax_temp_type': 'learnable_a', 'share_conv': False}),
+    ((15, 15), 2, 16, 3, 'GRAND_plus', {'softmax_temp_type': 'learnable_a'}),
+    ((64, 64), 8, 64, 3, 'GRAND_plus', {'learn_step': True, 'softmax_temp_type': 'learnable_a'}),    # fills the GPU: wide forward in production too
     ((17,), 4, 16, 2, 'GRAND_plus', {'fix_boundary': False}),
     # BASELINE config 4 shape: 64x64, 6 layers, hidden 128, GRAND, features [x, y, uu] (two meshes: the oracle stays quick)
     ((64, 64), 2, 128, 6, 'GRAND', {'gnn_inc_feat_f': False, 'noise_factor': 3.0}),
@@ -67,13 +76,18 @@ IDS = [f"{'x'.join(map(str, c[0]))}-b{c[1]}-C{c[2]}-L{c[3]}-{c[4]}" + ('-' + ','
 def _run(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra):
     extra = {k: v for k, v in extra.items() if k not in _META}
     opt, ds, data, oracle = make_case(mesh_dims, batch, hidden, layers, conv_type, **extra)
+    if extra.get('softmax_temp_type') == 'learnable_a':         # distinct temperatures per distinct conv (the start value 1 hides scale errors)
+        with torch.no_grad():
+            for k, layer in enumerate({id(l): l for l in oracle.conv_layers}.values()):
+                layer.sm_temp_a.fill_(1.3 + 0.25 * k)
     model = hip_model_like(oracle, ds, opt, gpu_device)
     tgt = data.x_phys if data.x_phys.dim() == 2 else data.x_phys.unsqueeze(-1)
     ref = oracle(data)
     F.mse_loss(ref, tgt).backward()
     o64, ref64 = oracle_fp64_twin(oracle, ds, opt, data, tgt)
-    out = model(data.clone().to(gpu_device))
-    F.mse_loss(out, tgt.to(gpu_device)).backward()
+    model._test_batch = (data.clone().to(gpu_device), tgt.to(gpu_device))
+    out = model(model._test_batch[0])
+    F.mse_loss(out, model._test_batch[1]).backward()
     torch.cuda.synchronize()
     return oracle, o64, model, ref, ref64, out
 
@@ -100,6 +114,7 @@ for _c, _id in zip(CASES, IDS):
         PARAMS.append(_c + (PRODUCTION_WIDE_MIN_NODES,)); PARAM_IDS.append(_id + '-production-kernel-choice')
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("mesh_dims,batch,hidden,layers,conv_type,extra,wide_min_nodes", PARAMS, ids=PARAM_IDS)
 def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra, wide_min_nodes):
@@ -116,6 +131,21 @@ def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, c
                 e64 = rel_err(model.steps[l].grad, o64.steps[l].grad)[0]
                 noise = rel_err(oracle.steps[l].grad, o64.steps[l].grad)[0]
                 assert e64 <= max(GRAD_TOL, 1.5 * noise), f"steps.{l}.grad vs fp64 oracle: {e64:.2e} (fp32 oracle: {noise:.2e})"
+        if extra.get('softmax_temp_type') == 'learnable_a':  # d L / d sm_temp_a: the d score_scale sums, chained through 1/(sqrt(C) T)
+            distinct = list({id(l): k for k, l in enumerate(model.conv_layers)}.values())
+            for li in distinct:
+                gh, g32, g64 = (m.conv_layers[li].sm_temp_a.grad for m in (model, oracle, o64))
+                assert gh is not None and gh.shape == g64.shape
+                e64, noise = rel_err(gh, g64)[0], rel_err(g32, g64)[0]
+                assert e64 <= max(GRAD_TOL, 1.5 * noise), f"layer {li} sm_temp_a.grad vs fp64 oracle: {e64:.2e} (fp32 oracle: {noise:.2e})"
+            # bit-reproducible: the per-workgroup partials are summed in a fixed order (no float atomics)
+            first = {n_: p_.grad.clone() for n_, p_ in model.named_parameters() if p_.grad is not None}
+            model.zero_grad(set_to_none=True)
+            F.mse_loss(model(model._test_batch[0]), model._test_batch[1]).backward()
+            torch.cuda.synchronize()
+            for n_, p_ in model.named_parameters():
+                if p_.grad is not None:
+                    assert torch.equal(p_.grad, first[n_]), f"{n_}.grad differs between two identical runs"
     finally:
         _graph_mod.WIDE_MIN_NODES = keep
     nf, gtol = extra.get('noise_factor', 1.5), extra.get('grad_tol', GRAD_TOL)

@@ -125,6 +125,7 @@ def test_compact_encoder_output_equals_dense(gpu_device):
                 assert rel_err(p.grad, grads_c[k])[0] <= 2e-6, (k, rel_err(p.grad, grads_c[k]))
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 def test_bench_line_contract(gpu_device):
     """bench.py prints ONE JSON line with the driver's keys, the roofline object of the dominant kernel group and a

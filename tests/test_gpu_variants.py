@@ -23,6 +23,7 @@ def _graph(n, e, seed, dev):
     return ei, MeshGraph(ei, n, dev)
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("C", [3, 8, 64, 100, 260])
 def test_spmm_sddmm_forward_backward(gpu_device, C):
@@ -57,6 +58,7 @@ def test_spmm_sddmm_forward_backward(gpu_device, C):
     assert torch.equal(Sp.spmm(graph, wh.detach(), xh.detach()), out.detach())   # bit-reproducible
 
 
+@pytest.mark.one_dispatch
 @pytest.mark.gpu
 def test_edge_softmax_and_edge_combine(gpu_device):
     n = 300
