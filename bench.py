@@ -114,6 +114,10 @@ def main():
                     help='materialise the zero-padded encoder output, the full last-layer output and the padded top gradient '
                          '(DESIGN.md §4) instead of their compact forms')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--windows', type=int, default=5,
+                    help='timed windows of --steps steps each; value / ms_per_step are the MEDIAN window (min and max reported beside it)')
+    ap.add_argument('--no-companion', action='store_true',
+                    help='skip the second timing of the other slot flow (dense when the headline is compact and vice versa)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -128,6 +132,14 @@ def main():
     if os.environ.get('GADAPT_BENCH_SHARE_GPU') == '1':
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     backend = os.environ.get('GADAPT_BENCH_BACKEND', 'nccl')
+    # Capturing the gradient all-reduce with the step (N > 1, RCCL): rehearsed first in CHILD processes, one per rank, before this
+    # process touches its GPU (g_adaptivity_amd/rccl_probe.py: a failed capture is not recoverable in-process on this ROCm).
+    # GADAPT_BENCH_CAPTURE_ALLREDUCE=1 / 0 force the choice without the rehearsal.
+    env_cap = os.environ.get('GADAPT_BENCH_CAPTURE_ALLREDUCE')
+    probe_ok = None
+    if world > 1 and backend == 'nccl' and env_cap not in ('0', '1'):
+        from g_adaptivity_amd.rccl_probe import rehearse
+        probe_ok = rehearse()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
@@ -146,109 +158,148 @@ def main():
     w = WORKLOADS[args.workload]
     if w['conv'] not in ('GRAND', 'GRAND_plus') and os.environ.get('GADAPT_BENCH_FORCE_GRAPH') != '1':
         args.no_graph = True                                          # generic-primitive convs: timed as eager launches
-    opt = hot_path_opt(mesh_dims=[w['n'], w['n']], hidden_dim=w['hidden'], num_layers=w['layers'], conv_type=w['conv'],
-                       gnn_inc_feat_f=w['f'], gnn_inc_feat_uu=w['uu'], device=str(dev), loss_type='mesh_loss',
-                       show_mesh_evol_plots='False', compact_slots=not args.dense_slots, learn_step=bool(w.get('learn_step', False)))
+    def rccl_capture_ok():
+        if backend != 'nccl':
+            if env_cap == '1' and rank == 0:
+                # only RCCL collectives can be stream-captured; a capture that a synchronising collective invalidates is NOT
+                # recoverable in-process (tools/capture_recovery_probe.py), so it is never attempted
+                print(f"[bench] GADAPT_BENCH_CAPTURE_ALLREDUCE=1 ignored: backend '{backend}' cannot be captured", file=sys.stderr)
+            return False
+        if env_cap in ('0', '1'):
+            return env_cap == '1'
+        t = torch.tensor([1.0 if probe_ok else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)                      # every rank's rehearsal must have passed
+        return bool(t.item() == 1.0)
+
     ds = MeshDataset([w['n'], w['n']], w['batch'], seed=rank)        # every rank owns its own shard of meshes
     data = collate(ds.samples).to(dev)
     target = data.x_phys
-    torch.manual_seed(0)                                              # identical replicas
-    model = GNN(ds, opt).to(dev)
-    model.train()
     # one GPU: the optimizer step is captured with forward and backward (step count on the device).  N > 1: forward + loss +
     # backward are the replayed graph, the RCCL all-reduce of the 33 KB gradient bucket and the Adam launch (step count on
-    # the device as well: no host-side value changes from step to step) follow it on the same stream.
-    # GADAPT_BENCH_CAPTURE_ALLREDUCE=1 also captures the collective and Adam in the graph (RCCL collectives are stream-
-    # capturable); off by default because it cannot be rehearsed on a one-GPU box, and a capture that fails falls back.
-    capture_all = world == 1 or (os.environ.get('GADAPT_BENCH_CAPTURE_ALLREDUCE') == '1' and backend == 'nccl')
-    if world > 1 and os.environ.get('GADAPT_BENCH_CAPTURE_ALLREDUCE') == '1' and backend != 'nccl' and rank == 0:
-        # only RCCL collectives can be stream-captured; a capture that a synchronising collective invalidates is NOT recoverable
-        # in-process on this ROCm (every later launch of the thread fails with hipErrorStreamCaptureInvalidated: measured with
-        # tools/capture_recovery_probe.py), so it is never attempted
-        print(f"[bench] GADAPT_BENCH_CAPTURE_ALLREDUCE=1 ignored: backend '{backend}' cannot be captured", file=sys.stderr)
-    optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=True)
-
+    # the device as well: no host-side value changes from step to step) follow it on the same stream; with the RCCL backend the
+    # collective and Adam are captured too once a one-rank capture probe has passed on every rank (see rccl_capture_ok).
+    capture_all = world == 1 or rccl_capture_ok()
     # loss.backward() with the root gradient handed over instead of created per step (g_adaptivity_amd.unit_gradient: same
     # value, two launches fewer - the one-element fill and the multiplication by it); --plain-backward: the literal call
     root = None if (args.plain_backward or args.torch_loss) else unit_gradient(dev)
 
-    def fwd_bwd():
-        out = model(data)
-        loss = loss_fn(out, target)
-        if root is None:
-            loss.backward()
-        else:
-            loss.backward(gradient=root)
-        return loss
+    def build_runner(dense_slots):
+        """model + optimizer + step() for one slot flow; the step is a replayed hipGraph unless --no-graph / capture fails."""
+        opt = hot_path_opt(mesh_dims=[w['n'], w['n']], hidden_dim=w['hidden'], num_layers=w['layers'], conv_type=w['conv'],
+                           gnn_inc_feat_f=w['f'], gnn_inc_feat_uu=w['uu'], device=str(dev), loss_type='mesh_loss',
+                           show_mesh_evol_plots='False', compact_slots=not dense_slots, learn_step=bool(w.get('learn_step', False)))
+        torch.manual_seed(0)                                          # identical replicas
+        model = GNN(ds, opt).to(dev)
+        model.train()
+        optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=True)
 
-    def eager_step():
-        optim.zero_grad()
-        loss = fwd_bwd()
-        optim.step()                                                  # all-reduce (N>1) + fused Adam
-        return loss
+        def fwd_bwd():
+            out = model(data)
+            loss = loss_fn(out, target)
+            if root is None:
+                loss.backward()
+            else:
+                loss.backward(gradient=root)
+            return loss
 
-    # first steps eagerly: builds the CSR cache and the flat bucket
-    for _ in range(2):
-        eager_step()
-    torch.cuda.synchronize()
-
-    graph = None
-    if not args.no_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                optim.zero_grad(); fwd_bwd()
-                if capture_all:
-                    optim.step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
+        def eager_step():
             optim.zero_grad()
-            # N > 1: other threads of the process make CUDA calls while this one captures (the RCCL process group's watchdog
-            # polls events); "thread_local" keeps those from invalidating the capture.  GADAPT_BENCH_CAPTURE_MODE overrides.
-            mode = os.environ.get('GADAPT_BENCH_CAPTURE_MODE', 'thread_local' if world > 1 else 'global')
-            with torch.cuda.graph(g, stream=side, capture_error_mode=mode):
-                static_loss = fwd_bwd()
-                if capture_all:
-                    optim.step()
-            graph = g
-        except Exception as e:                                        # stay correct: fall back to eager launches
-            print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
-            graph = None
-            capture_all = world == 1
-            try:
-                torch.cuda.synchronize()
-            except Exception:
-                pass
-            _native.clear_error()                                     # the invalidated capture left HIP's per-thread last error set
+            loss = fwd_bwd()
+            optim.step()                                              # all-reduce (N>1) + fused Adam
+            return loss
 
-    def step():
-        if graph is not None:
-            graph.replay()                                            # forward + loss + backward (+ all-reduce + Adam when captured)
-            if not capture_all:
-                optim.step()                                          # all-reduce + fused Adam
-        else:
+        for _ in range(2):                                            # first steps eagerly: builds the CSR cache and the flat bucket
             eager_step()
+        torch.cuda.synchronize()
+        graph, cap_all = None, capture_all
+        if not args.no_graph:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    optim.zero_grad(); fwd_bwd()
+                    if cap_all:
+                        optim.step()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                optim.zero_grad()
+                # N > 1: other threads of the process make CUDA calls while this one captures (the RCCL process group's watchdog
+                # polls events); "thread_local" keeps those from invalidating the capture.  GADAPT_BENCH_CAPTURE_MODE overrides.
+                mode = os.environ.get('GADAPT_BENCH_CAPTURE_MODE', 'thread_local' if world > 1 else 'global')
+                with torch.cuda.graph(g, stream=side, capture_error_mode=mode):
+                    fwd_bwd()
+                    if cap_all:
+                        optim.step()
+                graph = g
+            except Exception as e:                                    # stay correct: fall back to eager launches
+                print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
+                graph, cap_all = None, world == 1
+                try:
+                    torch.cuda.synchronize()
+                except Exception:
+                    pass
+                _native.clear_error()                                 # the invalidated capture left HIP's per-thread last error set
+
+        def step():
+            if graph is not None:
+                graph.replay()                                        # forward + loss + backward (+ all-reduce + Adam when captured)
+                if not cap_all:
+                    optim.step()                                      # all-reduce + fused Adam
+            else:
+                eager_step()
+
+        return {'opt': opt, 'model': model, 'optim': optim, 'step': step, 'fwd_bwd': fwd_bwd, 'graph': graph, 'capture_all': cap_all}
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(); barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_windows(step_fn):
+        """W warm-up steps, then `--windows` windows of EXACTLY K steps each, every window bracketed by barrier +
+        torch.cuda.synchronize() on both sides and reduced with MAX over ranks.  Returns the per-window seconds."""
+        for _ in range(args.warmup):
+            step_fn()
+        out = []
+        for _ in range(max(args.windows, 1)):
+            barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_fn()
+            torch.cuda.synchronize(); barrier()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            out.append(el)
+        return out
+
+    def summarise(times):
+        srt = sorted(times)
+        med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        per = lambda t: round(1e3 * t / args.steps, 4)                # noqa: E731
+        return med, {'n': len(times), 'steps_per_window': args.steps, 'ms_per_step_min': per(srt[0]), 'ms_per_step_median': per(med),
+                     'ms_per_step_max': per(srt[-1])}
+
+    main_run = build_runner(args.dense_slots)
+    model, optim, fwd_bwd, opt = main_run['model'], main_run['optim'], main_run['fwd_bwd'], main_run['opt']
+    graph, capture_all = main_run['graph'], main_run['capture_all']
+    elapsed, windows = summarise(timed_windows(main_run['step']))     # the headline: the MEDIAN window
     meshes = w['batch'] * world * args.steps
     value = meshes / elapsed
+
+    # the other slot flow in the same run (VERDICT r3 item 3): the headline's compact slots follow the identity encoder's
+    # zero-pad contract; the dense flow is the literal one SURVEY.md 8(d)'s bytes describe.  Fused GRAND kernels only.
+    companion = None
+    if not args.no_companion and w['conv'] in ('GRAND', 'GRAND_plus'):
+        other = build_runner(not args.dense_slots)
+        c_el, c_win = summarise(timed_windows(other['step']))
+        companion = {'slots': 'compact' if args.dense_slots else 'dense', 'value': round(meshes / c_el, 1),
+                     'ms_per_step': round(1e3 * c_el / args.steps, 4), 'windows': c_win,
+                     'launch': 'hipgraph' if other['graph'] is not None else 'eager'}
+        del other
+        torch.cuda.synchronize()
 
     # ---- instrumented pass (eager, HIP events around each hot-kernel launch)
     roofline, kernels = None, {}
@@ -426,7 +477,7 @@ def main():
         line = {
             'metric': 'meshes/sec fwd+bwd, 2D Poisson 64x64 mesh graph, batch 32, 1/2/4/8 GPU',
             'value': round(value, 1), 'unit': 'meshes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'windows': windows, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': args.workload, 'mesh': f"{w['n']}x{w['n']}", 'meshes_per_gpu': w['batch'],
                        'global_batch': w['batch'] * world, 'mp_layers': w['layers'], 'hidden': w['hidden'],
@@ -434,6 +485,10 @@ def main():
                        'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'root_gradient': 'created per step (loss.backward())' if root is None else 'preallocated (unit_gradient)', 'slots': 'dense' if args.dense_slots else 'compact', 'slots_note': None if args.dense_slots else 'identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the [N,4] encoder output in forward and backward, layer 1 hands it the 4 gradient columns it reads, the last layer writes the [N,4] head the model returns (GNN.py:299) and takes the compact top gradient; --dense-slots runs the literal dense flow', 'launch': ('hipgraph+adam' if world == 1 else ('hipgraph+allreduce+adam' if capture_all else 'hipgraph, then allreduce+adam')) if graph is not None else 'eager'},
             'roofline': roofline, 'roofline_mfma': roofline_mfma, 'kernels': kernels, 'cpu_baseline': cpu,
         }
+        if companion is not None:                                     # same run, the other slot flow (see above)
+            key = 'dense_slots' if companion['slots'] == 'dense' else 'compact_slots'
+            line['value_' + key], line['ms_per_step_' + key] = companion['value'], companion['ms_per_step']
+            line['windows_' + key] = companion['windows']
         print(json.dumps(line))
     if world > 1:
         dist.barrier()                                                # rank 0 was still measuring: leave together

@@ -12,8 +12,9 @@ from .graph import GraphCache, MeshGraph, prepare_edge_index
 from .mesh_graph import (DeviceMeshLoader, MeshData, MeshDataset, MeshLoader, Mixed_DataLoader, MixedMeshDataset, collate, interval_mesh,
                          square_mesh, synthetic_batch)
 from .params import hot_path_opt
+from .training import GraphedTrainStep
 
 __all__ = ['GNN', 'MLP', 'get_conv', 'build_conv_list', 'get_enc', 'get_dec', 'get_mlp', 'get_nonlin',
            'GRAND_plusConv', 'GRAND_conv', 'TRANS_conv', 'GAT_plus', 'GAT_conv', 'GCN_conv', 'MeshGraph', 'GraphCache', 'prepare_edge_index',
            'MeshData', 'MeshDataset', 'MeshLoader', 'DeviceMeshLoader', 'MixedMeshDataset', 'Mixed_DataLoader', 'collate', 'interval_mesh', 'square_mesh',
-           'synthetic_batch', 'hot_path_opt', 'mse_loss', 'l1_loss', 'unit_gradient']
+           'synthetic_batch', 'hot_path_opt', 'GraphedTrainStep', 'mse_loss', 'l1_loss', 'unit_gradient']

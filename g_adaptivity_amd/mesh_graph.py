@@ -379,12 +379,17 @@ class DeviceMeshLoader:
     NODE_FIELDS = ('x_comp', 'x_phys', 'f_tensor', 'uu_tensor', 'u_true_tensor')
 
     def __init__(self, dataset: MeshDataset, batch_size: int = 1, shuffle: bool = False, device='cuda',
-                 generator: Optional[torch.Generator] = None):
+                 generator: Optional[torch.Generator] = None, fields: Optional[Sequence[str]] = None, into=None):
+        """`fields`: the node fields a batch carries (default: all of NODE_FIELDS the samples have).  `into`: a callable mapping a
+        batch to the STATIC batch object of its topology (`training.GraphedTrainStep.static_batch`): from the second batch of a
+        size on, the gathers write straight into that object's tensors and the object itself is yielded - no copy between the
+        loader and a captured step.  (A yielded static batch is overwritten by the next one: do not hold on to it.)"""
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
         self.device, self.generator = torch.device(device), generator
         self.fields = {k: torch.stack([getattr(s, k) for s in dataset.samples]).to(self.device)
-                       for k in self.NODE_FIELDS if hasattr(dataset.samples[0], k)}
+                       for k in (fields or self.NODE_FIELDS) if hasattr(dataset.samples[0], k)}
         self._templates = {}
+        self.into, self._static = into, {}
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
@@ -407,12 +412,23 @@ class DeviceMeshLoader:
             order = torch.arange(n, device=self.device)
         for s in range(0, n, self.batch_size):
             idx = order[s:s + self.batch_size]
-            out = copy.copy(self._template(int(idx.numel())))         # shares the topology tensors
+            b = int(idx.numel())
+            static = self._static.get(b)
+            if static is not None:                                    # gathers land in the captured step's input buffers
+                for k, stacked in self.fields.items():
+                    dst = getattr(static, k)
+                    torch.index_select(stacked, 0, idx, out=dst.view(b, *stacked.shape[1:]))
+                static.idx = idx
+                yield static
+                continue
+            out = copy.copy(self._template(b))                        # shares the topology tensors
             out.__dict__ = dict(out.__dict__)
             for k, stacked in self.fields.items():
                 sel = stacked.index_select(0, idx)
                 out.__dict__[k] = sel.reshape(-1, *sel.shape[2:])
             out.idx = idx
+            if self.into is not None:
+                self._static[b] = self.into(out)                      # captured on first use, initialised with this batch's fields
             yield out
 
 

@@ -307,3 +307,33 @@ def test_allreduce_flat_on_a_caller_owned_communicator(gpu_device):
         assert b'allreduce_flat' in lib.gadapt_last_error()
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
+def test_rccl_allreduce_captured_in_a_hipgraph_one_rank(gpu_device):
+    """The rehearsal `bench.py --gpus N` (N > 1, RCCL) runs on every rank before it captures the gradient all-reduce with the step
+    (`g_adaptivity_amd/rccl_probe.py`), here with ONE rank - what a one-GPU box can host: a child process creates an RCCL process
+    group, captures copy -> ncclAllReduce -> scale in a hipGraph (thread_local capture mode, as the step does), replays it on
+    four inputs and checks the sums."""
+    from g_adaptivity_amd.rccl_probe import rehearse
+    keep = {k: os.environ.get(k) for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    try:
+        assert rehearse(timeout=300.0)
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
+def test_allreduce_flat_captured_in_a_hipgraph_one_rank(gpu_device):
+    """The C-ABI collective `gadapt_allreduce_flat` on a caller-owned one-rank communicator inside a captured hipGraph, replayed on
+    changing inputs (child process: tools/rccl_cabi_capture_probe.py)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rccl_cabi_capture_probe.py')], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT)
+    assert r.returncode == 0 and 'CABI_CAPTURE_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -147,3 +147,96 @@ def test_bench_line_contract(gpu_device):
     assert rf['bound'] == 'hbm' and rf['peak'] == 8000.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3 and rf['unit'] == 'GB/s'
     assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and 'sample' in cb
     assert abs(d['value'] - 32 * 1000.0 / d['ms_per_step']) / d['value'] < 0.01
+    # median of >= 5 windows of K steps, and the dense-slot flow timed in the same run
+    wd = d['windows']
+    assert wd['n'] >= 5 and wd['steps_per_window'] == 4 and wd['ms_per_step_min'] <= wd['ms_per_step_median'] <= wd['ms_per_step_max']
+    assert abs(wd['ms_per_step_median'] - d['ms_per_step']) < 1e-3
+    assert d['config']['slots'] == 'compact' and d['value_dense_slots'] > 0 and d['ms_per_step_dense_slots'] >= wd['ms_per_step_min'] * 0.9
+    assert d['windows_dense_slots']['n'] >= 5
+
+
+def _fresh_trainer(ds, opt, gpu_device, state):
+    from g_adaptivity_amd import GraphedTrainStep
+    model = GNN(ds, opt).to(gpu_device).train()
+    model.load_state_dict(copy.deepcopy(state))
+    optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=True)
+    return model, optim, GraphedTrainStep(model, optim)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("into", [False, True], ids=['copy-in', 'loader-writes-static-buffers'])
+def test_graphed_train_step_is_the_eager_loop(gpu_device, into):
+    """`GraphedTrainStep`: the reference's iteration (`src/run_GNN.py:99-131`) captured once per batch
+    topology and replayed on CHANGING batches.  Two epochs over a shuffled `DeviceMeshLoader` whose last batch is short (a
+    second topology -> a second capture): the replayed steps leave bit-identical parameters, moments and losses to the same
+    steps issued eagerly, the capture's warm-up iterations leave no trace, and the whole run tracks the CPU oracle trained with
+    torch.optim.Adam on the same batches."""
+    from g_adaptivity_amd import DeviceMeshLoader
+    opt = hot_path_opt(mesh_dims=[12, 12], hidden_dim=64, num_layers=3, lr=1e-3, decay=1e-4, batch_size=4, device=str(gpu_device))
+    ds = MeshDataset([12, 12], 14, seed=0)                              # 14 = 3 batches of 4 + one of 2
+    torch.manual_seed(0)
+    copt = dict(opt); copt['device'] = 'cpu'
+    oracle = OracleGNN(ds, copt).train()
+    state = copy.deepcopy(oracle.state_dict())
+    opt_ref = torch.optim.Adam(oracle.parameters(), lr=opt['lr'], weight_decay=opt['decay'])
+    m_e, o_e, step_e = _fresh_trainer(ds, opt, gpu_device, state)
+    m_g, o_g, step_g = _fresh_trainer(ds, opt, gpu_device, state)
+    fields = ('x_comp', 'x_phys', 'f_tensor', 'uu_tensor')
+
+    def loader(step=None):
+        gen = torch.Generator(device=gpu_device); gen.manual_seed(7)
+        return DeviceMeshLoader(ds, batch_size=4, shuffle=True, device=gpu_device, generator=gen, fields=fields,
+                                into=step.static_batch if step is not None else None)
+
+    le, lg = loader(), loader(step_g if into else None)
+    losses_e, losses_g, losses_ref = [], [], []
+    for epoch in range(2):
+        for d_e, d_g in zip(le, lg):
+            assert torch.equal(d_e.idx, d_g.idx)
+            losses_e.append(step_e.eager(d_e).clone())
+            losses_g.append(step_g(d_g).clone())
+            # the oracle on the same meshes (host collation)
+            batch = collate([ds.samples[i] for i in d_e.idx.tolist()])
+            opt_ref.zero_grad()
+            l = F.mse_loss(oracle(batch), batch.x_phys); l.backward(); opt_ref.step(); losses_ref.append(l.item())
+    torch.cuda.synchronize()
+    assert len(step_g._captured) == 2                                   # batch of 4, batch of 2
+    for a, b in zip(losses_e, losses_g):
+        assert torch.equal(a, b)
+    for (n1, p1), (n2, p2) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        assert torch.equal(p1, p2), n1
+    assert torch.equal(o_e.exp_avg, o_g.exp_avg) and torch.equal(o_e.exp_avg_sq, o_g.exp_avg_sq)
+    assert o_g.state_dict()['step'] == o_e.state_dict()['step'] == len(losses_e) == 8
+    for a, b in zip(losses_g, losses_ref):
+        assert abs(a.item() - b) <= 1e-4 * abs(b)
+    assert losses_ref[-1] < losses_ref[0]
+    lo, lh = oracle.conv_layers[0], m_g.conv_layers[0]
+    for name in ('lin_query.weight', 'lin_key.weight', 'lin_query.bias'):
+        w_ref, w_hip = dict(lo.named_parameters())[name], dict(lh.named_parameters())[name]
+        assert (w_hip.detach().cpu() - w_ref.detach()).abs().max().item() <= 2e-3 * 8 * opt['lr'] + 1e-6
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_with_eager_optimizer_step(gpu_device):
+    """capture_optimizer=False (process groups whose collectives cannot be captured): forward + loss + backward replayed, the
+    optimizer step issued eagerly on the gradients of the graph that just ran - also right after a capture of ANOTHER topology
+    re-pointed the parameters' .grad."""
+    from g_adaptivity_amd import DeviceMeshLoader, GraphedTrainStep
+    opt = hot_path_opt(mesh_dims=[10, 10], hidden_dim=32, num_layers=2, lr=1e-3, decay=0.0, device=str(gpu_device))
+    ds = MeshDataset([10, 10], 7, seed=1)
+    torch.manual_seed(1)
+    base = GNN(ds, opt).to(gpu_device).train()
+    state = copy.deepcopy(base.state_dict())
+    res = []
+    for graphed in (False, True):
+        model = GNN(ds, opt).to(gpu_device).train(); model.load_state_dict(copy.deepcopy(state))
+        optim = FlatAdam(model.parameters(), lr=opt['lr'], capturable=True)
+        step = GraphedTrainStep(model, optim, capture_optimizer=False)
+        for epoch in range(2):
+            for d in DeviceMeshLoader(ds, batch_size=3, shuffle=False, device=gpu_device):      # 3 + 3 + 1
+                (step if graphed else step.eager)(d)
+        torch.cuda.synchronize()
+        res.append([p.detach().clone() for p in model.parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert not torch.equal(res[0][1], list(base.parameters())[1])
