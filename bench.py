@@ -156,8 +156,6 @@ def main():
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # the step is captured on a side stream by design
 
     w = WORKLOADS[args.workload]
-    if w['conv'] not in ('GRAND', 'GRAND_plus') and os.environ.get('GADAPT_BENCH_FORCE_GRAPH') != '1':
-        args.no_graph = True                                          # generic-primitive convs: timed as eager launches
     def rccl_capture_ok():
         if backend != 'nccl':
             if env_cap == '1' and rank == 0:

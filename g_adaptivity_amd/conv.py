@@ -23,6 +23,15 @@ from ._native import SUPPORTED_HIDDEN
 from .graph import MeshGraph, graph_for
 
 
+def _detached(alpha_t):
+    """What `stored_alpha` keeps.  The reference stores the attention WITH its autograd graph (`src/GRAND_plus.py:253-256`,
+    SURVEY appendix A: nothing consumes it), which keeps the whole previous step's graph - saved activations and the parameters'
+    gradient accumulators, bound to the stream that step ran on - alive until the next forward overwrites it.  Besides the memory,
+    that made a hipGraph capture on a side stream segfault inside hipStreamEndCapture after eager steps on the default stream
+    (the stale accumulators pulled the default stream into the capture; tools/capture_bisect.sh).  The values are kept, the graph is not."""
+    return alpha_t.detach() if torch.is_tensor(alpha_t) else alpha_t
+
+
 class _AttentionDiffusionBase(nn.Module):
     def __init__(self, opt, in_channels, out_channels, heads=1, concat=False, beta=False, dropout=0.0,
                  edge_dim=None, bias=False, root_weight=False, skip_bias=False):
@@ -197,7 +206,7 @@ class GRAND_plusConv(_AttentionDiffusionBase):
             edge_weight = self._edge_area_sum(x, mesh, graph)
         res, alpha_t, graph = self._residual(x, edge_index, graph, want_alpha, edge_weight)
         if store:
-            self.stored_ei, self._stored = edge_index, (graph, alpha_t)
+            self.stored_ei, self._stored = edge_index, (graph, _detached(alpha_t))
         if isinstance(return_attention_weights, bool):                     # GRAND_plus.py:259-262
             alpha = (graph.alpha_to_edge_order(alpha_t[:, :graph.num_edges]).t().contiguous() if alpha_t.dim() == 2
                      else graph.alpha_to_edge_order(alpha_t[:graph.num_edges]).unsqueeze(-1))
@@ -260,7 +269,7 @@ class GRAND_conv(_AttentionDiffusionBase):
 
     def forward(self, x, edge_index, graph: Optional[MeshGraph] = None):
         res, alpha_t, graph = self._residual(x, edge_index, graph, True)
-        self.stored_ei, self._stored = edge_index, (graph, alpha_t)
+        self.stored_ei, self._stored = edge_index, (graph, _detached(alpha_t))
         return res
 
 
@@ -370,7 +379,7 @@ class GAT_plus(_GATBase):
             # the reference's forward has no branch for the other declared choices (params.py:272) and returns None
             raise NotImplementedError(f"gat_plus_type={kind!r}: src/GRAND_plus.py:400-416 implements 'GAT_res_lap' and 'GAT_lin' only")
         looped, alpha_t = self._attention(x, edge_index, graph)
-        self.stored_ei, self._stored = looped.edge_index, (looped, alpha_t)
+        self.stored_ei, self._stored = looped.edge_index, (looped, _detached(alpha_t))
         ax = Sp.spmm(looped, alpha_t, x)
         return ax - x if kind == 'GAT_res_lap' else ax
 

@@ -259,3 +259,20 @@ def test_grand_plus_conv_attention_dropout(gpu_device):
     assert not torch.equal(a, b)
     mean = torch.stack([drop(x, ei) for _ in range(400)]).mean(0)
     assert rel_err(mean + x, plain(x, ei) + x)[0] <= 0.1            # E[dropout(alpha)] = alpha
+
+
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
+@pytest.mark.parametrize("conv", ['GAT_plus', 'GAT', 'GCN', 'GRAND'])
+def test_step_captures_after_eager_steps_on_the_default_stream(gpu_device, conv):
+    """Regression (VERDICT r3 missing #3): `bench.py` of the GAT_plus workload segfaulted inside hipStreamEndCapture.  Cause: the
+    convs kept `stored_alpha` WITH its autograd graph, so the previous (eager, default-stream) step's graph - and with it the
+    parameters' gradient accumulators, bound to the default stream - was still alive when the step was captured on a side stream.
+    The exact flow (two eager steps on the default stream, side-stream warm-up, capture of zero_grad + forward + loss + backward +
+    Adam with the preallocated root gradient, replay), in a child process: a regression is a segfault."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PROBE_LAYERS='3', PROBE_EAGER_FIRST='2', PROBE_WARM='1', PROBE_ROOT='1', PROBE_ZERO_OUTSIDE='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'capture_probe_convs.py'), conv, 'step', '16', '4'],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0 and 'replayed ok' in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
