@@ -32,6 +32,21 @@ CASES = {
 ONLY = [a for a in sys.argv[1:]]
 
 
+def permuted(data, seed):
+    """Same batch, another edge order (edge_index and the per-edge masks together): the reference's edge order is the iteration
+    order of a Python set (src/data.py:430-441) and changes from run to run, and with it the fp32 summation order of its scatters."""
+    d = data.clone()
+    perm = torch.randperm(d.edge_index.shape[1], generator=torch.Generator().manual_seed(seed))
+    d.edge_index = d.edge_index[:, perm]
+    for m in ('to_boundary_edge_mask', 'to_corner_nodes_mask', 'diff_boundary_edges_mask'):
+        setattr(d, m, getattr(d, m)[perm])
+    return d
+
+
+def relerr(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / max(np.abs(b).max(), 1e-300))
+
+
 def run(dtype, ds, data, opt, state):
     m = OracleGNN(ds, dict(opt)).to(dtype)
     m.load_state_dict({k: v.to(dtype) for k, v in state.items()})
@@ -57,6 +72,14 @@ for name, (mesh_dims, batch, hidden, layers, conv, over) in CASES.items():
     state = OracleGNN(ds, dict(opt)).state_dict()
     out32, ei = run(torch.float32, ds, data, opt, state)
     out64, _ = run(torch.float64, ds, data, opt, state)
+    # band_<grad>: the fp32 oracle's worst relative error against the fp64 twin over FIVE edge orders of this batch (the stored one
+    # and four permutations) - the run-to-run band of the reference's own fp32 path, what tests/test_gpu_ops.py::test_golden_fixtures
+    # measures the HIP path's error against (tests/test_gpu_parity.py docstring)
+    band = {k: relerr(out32[k], out64[k]) for k in ('d_wq', 'd_bq', 'd_wk')}
+    for seed in range(1, 5):
+        outp, _ = run(torch.float32, ds, permuted(data, seed), opt, state)
+        for k in band:
+            band[k] = max(band[k], relerr(outp[k], out64[k]))
     lay = 'conv_layers.0.'
     np.savez_compressed(
         os.path.join(HERE, name + '.npz'),
@@ -66,5 +89,6 @@ for name, (mesh_dims, batch, hidden, layers, conv, over) in CASES.items():
         target=data.x_phys.numpy(),
         wq=state[lay + 'lin_query.weight'].numpy(), bq=state[lay + 'lin_query.bias'].numpy(),
         wk=state[lay + 'lin_key.weight'].numpy(), bk=state[lay + 'lin_key.bias'].numpy(),
-        **{k + '_f32': v for k, v in out32.items()}, **{k + '_f64': v for k, v in out64.items()})
-    print(name, 'x_phys', out32['x_phys'].shape, 'max|f32-f64|', float(np.abs(out32['x_phys'] - out64['x_phys']).max()))
+        **{k + '_f32': v for k, v in out32.items()}, **{k + '_f64': v for k, v in out64.items()},
+        **{'band_' + k: np.float64(v) for k, v in band.items()})
+    print(name, 'band', {k: '%.2e' % v for k, v in band.items()}, 'x_phys', out32['x_phys'].shape, 'max|f32-f64|', float(np.abs(out32['x_phys'] - out64['x_phys']).max()))

@@ -45,3 +45,32 @@ def oracle_fp64_twin(oracle, ds, opt, data, tgt):
     ref64 = o64(d64)
     F.mse_loss(ref64, tgt.double()).backward()
     return o64, ref64
+
+
+def permute_edges(data, seed):
+    """The same batch with its edge list in another order (edge_index and the three per-edge masks permuted together).  The
+    reference builds edge_index from a Python set of tuples (`src/data.py:430-441`), so ITS edge order - and with it the fp32
+    summation order of every scatter - changes from run to run."""
+    d = data.clone()
+    perm = torch.randperm(d.edge_index.shape[1], generator=torch.Generator().manual_seed(seed))
+    d.edge_index = d.edge_index[:, perm]
+    for m in ('to_boundary_edge_mask', 'to_corner_nodes_mask', 'diff_boundary_edges_mask'):
+        if getattr(d, m, None) is not None:
+            setattr(d, m, getattr(d, m)[perm])
+    return d
+
+
+def edge_order_band(oracle, o64, data, tgt, k=4):
+    """{parameter name: max relative error against the fp64 twin} of the fp32 oracle over `k` edge orders of the same batch:
+    the run-to-run band of the reference's own fp32 path (see permute_edges).  Parameters whose fp64 gradient is None are skipped."""
+    import torch.nn.functional as F
+    probe = copy.deepcopy(oracle)
+    g64 = {n: p.grad for n, p in o64.named_parameters() if p.grad is not None}
+    band = {n: 0.0 for n in g64}
+    for seed in range(1, k + 1):
+        probe.zero_grad(set_to_none=True)
+        F.mse_loss(probe(permute_edges(data, seed)), tgt).backward()
+        for n, p in probe.named_parameters():
+            if n in band and p.grad is not None:
+                band[n] = max(band[n], rel_err(p.grad, g64[n])[0])
+    return band

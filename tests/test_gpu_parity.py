@@ -1,22 +1,27 @@
 """HIP path vs the CPU oracle on the same seeded inputs (run on the MI355X: pytest -m gpu).
 
-Tolerances (BASELINE.json north_star / BASELINE.md): predicted node coordinates within 1e-5 relative fp32;
-parameter gradients within 1e-4 relative.  Gradients are measured against the oracle's fp64 twin.  Where the fp32
-oracle itself cannot reach 1e-4 (the 1-D case: |grad| ~ 1e-6 after heavy cancellation, fp32 oracle 2e-4 off its
-fp64 twin) the bar is "at least as accurate as the fp32 reference path": 1.5x the oracle's own measured rounding error.
-The BASELINE config-4 shape (64x64, 6 layers, hidden 128) is the extreme of that kind: |grad| ~ 1e-10, the remainder of sums
-that cancel to 1 part in 1e3..1e4, and BOTH fp32 paths sit at 0.7-3e-4 of the fp64 result with either one ahead depending on
-the parameter (measured on MI355X: HIP 1.4e-4 / 1.2e-4 / 1.1e-4 against the fp32 oracle's 1.0e-4 / 0.7e-4 / 0.7e-4 at two
-meshes; 2.3e-4 / 6.9e-4 / 4.8e-4 against 3.1e-4 / 7.1e-4 / 3.4e-4 at one).  Two such rounding-noise figures are not
-ordered (the ratio HIP / oracle ranged 0.7 ... 1.9 over those six), so that case is held to 3x the oracle's own error
-(`noise_factor`).  The softmax uses expf and a true division
-(csrc GADAPT_PRECISE_SOFTMAX): with v_exp_f32 / v_rcp_f32 the same case measured 3.4e-4.
+Tolerances (BASELINE.json north_star / BASELINE.md): predicted node coordinates within 1e-5 relative fp32; parameter gradients
+within 1e-4 relative, measured against the oracle's fp64 twin.  ONE rule for every case (no per-case factors):
+
+    error(HIP, fp64)  <=  max(1e-4, 1.5 x noise)
+
+where `noise` is the fp32 ORACLE's own error against its fp64 twin.  Some shapes cannot reach 1e-4 in fp32 at all: the 1-D case
+(|grad| ~ 1e-6) and above all BASELINE config 4 (64x64, 6 layers, hidden 128: |grad| ~ 1e-10, the remainder of sums that cancel to
+1 part in 1e3..1e4).  There the fp32 result is a draw from a band, for the reference too: its edge order is the iteration order of
+a Python set (`src/data.py:430-441`), so its scatter sums run in another order every run.  Measured (tools/diag_accumulation.py,
+CPU): the fp32 oracle's error on config 4's `lin_query.weight` gradient ranges 0.76e-4 .. 2.1e-4 over six edge orders of the
+SAME batch (2 meshes), 0.9e-4 .. 3.8e-4 at one mesh; accumulating the weight-gradient contraction in fp64 leaves it where it was
+(7.57e-5 -> 7.58e-5: the error is rounding of the per-node terms - x, alpha and g through the layers - amplified by the
+cancellation, not summation order), and so does taking scores and aggregation on differences x_j - x_i.  So when a gradient misses
+the bound against ONE oracle run, `noise` is taken as the maximum over the oracle's runs on four more edge orders of the same batch
+(`helpers.edge_order_band`) - the reference's own run-to-run band - and the same bound applies.  The softmax uses expf and a true
+division (csrc GADAPT_PRECISE_SOFTMAX): with v_exp_f32 / v_rcp_f32 config 4 measured 3.4e-4.
 """
 import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import hip_model_like, make_case, oracle_fp64_twin, rel_err
+from helpers import edge_order_band, hip_model_like, make_case, oracle_fp64_twin, rel_err
 
 COORD_TOL = 1e-5
 GRAD_TOL = 1e-4
@@ -52,24 +57,24 @@ CASES = [
     ((64, 64), 8, 64, 3, 'GRAND_plus', {'learn_step': True, 'softmax_temp_type': 'learnable_a'}),    # fills the GPU: wide forward in production too
     ((17,), 4, 16, 2, 'GRAND_plus', {'fix_boundary': False}),
     # BASELINE config 4 shape: 64x64, 6 layers, hidden 128, GRAND, features [x, y, uu] (two meshes: the oracle stays quick)
-    ((64, 64), 2, 128, 6, 'GRAND', {'gnn_inc_feat_f': False, 'noise_factor': 3.0}),
+    ((64, 64), 2, 128, 6, 'GRAND', {'gnn_inc_feat_f': False}),
     # BASELINE config 5 shape: 128x128 mesh, 20 Euler steps, hidden 64 (one mesh): 128-node mesh rows exceed the LDS window,
     # so this is the mesh-ordered NON-windowed tile path, and 20 layers of error growth in forward and backward
-    # (tests run every graph through the wide forward: here its 512-row window.  One mesh, 20 layers: d lin_query.bias measured
-    # 1.08e-4 against fp64 with it, 5.7e-5 with the tiled forward, fp32 oracle 2.0e-5 - rounding of two different summation
-    # orders amplified by 20 layers on ONE mesh; the 16-mesh batch below passes at 1e-4 - so this case is held to 1.5e-4)
-    ((128, 128), 1, 64, 20, 'GRAND_plus', {'grad_tol': 1.5e-4}),
+    # (under 'wide-any-size' the forward is the wide kernel's 512-row window.  One mesh, 20 layers: d lin_query.bias measured
+    # 1.08e-4 against fp64 with it, 5.7e-5 with the tiled forward; the fp32 oracle's own error there is 1.8e-5 .. 8.8e-5 over six
+    # edge orders of the batch - the band rule of the module docstring covers it)
+    ((128, 128), 1, 64, 20, 'GRAND_plus', {}),
     # BASELINE config 2 at its full batch (32 meshes 32x32, 4 layers, hidden 64)
     ((32, 32), 32, 64, 4, 'GRAND_plus', {}),
     # The other BASELINE configs at their FULL sizes (the fp64 oracle takes 8 / 16 / 56 s on the GPU box's host cores): config 3's
     # per-GPU shard = the metric workload, config 4, config 5
     ((64, 64), 32, 64, 4, 'GRAND_plus', {}),
     ((64, 64), 32, 64, 4, 'GRAND_plus', {'learn_step': True}),       # the metric workload with learnable steps: SUMS kernels at full size
-    ((64, 64), 32, 128, 6, 'GRAND', {'gnn_inc_feat_f': False, 'noise_factor': 3.0}),
+    ((64, 64), 32, 128, 6, 'GRAND', {'gnn_inc_feat_f': False}),
     ((128, 128), 16, 64, 20, 'GRAND_plus', {}),
 ]
 TRANS_CASES = [((11, 11), 2, 8, 3, 'relu'), ((14, 14), 3, 64, 2, 'tanh'), ((12, 12), 2, 32, 2, 'identity')]
-_META = ('noise_factor', 'grad_tol')
+_META = ()
 IDS = [f"{'x'.join(map(str, c[0]))}-b{c[1]}-C{c[2]}-L{c[3]}-{c[4]}" + ('-' + ','.join(k for k in c[5] if k not in _META) if [k for k in c[5] if k not in _META] else '') for c in CASES]
 
 
@@ -148,7 +153,7 @@ def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, c
                     assert torch.equal(p_.grad, first[n_]), f"{n_}.grad differs between two identical runs"
     finally:
         _graph_mod.WIDE_MIN_NODES = keep
-    nf, gtol = extra.get('noise_factor', 1.5), extra.get('grad_tol', GRAD_TOL)
+    band = {}                                               # the oracle's edge-order band, computed at most once and only if needed
     norm, elem = rel_err(out, ref)
     if extra.get('residual', True):
         assert norm <= COORD_TOL and elem <= COORD_TOL, f"x_phys vs fp32 oracle: normwise {norm:.2e} elementwise {elem:.2e}"
@@ -167,8 +172,12 @@ def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, c
             g64 = dict(l64.named_parameters())[name].grad
             gh = dict(lh.named_parameters())[name].grad
             e64, e32, noise = rel_err(gh, g64)[0], rel_err(gh, g32)[0], rel_err(g32, g64)[0]
-            assert e64 <= max(gtol, nf * noise), f"layer {li} {name}.grad vs fp64 oracle: {e64:.2e} (fp32 oracle: {noise:.2e})"
-            assert e32 <= gtol + 2 * noise, f"layer {li} {name}.grad vs fp32 oracle: {e32:.2e} (oracle rounding {noise:.2e})"
+            if e64 > max(GRAD_TOL, 1.5 * noise):             # outside ONE oracle run's error: compare with the oracle's run-to-run band
+                if not band:
+                    band.update(edge_order_band(oracle, o64, model._test_batch[0].to('cpu'), model._test_batch[1].cpu()))
+                noise = max(noise, band[f'conv_layers.{li}.{name}'])
+            assert e64 <= max(GRAD_TOL, 1.5 * noise), f"layer {li} {name}.grad vs fp64 oracle: {e64:.2e} (fp32 oracle, worst of its edge orders: {noise:.2e})"
+            assert e32 <= GRAD_TOL + 2 * noise, f"layer {li} {name}.grad vs fp32 oracle: {e32:.2e} (oracle rounding {noise:.2e})"
         # d/d lin_key.bias vanishes analytically (softmax shift invariance); the oracle's is rounding noise
         assert lh.lin_key.bias.grad.abs().max().item() == 0.0
         assert l64.lin_key.bias.grad.abs().max().item() <= 1e-9 * max(l64.lin_query.bias.grad.abs().max().item(), 1e-30) + 1e-18
