@@ -65,6 +65,9 @@ PROTOTYPES = {
     'gadapt_adam_step': (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     'gadapt_adam_step_dev': (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _F, _P]),
     'gadapt_allreduce_flat': (_I, [_P, _P, _L, _I, _P]),
+    'gadapt_gat_plus_block_forward': (_I, [_G, _P, _I, _P, _P, _L, _F, _I, _I, _I, _P, _P, _I, _P]),
+    'gadapt_gat_plus_block_backward': (_I, [_G, _P, _P, _P, _P, _I, _P, _P, _L, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'gadapt_gat_plus_partial_rows': (_I, [_L, _I]),
     'gadapt_profile_enable': (_I, [_I]),
     'gadapt_profile_read': (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'gadapt_profile_samples': (_I, [_I, C.POINTER(C.c_double), _I]),

@@ -906,3 +906,5 @@ extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, 
 }
 
 #include "gadapt_sparse.inc"
+
+#include "gadapt_gat.inc"

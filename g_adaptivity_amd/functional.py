@@ -240,6 +240,75 @@ def grand_euler_block(x0: torch.Tensor, wq, bq, wk, bk, layer_params: torch.Tens
                                   *(steps or ()))
 
 
+NONLIN_CODES = {'identity': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'leaky_relu': 4, 'elu': 5, 'selu': 6}   # get_nonlin, src/GNN.py:48-64
+
+
+class _GatPlusBlock(torch.autograd.Function):
+    """x_L = the L iterations of `src/GNN.py:273-296` around `GAT_plus.forward` (`src/GRAND_plus.py:400-416`) on the self-looped
+    graph: per layer one fused forward launch, in backward a target-side and a source-side launch plus the ordered sum of the
+    att_src / att_dst gradient partials (include/gadapt_hip.h, gadapt_gat_plus_block_*).  att_src / att_dst: [S,C], S = 1
+    (share_conv) or L."""
+
+    @staticmethod
+    def forward(ctx, x0, att_src, att_dst, looped: MeshGraph, num_layers: int, dt: float, residual: bool, res_lap: bool, non_lin: int,
+                out_cols=None):
+        for t, n in ((x0, 'x'), (att_src, 'att_src'), (att_dst, 'att_dst')):
+            _require_gpu(t, n)
+        n, c = x0.shape
+        if n != looped.num_nodes:
+            raise ValueError(f"x has {n} rows but the graph has {looped.num_nodes} nodes")
+        if c not in _native.SUPPORTED_HIDDEN:
+            raise NotImplementedError(f"hidden_dim={c}: fused kernels are built for {_native.SUPPORTED_HIDDEN}")
+        L, S = int(num_layers), att_src.shape[0]
+        assert S in (1, L) and att_src.shape == (S, c) and att_dst.shape == (S, c)
+        dev, st = x0.device, current_stream(x0.device)
+        att_src, att_dst = att_src.contiguous(), att_dst.contiguous()
+        x_all = torch.empty(L + 1, n, c, device=dev, dtype=torch.float32)
+        x_all[0].copy_(x0)
+        ab = torch.empty(L, 2, n, device=dev, dtype=torch.float32)
+        alpha = torch.empty(L, max(looped.num_edges, 1), device=dev, dtype=torch.float32)
+        check(lib().gadapt_gat_plus_block_forward(looped.c_ref, ptr(x_all), L, ptr(att_src), ptr(att_dst), c if S > 1 else 0, float(dt),
+                                                  int(bool(residual)), int(bool(res_lap)), int(non_lin), ptr(ab), ptr(alpha), c, st),
+              'gadapt_gat_plus_block_forward')
+        ctx.graph, ctx.L, ctx.S, ctx.c = looped, L, S, c
+        ctx.cfg = (float(dt), int(bool(residual)), int(bool(res_lap)), int(non_lin))
+        ctx.out_cols = out_cols
+        ctx.save_for_backward(x_all, alpha, ab, att_src, att_dst)
+        ctx.mark_non_differentiable(alpha)
+        out = x_all[L] if out_cols is None else x_all[L][:, :out_cols]          # x[:, :dim] (GNN.py:299)
+        return out, alpha
+
+    @staticmethod
+    def backward(ctx, g_top, _g_alpha):
+        x_all, alpha, ab, att_src, att_dst = ctx.saved_tensors
+        graph, L, S, c = ctx.graph, ctx.L, ctx.S, ctx.c
+        dt, residual, res_lap, non_lin = ctx.cfg
+        n = graph.num_nodes
+        dev, st = g_top.device, current_stream(g_top.device)
+        g_top = g_top.contiguous()
+        if ctx.out_cols is not None:            # one zero-padding pass instead of autograd's zeros + slice copy
+            g_phys, g_top = g_top, torch.empty(n, c, device=dev, dtype=torch.float32)
+            check(lib().gadapt_pad_columns(ptr(g_phys), ptr(g_top), n, ctx.out_cols, c, st), 'gadapt_pad_columns')
+        g_ws = torch.empty(2, n, c, device=dev, dtype=torch.float32)
+        gr_ws = torch.empty(n, c, device=dev, dtype=torch.float32)
+        dz_ws = torch.empty(max(graph.num_edges, 1), device=dev, dtype=torch.float32)
+        db_ws = torch.empty(n, device=dev, dtype=torch.float32)
+        part = torch.empty(lib().gadapt_gat_plus_partial_rows(n, c), 2 * c, device=dev, dtype=torch.float32)
+        d_att = torch.empty(S, 2, c, device=dev, dtype=torch.float32)          # (d att_src | d att_dst): one flat tensor, FlatAdam's bucket
+        d_x0 = torch.empty(n, c, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        check(lib().gadapt_gat_plus_block_backward(graph.c_ref, ptr(x_all), ptr(alpha), ptr(ab), ptr(g_top), L, ptr(att_src), ptr(att_dst),
+                                                   c if S > 1 else 0, dt, residual, res_lap, non_lin, ptr(g_ws), ptr(gr_ws), ptr(dz_ws),
+                                                   ptr(db_ws), ptr(part), ptr(d_att), ptr(d_x0), c, st), 'gadapt_gat_plus_block_backward')
+        return d_x0, d_att[:, 0], d_att[:, 1], None, None, None, None, None, None, None
+
+
+def gat_plus_block(x0: torch.Tensor, att_src: torch.Tensor, att_dst: torch.Tensor, looped: MeshGraph, num_layers: int, dt: float,
+                   residual: bool = True, res_lap: bool = True, non_lin: str = 'identity', out_cols: Optional[int] = None):
+    """(x_L [N,C] or its first `out_cols` columns, alpha [L,E] in the target-CSR order of `looped`): L fused GAT_plus layers with
+    the update of `src/GNN.py:284-296`.  `looped` = `graph.with_self_loops()` (GATConv's edge surgery)."""
+    return _GatPlusBlock.apply(x0.contiguous(), att_src, att_dst, looped, num_layers, dt, residual, res_lap, NONLIN_CODES[non_lin], out_cols)
+
+
 def score_scale(hidden_dim: int, temperature=None):
     """1/(sqrt(C) T): `src/GRAND_plus.py:279` and `:35-37`."""
     s = 1.0 / math.sqrt(hidden_dim)

@@ -220,6 +220,12 @@ class GNN(nn.Module):
             and o.get('softmax_temp_type') != 'learnable_v'
         return bool(o['residual']) and plain and native and not (self.training and o.get('dropout', 0.0) > 0)
 
+    def _gat_plus_fusable(self) -> bool:
+        o = self.opt
+        return (o['conv_type'] == 'GAT_plus' and o['hidden_dim'] in Fn._native.SUPPORTED_HIDDEN and not o.get('learn_step')
+                and o.get('gat_plus_type') in ('GAT_res_lap', 'GAT_lin') and o['non_lin'] in Fn.NONLIN_CODES
+                and o.get('fused_gat_plus', True) and not (self.training and o.get('dropout', 0.0) > 0))
+
     # ------------------------------------------------------------------ forward
     def forward(self, data):
         o = self.opt
@@ -321,6 +327,18 @@ class GNN(nn.Module):
             if store:                                                      # GRAND_plus.py:253-256, :381
                 for l, layer in enumerate(self.conv_layers):
                     layer.stored_ei, layer._stored = graph.edge_index, (graph, alpha[l])
+        elif self._gat_plus_fusable():
+            # conv_type='GAT_plus' (GNN.py:120-121): the L layers with their update (GNN.py:284-296) as one block op - per layer one
+            # fused forward launch, two in backward (csrc/gadapt_gat.inc) - on the self-looped graph GATConv builds
+            looped = graph.with_self_loops()
+            distinct = [self.conv_layers[0]] if o['share_conv'] else list(self.conv_layers)
+            att_src = torch.stack([l.att_src.reshape(-1) for l in distinct]) if len(distinct) > 1 else distinct[0].att_src.reshape(1, -1)
+            att_dst = torch.stack([l.att_dst.reshape(-1) for l in distinct]) if len(distinct) > 1 else distinct[0].att_dst.reshape(1, -1)
+            sliced = self.dec is None or isinstance(self.dec, nn.Identity)
+            x, alpha = Fn.gat_plus_block(x, att_src, att_dst, looped, o['num_layers'], float(o['time_step']), bool(o['residual']),
+                                         o['gat_plus_type'] == 'GAT_res_lap', o['non_lin'], out_cols=self.dim if sliced else None)
+            for l, layer in enumerate(self.conv_layers):                  # GRAND_plus.py:403-404,413-414: stored_ei / stored_alpha
+                layer.stored_ei, layer._stored = looped.edge_index, (looped, alpha[l])
         else:
             mesh = getattr(self.dataset, 'mesh', None)
             if o.get('data_type') == 'randg_mix' and isinstance(getattr(data, 'mesh', None), (list, tuple)) and data.mesh:

@@ -234,6 +234,30 @@ int gadapt_edge_softmax_backward(const gadapt_graph* g, const float* alpha, cons
 int gadapt_edge_combine(const gadapt_graph* g, const float* u_src, const float* v_dst, float* out, int op, void* stream);
 int gadapt_edge_rowsum(const gadapt_graph* g, int by_source, const float* edge_vals, float* out, void* stream);
 
+/* ------------------------------------------------------------------ GAT_plus block (fused)
+ * Replaces, for conv_type = 'GAT_plus' (get_conv, GNN.py:120-121), the L iterations of GNN.forward's layer loop (GNN.py:273-296)
+ * around GAT_plus.forward (GRAND_plus.py:400-416: GATConv attention with identity maps, re-applied as sparse(alpha)^T x):
+ *     a = <x, att_src>, b = <x, att_dst>;  alpha_e = softmax_i(leaky_relu(a_j + b_i, 0.2)) over the in-edges e: j -> i of the
+ *     SELF-LOOPED graph (GATConv: remove_self_loops + add_self_loops - `g` must be that graph);
+ *     res_i = sum_e alpha_e x_j - x_i  (res_lap = 1, 'GAT_res_lap')  |  sum_e alpha_e x_j  (res_lap = 0, 'GAT_lin');
+ *     x <- x + dt * non_lin(res)  (residual = 1)  |  x <- non_lin(res)  (residual = 0).
+ * non_lin: 0 identity, 1 relu, 2 tanh, 3 sigmoid, 4 leaky_relu(0.01), 5 elu, 6 selu (get_nonlin, GNN.py:48-64).  Dropout is not
+ * part of it (callers with dropout > 0 in training mode use the per-layer primitives below).
+ * x_all [(L+1),N,C]: slot 0 = input, slot l+1 = output of layer l.  att_src / att_dst [C] per layer, att_stride floats apart
+ * (0: one shared conv).  ab [L,2,N] (the per-node score halves of every layer) and alpha [L,max(E,1)] (target-CSR order of `g`)
+ * are outputs the backward reads.  C in {4,...,128} like the GRAND kernels.
+ * backward: g_top [N,C] = dL/dx_L; workspaces g_ws [2,N,C], gr_ws [N,C], dz_ws [max(E,1)], db_ws [N],
+ * part_ws [gadapt_gat_plus_partial_rows(N,C), 2C]; d_att [S,2,C] = (d att_src | d att_dst) per distinct conv, written whole
+ * (summed over the layers in a fixed order when shared: bit-reproducible); d_x0 [N,C] nullable. */
+int gadapt_gat_plus_block_forward(const gadapt_graph* g, float* x_all, int n_layers, const float* att_src, const float* att_dst,
+                                  int64_t att_stride, float dt, int residual, int res_lap, int non_lin, float* ab, float* alpha,
+                                  int c, void* stream);
+int gadapt_gat_plus_block_backward(const gadapt_graph* g, const float* x_all, const float* alpha, const float* ab, const float* g_top,
+                                   int n_layers, const float* att_src, const float* att_dst, int64_t att_stride, float dt, int residual,
+                                   int res_lap, int non_lin, float* g_ws, float* gr_ws, float* dz_ws, float* db_ws, float* part_ws,
+                                   float* d_att, float* d_x0 /*nullable*/, int c, void* stream);
+int gadapt_gat_plus_partial_rows(int64_t n_nodes, int c);
+
 /* ------------------------------------------------------------------ loss seed
  * mesh_loss (run_GNN.py:80-84,106): loss = mean |x_phys - target|^p, p = 2 (mse) or 1 (l1),
  * x_phys = x_top[:, :d] (GNN.py:299).  Writes x_phys [N,d], g_top [N,C] (zero outside

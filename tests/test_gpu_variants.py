@@ -116,10 +116,18 @@ def _model_parity(gpu_device, mesh_dims, batch, hidden, layers, conv_type, **ext
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,non_lin,share", [('GAT_res_lap', 'identity', True), ('GAT_res_lap', 'tanh', False), ('GAT_lin', 'relu', True)])
-def test_gat_plus_parity(gpu_device, kind, non_lin, share):
-    """`conv_type='GAT_plus'` (`src/GRAND_plus.py:386-416`): additive attention, default self-loops, A^T x - x."""
-    model, oracle, checked = _model_parity(gpu_device, (12, 12), 3, 16, 3, 'GAT_plus', gat_plus_type=kind, non_lin=non_lin, share_conv=share)
+@pytest.mark.parametrize("fused", [True, False], ids=['fused-block', 'per-layer-primitives'])
+@pytest.mark.parametrize("kind,non_lin,share,hidden,residual", [
+    ('GAT_res_lap', 'identity', True, 16, True), ('GAT_res_lap', 'tanh', False, 16, True), ('GAT_lin', 'relu', True, 16, True),
+    ('GAT_res_lap', 'identity', True, 64, True), ('GAT_res_lap', 'selu', False, 64, True), ('GAT_lin', 'sigmoid', True, 128, True),
+    ('GAT_res_lap', 'elu', True, 32, False), ('GAT_res_lap', 'leaky_relu', False, 8, True), ('GAT_res_lap', 'identity', True, 4, True)])
+def test_gat_plus_parity(gpu_device, kind, non_lin, share, hidden, residual, fused):
+    """`conv_type='GAT_plus'` (`src/GRAND_plus.py:386-416`): additive attention, default self-loops, A^T x - x.  Both routes
+    against the oracle: the fused block op of csrc/gadapt_gat.inc (what `GNN` runs) and the per-layer generic primitives it
+    replaced (dropout / learn_step still take them).  Coordinates and every parameter gradient."""
+    model, oracle, checked = _model_parity(gpu_device, (12, 12), 3, hidden, 3, 'GAT_plus', gat_plus_type=kind, non_lin=non_lin, share_conv=share,
+                                           residual=residual, fused_gat_plus=fused)
+    assert model._gat_plus_fusable() == fused
     assert sorted(n.split('.')[-1] for n in checked if n.startswith('conv_layers.0.')) == ['att_dst', 'att_src']
     layer = model.conv_layers[0]
     n = 3 * 144
@@ -276,3 +284,50 @@ def test_step_captures_after_eager_steps_on_the_default_stream(gpu_device, conv)
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'capture_probe_convs.py'), conv, 'step', '16', '4'],
                        capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0 and 'replayed ok' in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [8, 64, 128])
+def test_gat_plus_block_on_any_graph(gpu_device, C):
+    """The fused GAT_plus block at operator level on a random graph with rows longer than 8 (the loop paths of all three kernels),
+    isolated nodes and a ragged node count, against the same layers composed from the generic primitives in fp64-free torch
+    autograd (`sparse_ops`): output, attention, d x0 and both parameter gradients, shared and per-layer vectors; bit-reproducible."""
+    import math
+    from g_adaptivity_amd import functional as Fn, sparse_ops as Sp
+    from g_adaptivity_amd.graph import MeshGraph
+    n, L, dt = 777, 3, 0.1
+    gen = torch.Generator().manual_seed(5)
+    ei = torch.randint(0, n, (2, 4000), generator=gen)
+    ei = torch.cat([ei, torch.tensor([[3] * 40, list(range(100, 140))]), torch.tensor([list(range(200, 230)), [11] * 30])], dim=1)
+    ei = ei[:, (ei[1] != 17) & (ei[0] != ei[1])]
+    looped = MeshGraph(ei, n, gpu_device).with_self_loops()
+    assert looped.max_in_degree > 8
+    x0 = torch.randn(n, C, generator=gen).to(gpu_device)
+    up = torch.randn(n, C, generator=gen).to(gpu_device)
+    for S in (1, L):
+        src0 = (torch.randn(S, C, generator=gen) / math.sqrt(C)).to(gpu_device)
+        dst0 = (torch.randn(S, C, generator=gen) / math.sqrt(C)).to(gpu_device)
+        for nl, res_lap in (('identity', True), ('tanh', True), ('relu', False)):
+            def run(fused):
+                xr = x0.clone().requires_grad_(True)
+                s_, d_ = src0.clone().requires_grad_(True), dst0.clone().requires_grad_(True)
+                if fused:
+                    y, alpha = Fn.gat_plus_block(xr, s_, d_, looped, L, dt, True, res_lap, nl)
+                    alpha_last = alpha[-1]
+                else:
+                    y = xr
+                    for l in range(L):
+                        k = l if S > 1 else 0
+                        a_src, a_dst = (y * s_[k]).sum(-1), (y * d_[k]).sum(-1)
+                        alpha_last = Sp.edge_softmax(looped, torch.nn.functional.leaky_relu(Sp.edge_add(looped, a_src, a_dst), 0.2))
+                        m = Sp.spmm(looped, alpha_last, y)
+                        r = {'identity': lambda t: t, 'tanh': torch.tanh, 'relu': torch.relu}[nl](m - y if res_lap else m)
+                        y = y + dt * r
+                (y * up).sum().backward()
+                torch.cuda.synchronize()
+                return y.detach(), alpha_last.detach(), xr.grad, s_.grad, d_.grad
+            a, b = run(True), run(False)
+            for name, u, v, tol in zip(('x_L', 'alpha', 'd x0', 'd att_src', 'd att_dst'), a, b, (2e-6, 2e-6, 2e-5, 5e-5, 5e-5)):
+                assert rel_err(u, v)[0] <= tol, (S, nl, name, rel_err(u, v))
+            again = run(True)
+            assert all(torch.equal(u, v) for u, v in zip(a, again))
