@@ -89,11 +89,12 @@ def load_profile_avg_us(workload, kernel, variant):
         return None, None
     # rNN_bench_<workload>_... = bench.py itself under rocprofv3 (tools/bench_all.sh); rNN_<workload>_... = tools/profile_step.py
     paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_bench_{workload}_rocprofv3_kernel_stats.csv')), reverse=True) + \
-            sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_{workload}_rocprofv3_kernel_stats.csv')), reverse=True)
+            sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', f'r*_{workload}_rocprofv3_kernel_stats.csv')) if '_bench_' not in os.path.basename(f)),
+                   reverse=True)
     for path in paths:
         tot, calls = 0.0, 0
         for row in csv.DictReader(open(path)):
-            if kname(row['Name']) == kernel and (kvariant(row['Name']) or 'dense') == variant:
+            if kname(row['Name']) == kernel and kvariant(row['Name']) == variant:     # None (the name cannot tell the variant): skipped
                 tot += float(row['TotalDurationNs']); calls += int(row['Calls'])
         if calls:
             return tot / calls / 1e3, os.path.relpath(path, ROOT)

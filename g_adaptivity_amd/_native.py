@@ -68,6 +68,7 @@ PROTOTYPES = {
     'gadapt_gat_plus_block_forward': (_I, [_G, _P, _I, _P, _P, _L, _F, _I, _I, _I, _P, _P, _I, _P]),
     'gadapt_gat_plus_block_backward': (_I, [_G, _P, _P, _P, _P, _I, _P, _P, _L, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'gadapt_gat_plus_partial_rows': (_I, [_L, _I]),
+    'gadapt_gather_fields': (_I, [_I, _P, _P, _P, _P, _I, _P]),
     'gadapt_profile_enable': (_I, [_I]),
     'gadapt_profile_read': (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'gadapt_profile_samples': (_I, [_I, C.POINTER(C.c_double), _I]),

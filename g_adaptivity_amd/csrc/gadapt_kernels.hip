@@ -792,6 +792,45 @@ extern "C" int gadapt_allreduce_flat(void* comm, float* bucket, int64_t n, int a
     return GADAPT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// batch assembly on the device: sample rows of up to GADAPT_GATHER_MAX stacked per-sample fields -> the batch's node fields
+// ------------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const float* src[GADAPT_GATHER_MAX]; float* dst[GADAPT_GATHER_MAX]; int64_t row[GADAPT_GATHER_MAX];   // row: floats per sample
+    const int64_t* idx; int n_fields, n_take;
+};
+__global__ __launch_bounds__(256) void gather_fields_kernel(GatherArgs p) {
+    const int f = blockIdx.z, b = blockIdx.y;
+    if (f >= p.n_fields) return;
+    const int64_t row = p.row[f];
+    const float* s = p.src[f] + p.idx[b] * row;
+    float* d = p.dst[f] + (int64_t)b * row;
+    if ((row & 3) == 0 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+        const int64_t n4 = row >> 2;
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256)
+            reinterpret_cast<float4*>(d)[e] = reinterpret_cast<const float4*>(s)[e];
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < row; e += (int64_t)gridDim.x * 256) d[e] = s[e];
+    }
+}
+extern "C" int gadapt_gather_fields(int n_fields, const float* const* src, float* const* dst, const int64_t* row_floats, const int64_t* idx,
+                                    int n_take, void* stream) {
+    if (n_fields <= 0 || n_fields > GADAPT_GATHER_MAX || !src || !dst || !row_floats || !idx || n_take <= 0)
+        return fail(GADAPT_E_BADARG, "gather_fields: 1..GADAPT_GATHER_MAX fields, a sample index vector and a positive count");
+    GatherArgs p{};
+    int64_t longest = 0;
+    for (int f = 0; f < n_fields; ++f) {
+        if (!src[f] || !dst[f] || row_floats[f] <= 0) return fail(GADAPT_E_BADARG, "gather_fields: null field or empty row");
+        p.src[f] = src[f]; p.dst[f] = dst[f]; p.row[f] = row_floats[f];
+        longest = row_floats[f] > longest ? row_floats[f] : longest;
+    }
+    p.idx = idx; p.n_fields = n_fields; p.n_take = n_take;
+    int bx = (int)((longest / 4 + 255) / 256);
+    bx = bx < 1 ? 1 : (bx > 32 ? 32 : bx);
+    hipLaunchKernelGGL(gather_fields_kernel, dim3(bx, n_take, n_fields), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return check_launch("gather_fields_kernel");
+}
+
 extern "C" int gadapt_pad_columns(const float* g_phys, float* g_top, int64_t n_nodes, int d, int c, void* stream) {
     if (!g_phys || !g_top || n_nodes <= 0 || d <= 0 || d > c || c % 4) return fail(GADAPT_E_BADARG, "pad_columns: bad argument");
     const int64_t n = n_nodes * (c / 4);

@@ -283,7 +283,6 @@ class GNN(nn.Module):
                 out0 = x_all[0]
             else:
                 out0 = None
-            learnable = o.get('learn_step') or o.get('softmax_temp_type') == 'learnable_a'
             if (o.get('compact_slots', True) and native_in and x_all is not None and o['num_layers'] >= 2 and o['hidden_dim'] >= 8
                     and self.enc.weight.shape[1] <= 4 and self._enc_is_zero_pad()):
                 # identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the compact [N,4] features, the padded

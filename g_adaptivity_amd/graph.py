@@ -75,10 +75,14 @@ def _fp_mix(v: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """Position-dependent NON-LINEAR mix of every element (splitmix64 finaliser of v_i + (i+1) * golden ratio).  A linear
     checksum pair (sum of v_i * (i+1), sum of v_i) collides on structured edits - e.g. flipping the diagonal of one grid quad,
     (a, a+n+1) -> (a+1, a+n) in place in both directions, keeps both sums - and would hand back a stale CSR."""
-    z = v + w * _FP_GOLD
-    z = (z ^ (z >> 30)) * _FP_M1
-    z = (z ^ (z >> 27)) * _FP_M2
-    return z ^ (z >> 31)
+    z = w * _FP_GOLD                      # the one [n] temporary of the chain; every later step works in place on it and on `t`
+    z.add_(v)
+    t = z >> 30
+    z.bitwise_xor_(t).mul_(_FP_M1)
+    torch.bitwise_right_shift(z, 27, out=t)
+    z.bitwise_xor_(t).mul_(_FP_M2)
+    torch.bitwise_right_shift(z, 31, out=t)
+    return z.bitwise_xor_(t)
 
 
 def content_fingerprint(tensors) -> Tuple:

@@ -403,6 +403,25 @@ class DeviceMeshLoader:
             t = self._templates[b] = t.to(self.device)
         return t
 
+    def _gather(self, idx: torch.Tensor, dsts) -> None:
+        """dst_k[b] = field_k[idx[b]] for every field: ONE launch (`gadapt_gather_fields`) for the fp32 fields on the GPU, torch's
+        index_select for anything else."""
+        native = self.device.type == 'cuda' and all(s_.dtype == torch.float32 and s_.is_contiguous() and d_.is_contiguous()
+                                                     for s_, d_ in zip(self.fields.values(), dsts)) and len(dsts) <= 8
+        if not native:
+            for stacked, dst in zip(self.fields.values(), dsts):
+                torch.index_select(stacked, 0, idx, out=dst.view(idx.numel(), *stacked.shape[1:]))
+            return
+        import ctypes as C
+        from . import _native
+        k = len(dsts)
+        src = (C.c_void_p * k)(*[s_.data_ptr() for s_ in self.fields.values()])
+        dst = (C.c_void_p * k)(*[d_.data_ptr() for d_ in dsts])
+        rows = (C.c_int64 * k)(*[s_[0].numel() for s_ in self.fields.values()])
+        idx = idx.to(torch.int64).contiguous()
+        _native.check(_native.lib().gadapt_gather_fields(k, src, dst, rows, idx.data_ptr(), int(idx.numel()),
+                                                        _native.current_stream(self.device)), 'gadapt_gather_fields')
+
     def __iter__(self) -> Iterable[MeshData]:
         n = len(self.dataset)
         if self.shuffle:
@@ -415,17 +434,17 @@ class DeviceMeshLoader:
             b = int(idx.numel())
             static = self._static.get(b)
             if static is not None:                                    # gathers land in the captured step's input buffers
-                for k, stacked in self.fields.items():
-                    dst = getattr(static, k)
-                    torch.index_select(stacked, 0, idx, out=dst.view(b, *stacked.shape[1:]))
+                self._gather(idx, [getattr(static, k) for k in self.fields])
                 static.idx = idx
                 yield static
                 continue
             out = copy.copy(self._template(b))                        # shares the topology tensors
             out.__dict__ = dict(out.__dict__)
-            for k, stacked in self.fields.items():
-                sel = stacked.index_select(0, idx)
-                out.__dict__[k] = sel.reshape(-1, *sel.shape[2:])
+            dsts = [torch.empty(b * stacked.shape[1], *stacked.shape[2:], device=self.device, dtype=stacked.dtype)
+                    for stacked in self.fields.values()]
+            self._gather(idx, dsts)
+            for k, dst in zip(self.fields, dsts):
+                out.__dict__[k] = dst
             out.idx = idx
             if self.into is not None:
                 self._static[b] = self.into(out)                      # captured on first use, initialised with this batch's fields

@@ -276,6 +276,14 @@ int gadapt_loss_forward(const float* pred, int64_t pred_stride, const float* tar
                         int l1, float* seed, float* loss_out, float* scratch, void* stream);
 int gadapt_loss_scratch_floats(void);
 
+/* Batch assembly on the device (what PyG's DataLoader collation does on the host for the node fields, run_GNN.py:72-76, for a
+ * dataset whose samples share one mesh): for up to GADAPT_GATHER_MAX fields k, dst[k][b, :] = src[k][idx[b], :] for b < n_take, rows
+ * of row_floats[k] floats (x_comp, x_phys, f_tensor, uu_tensor ... stacked per sample).  idx: int64 on the device.  src / dst /
+ * row_floats are host arrays of n_fields entries (device pointers inside).  One launch per batch. */
+#define GADAPT_GATHER_MAX 8
+int gadapt_gather_fields(int n_fields, const float* const* src, float* const* dst, const int64_t* row_floats, const int64_t* idx,
+                         int n_take, void* stream);
+
 /* Backward of the slice x_phys = x_top[:, :d] (GNN.py:299): g_top [N,C] = g_phys [N,d] zero-padded. */
 int gadapt_pad_columns(const float* g_phys, float* g_top, int64_t n_nodes, int d, int c, void* stream);
 

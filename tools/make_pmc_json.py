@@ -30,7 +30,8 @@ def name(n):
 
 
 def variant(n):
-    """Variant names of bench.py (VARIANT_NAMES) from the template arguments in the kernel name; None = dense / not told apart."""
+    """Variant names of bench.py (VARIANT_NAMES) from the template arguments in the kernel name: 'dense' where the name says so,
+    None where the name cannot tell (the tiled forward's head-only output is a run-time argument): callers skip those."""
     try:
         a = n[n.index('<') + 1:n.index('>')].replace(' ', '').split(',')
     except ValueError:
@@ -48,7 +49,9 @@ def variant(n):
         return 'compact_g' if len(a) > 1 and a[1] == 'true' else 'dense'
     if 'wide::fwd' in n:                                    # <XC, BIG, HEAD>
         a += ['false'] * (3 - len(a))
-        return 'compact_x' if a[0] == 'true' else 'head_only_out' if a[2] == 'true' else None
+        return 'compact_x' if a[0] == 'true' else 'head_only_out' if a[2] == 'true' else 'dense'
+    if 'grand_fwd' in n:                                    # <C, XC>; head-only output: run-time argument
+        return 'compact_x' if len(a) > 1 and a[1] == 'true' else None
     return None
 
 
