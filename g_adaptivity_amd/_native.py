@@ -50,6 +50,7 @@ PROTOTYPES = {
     'gadapt_edge_softmax_backward': (_I, [_G, _P, _P, _P, _P]),
     'gadapt_edge_combine': (_I, [_G, _P, _P, _P, _I, _P]),
     'gadapt_edge_rowsum': (_I, [_G, _I, _P, _P, _P]),
+    'gadapt_edge_vector_op': (_I, [_G, _I, _P, _P, _P, _P, _I, _P]),
     'gadapt_loss_forward': (_I, [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P]),
     'gadapt_loss_scratch_floats': (_I, []),
     'gadapt_layer_forward': (_I, [_G, _P, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -40,9 +40,6 @@ class _AttentionDiffusionBase(nn.Module):
             if in_channels[0] != in_channels[1]:
                 raise NotImplementedError("bipartite in_channels are not used by the reference's get_conv")
             in_channels = in_channels[0]
-        if edge_dim is not None:
-            raise NotImplementedError("edge_dim: get_conv passes edge_dim=None (src/GNN.py:119); per-edge key / value terms "
-                                      "(src/GRAND_plus.py:271-277,338-340) are not built")
         if in_channels != heads * out_channels:
             # value = Identity(x).view(-1, H, C) (GRAND_plus.py:150,227): the view needs in_channels == H C
             raise NotImplementedError(f"identity value map needs in_channels == heads * out_channels (src/GRAND_plus.py:150,227): "
@@ -54,16 +51,17 @@ class _AttentionDiffusionBase(nn.Module):
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
         self.root_weight = bool(root_weight)
         self.concat, self.beta = concat, bool(beta and root_weight)        # GRAND_plus.py:137
-        self.dropout, self.edge_dim = float(dropout), None
+        self.dropout, self.edge_dim = float(dropout), edge_dim
         self.lin_key = nn.Linear(in_channels, heads * out_channels)        # GRAND_plus.py:146
         self.lin_query = nn.Linear(in_channels, heads * out_channels)      # GRAND_plus.py:147
         self.lin_value = nn.Identity()                                     # GRAND_plus.py:150
         skip_out = heads * out_channels if concat else out_channels        # GRAND_plus.py:168-181
         self.lin_skip = nn.Linear(in_channels, skip_out, bias=skip_bias)   # used only with root_weight (GRAND_plus.py:244-250)
-        self.lin_edge = None
+        # GRAND_plus.py:165-168: a per-edge term on key and value (get_conv passes edge_dim=None, src/GNN.py:119)
+        self.lin_edge = nn.Linear(edge_dim, heads * out_channels, bias=False) if edge_dim is not None else None
         self.lin_beta = nn.Linear(3 * skip_out, 1, bias=False) if self.beta else None
         # the fused kernels carry what get_conv builds: one head, no root term, no attention dropout
-        self._general = heads > 1 or self.root_weight or self.dropout > 0.0
+        self._general = heads > 1 or self.root_weight or self.dropout > 0.0 or edge_dim is not None
         self._alpha = None
         self._stored = None            # (graph, alpha in target-CSR order) of the last call
         self.stored_ei = None
@@ -88,6 +86,8 @@ class _AttentionDiffusionBase(nn.Module):
         self.lin_key.reset_parameters()
         self.lin_query.reset_parameters()
         self.lin_skip.reset_parameters()
+        if self.lin_edge is not None:
+            self.lin_edge.reset_parameters()
         if self.lin_beta is not None:
             self.lin_beta.reset_parameters()
 
@@ -99,14 +99,15 @@ class _AttentionDiffusionBase(nn.Module):
         t = self._temperature()
         return s if t is None else s / t
 
-    def _residual(self, x, edge_index, graph: Optional[MeshGraph], want_alpha: bool, edge_weight: Optional[torch.Tensor] = None):
+    def _residual(self, x, edge_index, graph: Optional[MeshGraph], want_alpha: bool, edge_weight: Optional[torch.Tensor] = None,
+                  edge_attr: Optional[torch.Tensor] = None):
         """A(x)x - x and the attention (target-CSR order).  The fused kernels carry the hidden sizes they are built for;
         any other width, and scores with a per-edge factor (`reg_skew`), take the same arithmetic through the generic
         primitives (Q/K projections as dense GEMMs, sddmm -> edge softmax -> spmm in HIP)."""
         if graph is None:
             graph = graph_for(edge_index, x.shape[0], x.device)
-        if self._general:
-            return self._residual_general(x, graph, edge_weight)
+        if self._general or edge_attr is not None:
+            return self._residual_general(x, graph, edge_weight, edge_attr)
         if edge_weight is None and x.shape[1] in SUPPORTED_HIDDEN:
             res, alpha_t = Fn.grand_residual(x, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
                                              self.lin_key.bias, self._scale(x.device), graph, want_alpha)
@@ -122,7 +123,7 @@ class _AttentionDiffusionBase(nn.Module):
             return t.reshape(-1)[h]
         return t
 
-    def _residual_general(self, x, graph: MeshGraph, edge_weight: Optional[torch.Tensor]):
+    def _residual_general(self, x, graph: MeshGraph, edge_weight: Optional[torch.Tensor], edge_attr: Optional[torch.Tensor] = None):
         """The constructor options get_conv never passes (`src/GRAND_plus.py:114-183,239-250,336`): H heads over slices of x
         (value = Identity(x).view(-1, H, C)), concatenation of the heads, `root_weight` / `beta`, attention dropout.  Per head the
         generic primitives (sddmm -> edge softmax -> spmm in HIP); projections, skip and gate are dense torch GEMMs."""
@@ -130,11 +131,30 @@ class _AttentionDiffusionBase(nn.Module):
         q = torch.nn.functional.linear(x, self.lin_query.weight, self.lin_query.bias).view(n, hd, c)    # GRAND_plus.py:225
         k = torch.nn.functional.linear(x, self.lin_key.weight, self.lin_key.bias).view(n, hd, c)        # :226
         v = x.view(n, hd, c)                                                                            # :227
+        # edge features (GRAND_plus.py:273-277,338-340): caller's edge order -> the graph's target-CSR slots (a re-ordering of the
+        # INPUT, once per call); lin_edge(edge_attr) joins the key and the value, a bare edge_attr (no lin_edge) the value only -
+        # the reference tests `edge_attr is not None` at :339
+        e_key = e_val = None
+        if self.lin_edge is not None:
+            assert edge_attr is not None                                                                # :274
+        if edge_attr is not None:
+            ea = edge_attr.to(x.dtype).index_select(0, graph.eid_t.long())
+            if self.lin_edge is not None:
+                e_key = e_val = self.lin_edge(ea).view(-1, hd, c)                                       # :275-277
+            else:
+                e_val = ea.reshape(-1, hd, c)
+        pad = (-c) % 4                                                                                  # the per-edge-vector primitives take C % 4 == 0
+
+        def _p(t):
+            return torch.nn.functional.pad(t, (0, pad)).contiguous() if pad else t.contiguous()
         outs, alphas = [], []
         for h in range(hd):
             scale = 1.0 / math.sqrt(c)
             t = self._head_temperature(h)
-            s_ = Sp.sddmm(graph, q[:, h].contiguous(), k[:, h].contiguous()) * scale                    # :279
+            s_ = Sp.sddmm(graph, q[:, h].contiguous(), k[:, h].contiguous())
+            if e_key is not None:
+                s_ = s_ + Sp.edge_node_dot(graph, _p(q[:, h]), _p(e_key[:, h]))                         # <query_i, key_j + edge_e>
+            s_ = s_ * scale                                                                             # :279
             if edge_weight is not None:
                 s_ = s_ * edge_weight                                                                   # :324
             if t is not None:
@@ -142,7 +162,10 @@ class _AttentionDiffusionBase(nn.Module):
             a = Sp.edge_softmax(graph, s_)                                                              # :333
             alphas.append(a)
             a = torch.nn.functional.dropout(a, p=self.dropout, training=self.training)                  # :336
-            outs.append(Sp.spmm(graph, a, v[:, h].contiguous()))                                        # :338-343, aggr='add'
+            o_h = Sp.spmm(graph, a, v[:, h].contiguous())                                               # :338-343, aggr='add'
+            if e_val is not None:
+                o_h = o_h + Sp.edge_weighted_rowsum(graph, a, _p(e_val[:, h]))[:, :c]                   # sum_e alpha_e edge_e
+            outs.append(o_h)
         out = torch.cat(outs, dim=1) if self.concat else outs[0]                                        # :239-242 (mean over ONE head)
         if self.root_weight:                                                                            # :244-250
             x_r = self.lin_skip(x)
@@ -189,7 +212,8 @@ class GRAND_plusConv(_AttentionDiffusionBase):
 
     def forward(self, x, edge_index, global_features=None, mesh=None, edge_attr=None,
                 return_attention_weights=None, graph: Optional[MeshGraph] = None):
-        assert edge_attr is None, "edge_attr needs lin_edge (edge_dim), which get_conv never builds"
+        if self.lin_edge is not None:
+            assert edge_attr is not None                                   # GRAND_plus.py:274
         self.mesh_points, self.mesh = x, mesh                              # GRAND_plus.py:229-230
         if self.opt.get('softmax_temp_type') == 'learnable_v':
             # GRAND_plus.py:330-331 applies Linear(C, heads) to the [E, heads] score tensor and then .squeeze(2) a 2-D
@@ -204,7 +228,7 @@ class GRAND_plusConv(_AttentionDiffusionBase):
             if graph is None:
                 graph = graph_for(edge_index, x.shape[0], x.device)
             edge_weight = self._edge_area_sum(x, mesh, graph)
-        res, alpha_t, graph = self._residual(x, edge_index, graph, want_alpha, edge_weight)
+        res, alpha_t, graph = self._residual(x, edge_index, graph, want_alpha, edge_weight, edge_attr)
         if store:
             self.stored_ei, self._stored = edge_index, (graph, _detached(alpha_t))
         if isinstance(return_attention_weights, bool):                     # GRAND_plus.py:259-262

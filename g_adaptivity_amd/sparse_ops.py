@@ -159,6 +159,66 @@ class _EdgeCombine(torch.autograd.Function):
         return du, dv, None, None
 
 
+def _edge_vec_raw(graph: MeshGraph, mode: int, w, a, b, c: int) -> torch.Tensor:
+    dev = (b if b is not None else a).device
+    e = max(graph.num_edges, 1)
+    out = torch.empty((e,) if mode == 0 else ((graph.num_nodes, c) if mode == 1 else (e, c)), device=dev, dtype=torch.float32)
+    check(lib().gadapt_edge_vector_op(graph.c_ref, mode, ptr(w), ptr(a), ptr(b), ptr(out), c, current_stream(dev)), 'gadapt_edge_vector_op')
+    return out[:graph.num_edges] if mode != 1 else out
+
+
+class _EdgeNodeDot(torch.autograd.Function):
+    """s_e = <a_i, B_e>, i = target of e; B [E,C] per-edge vectors in target-CSR order."""
+
+    @staticmethod
+    def forward(ctx, a, b, graph: MeshGraph):
+        a, b = _dev(a, 'edge_node_dot a'), _dev(b, 'edge_node_dot b')
+        if a.shape[0] != graph.num_nodes or b.shape != (graph.num_edges, a.shape[1]) or a.shape[1] % 4:
+            raise ValueError(f"edge_node_dot: a {tuple(a.shape)}, b {tuple(b.shape)} for {graph.num_nodes} nodes / {graph.num_edges} edges (C % 4 == 0)")
+        ctx.graph = graph
+        ctx.save_for_backward(a, b)
+        return _edge_vec_raw(graph, 0, None, a, b, a.shape[1])
+
+    @staticmethod
+    def backward(ctx, ds):
+        a, b = ctx.saved_tensors
+        ds = ds.contiguous()
+        da = _edge_vec_raw(ctx.graph, 1, ds, None, b, a.shape[1]) if ctx.needs_input_grad[0] else None
+        db = _edge_vec_raw(ctx.graph, 2, ds, a, None, a.shape[1]) if ctx.needs_input_grad[1] else None
+        return da, db, None
+
+
+class _EdgeWeightedRowsum(torch.autograd.Function):
+    """out_i = sum over the in-edges e of i of w_e B_e."""
+
+    @staticmethod
+    def forward(ctx, w, b, graph: MeshGraph):
+        w, b = _dev(w, 'edge_weighted_rowsum w'), _dev(b, 'edge_weighted_rowsum b')
+        if w.numel() != graph.num_edges or b.shape[0] != graph.num_edges or b.shape[1] % 4:
+            raise ValueError("edge_weighted_rowsum: w [E], b [E,C] with C % 4 == 0 expected")
+        ctx.graph = graph
+        ctx.save_for_backward(w, b)
+        return _edge_vec_raw(graph, 1, w.reshape(-1), None, b, b.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        w, b = ctx.saved_tensors
+        g = g.contiguous()
+        dw = _edge_vec_raw(ctx.graph, 0, None, g, b, b.shape[1]).view_as(w) if ctx.needs_input_grad[0] else None
+        db = _edge_vec_raw(ctx.graph, 2, w.reshape(-1), g, None, b.shape[1]) if ctx.needs_input_grad[1] else None
+        return dw, db, None
+
+
+def edge_node_dot(graph: MeshGraph, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[E] s_e = <a_i, b_e> for e: j -> i; `b` [E,C] in target-CSR order (the <query_i, lin_edge(edge_attr)_e> term, GRAND_plus.py:273-279)."""
+    return _EdgeNodeDot.apply(a, b, graph)
+
+
+def edge_weighted_rowsum(graph: MeshGraph, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[N,C] out_i = sum over in-edges of w_e b_e (the alpha-weighted edge term of the message, GRAND_plus.py:338-342)."""
+    return _EdgeWeightedRowsum.apply(w, b, graph)
+
+
 def spmm(graph: MeshGraph, w: Optional[torch.Tensor], x: torch.Tensor) -> torch.Tensor:
     """[N,C] aggregation out_i = sum over in-edges j->i of w_e x_j (`w=None`: plain sum); w in target-CSR order."""
     return _SpMM.apply(w, x, graph)

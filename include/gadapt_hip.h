@@ -233,6 +233,12 @@ int gadapt_edge_softmax_forward(const gadapt_graph* g, const float* scores, floa
 int gadapt_edge_softmax_backward(const gadapt_graph* g, const float* alpha, const float* d_alpha, float* d_scores, void* stream);
 int gadapt_edge_combine(const gadapt_graph* g, const float* u_src, const float* v_dst, float* out, int op, void* stream);
 int gadapt_edge_rowsum(const gadapt_graph* g, int by_source, const float* edge_vals, float* out, void* stream);
+/* Per-edge VECTORS b [E,C] in target-CSR order (the conv option edge_dim / lin_edge, GRAND_plus.py:165-166: a per-edge term on
+ * key and value, :273-277,338-340).  i = the target (row) of edge e.  C a multiple of 4.
+ *   mode 0  s_e   = <a_i, b_e>                   out [E]      (score term <query_i, edge_e>; d w of mode 1)
+ *   mode 1  out_i = sum_{e in row i} w_e b_e     out [N,C]    (aggregated edge term; d a of mode 0)
+ *   mode 2  out_e = w_e a_i                      out [E,C]    (d b of modes 0 and 1)                                      */
+int gadapt_edge_vector_op(const gadapt_graph* g, int mode, const float* w, const float* a, const float* b, float* out, int c, void* stream);
 
 /* ------------------------------------------------------------------ GAT_plus block (fused)
  * Replaces, for conv_type = 'GAT_plus' (get_conv, GNN.py:120-121), the L iterations of GNN.forward's layer loop (GNN.py:273-296)

@@ -93,19 +93,26 @@ def grand_residual(x, edge_index, w_query, b_query, w_key, b_key,
 
 def grand_plus_general(x, edge_index, w_query, b_query, w_key, b_key, heads: int = 1, concat: bool = True,
                        w_skip=None, b_skip=None, w_beta=None, temperature=None, dropout_mask=None,
-                       return_attention: bool = False):
+                       return_attention: bool = False, w_edge=None, edge_attr=None):
     """`GRAND_plusConv.forward` with the constructor options `get_conv` never passes (`src/GRAND_plus.py:114-183,204-267,
     269-343`): H heads (value = Identity(x).view(-1, H, C): needs in_channels = H C), concat / mean over the heads,
     `root_weight` (`w_skip`, `b_skip` given: `lin_skip`), `beta` (`w_beta` given: `lin_beta`), attention dropout as an explicit
     per-edge, per-head mask of 0 / 1/(1-p) factors (`dropout_mask [E,H]`: what F.dropout multiplies with, :336).
-    `temperature`: scalar or [1,H,1] (`sm_temp_a`).  Returns out - x (:267)."""
+    `temperature`: scalar or [1,H,1] (`sm_temp_a`).  `w_edge` [H C, edge_dim] (`lin_edge`, :165-166) with `edge_attr [E, edge_dim]`:
+    the projected edge features are added to the key (:273-277) and to the value (:338-340); `edge_attr` WITHOUT `w_edge` is added
+    to the value as it is (:339 tests `edge_attr is not None`, not `lin_edge`), so it must already be [E, H C].  Returns out - x (:267)."""
     n = x.shape[0]
     c = w_query.shape[0] // heads
     src, dst = edge_index[0], edge_index[1]
     query = F.linear(x, w_query, b_query).view(-1, heads, c)     # :225
     key = F.linear(x, w_key, b_key).view(-1, heads, c)           # :226
     value = x.view(-1, heads, c)                                 # :150,:227
-    alpha = (query.index_select(0, dst) * key.index_select(0, src)).sum(dim=-1) / math.sqrt(c)     # [E,H] :279
+    key_j = key.index_select(0, src)
+    if w_edge is not None:
+        assert edge_attr is not None                             # :274
+        edge_attr = F.linear(edge_attr, w_edge).view(-1, heads, c)   # :275-276
+        key_j = key_j + edge_attr                                # :277
+    alpha = (query.index_select(0, dst) * key_j).sum(dim=-1) / math.sqrt(c)     # [E,H] :279
     if temperature is not None:
         t = temperature if not torch.is_tensor(temperature) else (temperature.squeeze(2) if temperature.dim() == 3 else temperature)
         alpha = alpha / t                                        # :35-37,:326-329 (sm_temp_a.squeeze(2): [1,H])
@@ -113,7 +120,10 @@ def grand_plus_general(x, edge_index, w_query, b_query, w_key, b_key, heads: int
     kept = alpha
     if dropout_mask is not None:
         alpha = alpha * dropout_mask                             # :336
-    msg = value.index_select(0, src) * alpha.view(-1, heads, 1)  # :342
+    value_j = value.index_select(0, src)
+    if edge_attr is not None:
+        value_j = value_j + edge_attr.view(-1, heads, c)         # :338-340
+    msg = value_j * alpha.view(-1, heads, 1)                     # :342
     out = torch.zeros(n, heads, c, dtype=x.dtype, device=x.device).index_add_(0, dst, msg)
     out = out.view(-1, heads * c) if concat else out.mean(dim=1) # :239-242
     if w_skip is not None:                                       # root_weight :244-250

@@ -237,3 +237,39 @@ def test_triangle_edge_area_sum_matches_the_reference_loop():
             want[e] = sum(area[k % len(cells)] for k in hits)
     assert torch.allclose(got, want, rtol=0, atol=1e-15)
     assert (want > 0).any() and (want == 0).any()                        # oriented matching: some directed edges get no triangle
+
+
+def test_edge_features_against_a_dense_loop():
+    """`edge_dim` / `lin_edge` (`src/GRAND_plus.py:165-166,273-277,338-340`) in the oracle's general restatement against an
+    explicit per-target loop: projected edge features join the key and the value; two heads, concatenated."""
+    import math
+    from oracle.pyg_restatement import grand_plus_general
+    torch.manual_seed(0)
+    n, c, H, ed = 7, 4, 2, 3
+    x = torch.randn(n, H * c, dtype=torch.float64)
+    ei = torch.tensor([[0, 1, 2, 3, 4, 5, 6, 0, 2, 4], [1, 2, 3, 4, 5, 6, 0, 3, 5, 1]])
+    wq, wk = torch.randn(H * c, H * c, dtype=torch.float64), torch.randn(H * c, H * c, dtype=torch.float64)
+    bq, bk = torch.randn(H * c, dtype=torch.float64), torch.randn(H * c, dtype=torch.float64)
+    we, ea = torch.randn(H * c, ed, dtype=torch.float64), torch.randn(ei.shape[1], ed, dtype=torch.float64)
+    res = grand_plus_general(x, ei, wq, bq, wk, bk, heads=H, concat=True, w_edge=we, edge_attr=ea)
+    q, k, v = (x @ wq.T + bq).view(n, H, c), (x @ wk.T + bk).view(n, H, c), x.view(n, H, c)
+    e = (ea @ we.T).view(-1, H, c)
+    out = torch.zeros(n, H, c, dtype=torch.float64)
+    for i in range(n):
+        es = [t for t in range(ei.shape[1]) if ei[1, t] == i]
+        for h in range(H):
+            s = torch.stack([(q[i, h] * (k[ei[0, t], h] + e[t, h])).sum() / math.sqrt(c) for t in es])
+            for w_, t in zip(torch.softmax(s, 0), es):
+                out[i, h] += w_ * (v[ei[0, t], h] + e[t, h])
+    assert (out.view(n, -1) - x - res).abs().max().item() <= 1e-12
+    # a bare edge_attr (no lin_edge) joins the value only (:339)
+    bare = torch.randn(ei.shape[1], H * c, dtype=torch.float64)
+    res2 = grand_plus_general(x, ei, wq, bq, wk, bk, heads=H, concat=True, edge_attr=bare)
+    out2 = torch.zeros(n, H, c, dtype=torch.float64)
+    for i in range(n):
+        es = [t for t in range(ei.shape[1]) if ei[1, t] == i]
+        for h in range(H):
+            s = torch.stack([(q[i, h] * k[ei[0, t], h]).sum() / math.sqrt(c) for t in es])
+            for w_, t in zip(torch.softmax(s, 0), es):
+                out2[i, h] += w_ * (v[ei[0, t], h] + bare[t].view(H, c)[h])
+    assert (out2.view(n, -1) - x - res2).abs().max().item() <= 1e-12
