@@ -45,6 +45,22 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X fp32 matrix (= vector) peak, SURVEY.md §8(d)
 
 
+def algorithmic_bytes_gat(kernel, n_nodes, n_edges, c, variant=0):
+    """Fused GAT_plus layer launches (csrc/gadapt_gat.inc), counted the way SURVEY.md 8(d) counts the GRAND layer: every node
+    matrix a launch must read or write once, int32 CSR, per-edge and per-node scalars (alpha, d z, a, b) as 4 bytes each."""
+    csr = 4 * (n_edges + n_nodes + 1)
+    dense = 4 * n_nodes * c
+    if kernel == 'forward':            # read x, write x'; alpha out, a / b in and out
+        return 2 * dense + csr + 4 * n_edges + 16 * n_nodes
+    if kernel == 'backward_target':    # read x and g, write g_r; alpha in, d z out, a / b in, d b out
+        return 3 * dense + csr + 8 * n_edges + 12 * n_nodes
+    if kernel == 'backward_source':    # read x (partials), g and g_r, write d x; alpha and d z in (through perm_s), d b in
+        if variant & 16:               # layer 0 without d x0: parameter partials only
+            return dense + csr + 8 * n_edges + 4 * n_nodes
+        return 4 * dense + csr + 12 * n_edges + 4 * n_nodes
+    raise KeyError(kernel)
+
+
 def algorithmic_bytes(kernel, n_nodes, n_edges, c, variant=0, dim=2):
     """compulsory traffic of one layer launch over the whole batch (fp32, int32 CSR).
 
@@ -64,7 +80,7 @@ def algorithmic_bytes(kernel, n_nodes, n_edges, c, variant=0, dim=2):
     raise KeyError(kernel)
 
 
-VARIANT_NAMES = {0: 'dense', 1: 'compact_g', 2: 'compact_x', 4: 'head_only_out', 6: 'compact_x+head_only_out', 8: 'out4', 9: 'compact_g+out4'}
+VARIANT_NAMES = {16: 'partials_only', 0: 'dense', 1: 'compact_g', 2: 'compact_x', 4: 'head_only_out', 6: 'compact_x+head_only_out', 8: 'out4', 9: 'compact_g+out4'}
 
 
 def load_pmc(workload):
@@ -325,6 +341,8 @@ def main():
         p1, p2 = median_of(3), median_of(4)
         event_overhead_ms = min(max(2.0 * p1 - p2, 0.0), p1)          # D = 2 p1 - p2 (see gadapt_profile_calibrate)
         graph_obj = next(iter(model._graphs.values()))
+        if w['conv'] == 'GAT_plus':
+            graph_obj = graph_obj.with_self_loops()                   # the graph the GAT_plus kernels walk (GATConv's self-loops)
         n_nodes, n_edges = graph_obj.num_nodes, graph_obj.num_edges
         for kid, name in enumerate(('forward', 'backward_target', 'backward_source')):
             cap = 4 * args.steps * w['layers'] + 16
@@ -348,7 +366,7 @@ def main():
                 # this is an upper bound of the kernel's own duration (conservative for the roofline).  The calibrated dispatch
                 # share is reported beside it (`net_us`), never subtracted from what prices `frac`.
                 raw_ms = max(sum(meds) / len(meds), 1e-6)
-                by = algorithmic_bytes(name, n_nodes, n_edges, w['hidden'], v)
+                by = (algorithmic_bytes_gat if w['conv'] == 'GAT_plus' else algorithmic_bytes)(name, n_nodes, n_edges, w['hidden'], v)
                 variants[VARIANT_NAMES.get(v, str(v))] = {'launches_per_step': len(meds), 'avg_us': round(raw_ms * 1e3, 2),
                                                           'net_us': round(max(raw_ms - event_overhead_ms, 1e-6) * 1e3, 2),
                                                           'alg_bytes_per_launch': by, 'achieved_GBs': round(by / (raw_ms * 1e-3) / 1e9, 1)}

@@ -251,7 +251,7 @@ class _GatPlusBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, att_src, att_dst, looped: MeshGraph, num_layers: int, dt: float, residual: bool, res_lap: bool, non_lin: int,
-                out_cols=None):
+                out_cols=None, x_all=None):
         for t, n in ((x0, 'x'), (att_src, 'att_src'), (att_dst, 'att_dst')):
             _require_gpu(t, n)
         n, c = x0.shape
@@ -263,8 +263,12 @@ class _GatPlusBlock(torch.autograd.Function):
         assert S in (1, L) and att_src.shape == (S, c) and att_dst.shape == (S, c)
         dev, st = x0.device, current_stream(x0.device)
         att_src, att_dst = att_src.contiguous(), att_dst.contiguous()
-        x_all = torch.empty(L + 1, n, c, device=dev, dtype=torch.float32)
-        x_all[0].copy_(x0)
+        if x_all is None:                      # else: the caller's [(L+1),N,C] buffer whose slot 0 already IS x0 (no copy)
+            x_all = torch.empty(L + 1, n, c, device=dev, dtype=torch.float32)
+            x_all[0].copy_(x0)
+        else:
+            x_all = x_all[0]                   # boxed in a list so autograd does not track it as an input
+            assert x_all.shape == (L + 1, n, c) and x_all.is_contiguous() and x_all.data_ptr() == x0.data_ptr()
         ab = torch.empty(L, 2, n, device=dev, dtype=torch.float32)
         alpha = torch.empty(L, max(looped.num_edges, 1), device=dev, dtype=torch.float32)
         check(lib().gadapt_gat_plus_block_forward(looped.c_ref, ptr(x_all), L, ptr(att_src), ptr(att_dst), c if S > 1 else 0, float(dt),
@@ -299,14 +303,16 @@ class _GatPlusBlock(torch.autograd.Function):
         check(lib().gadapt_gat_plus_block_backward(graph.c_ref, ptr(x_all), ptr(alpha), ptr(ab), ptr(g_top), L, ptr(att_src), ptr(att_dst),
                                                    c if S > 1 else 0, dt, residual, res_lap, non_lin, ptr(g_ws), ptr(gr_ws), ptr(dz_ws),
                                                    ptr(db_ws), ptr(part), ptr(d_att), ptr(d_x0), c, st), 'gadapt_gat_plus_block_backward')
-        return d_x0, d_att[:, 0], d_att[:, 1], None, None, None, None, None, None, None
+        return d_x0, d_att[:, 0], d_att[:, 1], None, None, None, None, None, None, None, None
 
 
 def gat_plus_block(x0: torch.Tensor, att_src: torch.Tensor, att_dst: torch.Tensor, looped: MeshGraph, num_layers: int, dt: float,
-                   residual: bool = True, res_lap: bool = True, non_lin: str = 'identity', out_cols: Optional[int] = None):
+                   residual: bool = True, res_lap: bool = True, non_lin: str = 'identity', out_cols: Optional[int] = None,
+                   x_all: Optional[torch.Tensor] = None):
     """(x_L [N,C] or its first `out_cols` columns, alpha [L,E] in the target-CSR order of `looped`): L fused GAT_plus layers with
     the update of `src/GNN.py:284-296`.  `looped` = `graph.with_self_loops()` (GATConv's edge surgery)."""
-    return _GatPlusBlock.apply(x0.contiguous(), att_src, att_dst, looped, num_layers, dt, residual, res_lap, NONLIN_CODES[non_lin], out_cols)
+    return _GatPlusBlock.apply(x0.contiguous(), att_src, att_dst, looped, num_layers, dt, residual, res_lap, NONLIN_CODES[non_lin], out_cols,
+                               None if x_all is None else [x_all])
 
 
 def score_scale(hidden_dim: int, temperature=None):

@@ -245,7 +245,13 @@ class GNN(nn.Module):
         glob = []                                                          # per-mesh CNN features, GNN.py:240-268
         if o.get('gnn_inc_glob_feat_f') or o.get('gnn_inc_glob_feat_uu'):
             batch = data.batch.to(dev)
-            n_meshes = int(data.batch.max().item()) + 1
+            # meshes in the batch: what collation recorded (`_num_graphs`, PyG's `Batch.num_graphs`) or the corner list's length -
+            # a host synchronisation on `batch.max()` only for a batch object that carries neither (it would break a hipGraph capture)
+            n_meshes = getattr(data, '_num_graphs', None)
+            if n_meshes is None and isinstance(getattr(data, 'corner_nodes', None), (list, tuple)) and self.dim == 2:
+                n_meshes = len(data.corner_nodes)
+            if n_meshes is None:
+                n_meshes = int(data.batch.max().item()) + 1
             mapping = getattr(data, 'mapping_tensor', None) if o.get('data_type') == 'randg_mix' else \
                 getattr(self.dataset, 'mapping_tensor', None)
             for flag, name, extractor in (('gnn_inc_glob_feat_f', 'f_tensor', 'global_feature_extractor_cnn_f'),
@@ -277,13 +283,13 @@ class GNN(nn.Module):
         elif isinstance(self.enc, nn.Linear) and not self.enc.weight.requires_grad and self.enc.bias is None:
             native_in = all(t is None or (t.dtype == torch.float32 and t.dim() == 1) for t in (f, uu)) and x_comp.dtype == torch.float32 \
                 and o['hidden_dim'] in Fn._native.SUPPORTED_HIDDEN         # the encoder kernel's row layouts; other widths: dense GEMM
-            if fusable and not (self.training and o.get('dropout', 0.0) > 0):
+            if (fusable or self._gat_plus_fusable()) and not (self.training and o.get('dropout', 0.0) > 0):
                 # encoder output lands in slot 0 of the block's activation buffer: no copy
                 x_all = torch.empty(o['num_layers'] + 1, n, o['hidden_dim'], device=dev, dtype=torch.float32)
                 out0 = x_all[0]
             else:
                 out0 = None
-            if (o.get('compact_slots', True) and native_in and x_all is not None and o['num_layers'] >= 2 and o['hidden_dim'] >= 8
+            if (fusable and o.get('compact_slots', True) and native_in and x_all is not None and o['num_layers'] >= 2 and o['hidden_dim'] >= 8
                     and self.enc.weight.shape[1] <= 4 and self._enc_is_zero_pad()):
                 # identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the compact [N,4] features, the padded
                 # [N,C] matrix is never written (nor read back by the layer-0 backward)
@@ -335,7 +341,8 @@ class GNN(nn.Module):
             att_dst = torch.stack([l.att_dst.reshape(-1) for l in distinct]) if len(distinct) > 1 else distinct[0].att_dst.reshape(1, -1)
             sliced = self.dec is None or isinstance(self.dec, nn.Identity)
             x, alpha = Fn.gat_plus_block(x, att_src, att_dst, looped, o['num_layers'], float(o['time_step']), bool(o['residual']),
-                                         o['gat_plus_type'] == 'GAT_res_lap', o['non_lin'], out_cols=self.dim if sliced else None)
+                                         o['gat_plus_type'] == 'GAT_res_lap', o['non_lin'], out_cols=self.dim if sliced else None,
+                                         x_all=x_all if (x_all is not None and x.data_ptr() == x_all.data_ptr()) else None)
             for l, layer in enumerate(self.conv_layers):                  # GRAND_plus.py:403-404,413-414: stored_ei / stored_alpha
                 layer.stored_ei, layer._stored = looped.edge_index, (looped, alpha[l])
         else:

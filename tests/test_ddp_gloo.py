@@ -152,16 +152,19 @@ def _run_w8(n_meshes):
     for p in procs:
         p.start()
     try:
-        got = q.get(timeout=300)
+        got = q.get(timeout=600)                                # eight single-threaded ranks on as many cores: minutes when the box is busy
     except Exception:
         got = None
     ok = got is not None
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=180)
         if p.is_alive():
             p.kill()
             ok = False
         ok = ok and p.exitcode == 0
+    if not ok:                                                  # say why, so a flaky rendezvous and a wrong result are told apart
+        print(f"[w8] run of {n_meshes} meshes failed: result {'received' if got is not None else 'missing'}, "
+              f"exit codes {[p.exitcode for p in procs]}", flush=True)
     return got if ok else None
 
 

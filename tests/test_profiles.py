@@ -56,7 +56,7 @@ def test_bench_line_roofline_is_reproducible_from_profiles():
     assert prof is not None, "no committed rocprofv3 kernel stats for the bench workload"
     tot = calls = 0
     for row in csv.DictReader(open(os.path.join(ROOT, prof['file']))):
-        if kname(row['Name']) == rf['kernel'] and (kvariant(row['Name']) or 'dense') == rf['variant']:
+        if kname(row['Name']) == rf['kernel'] and kvariant(row['Name']) == rf['variant']:
             tot += float(row['TotalDurationNs']); calls += int(row['Calls'])
     assert calls > 0
     csv_us = tot / calls / 1e3
