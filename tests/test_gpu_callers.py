@@ -160,13 +160,18 @@ def _free_port():
 
 @pytest.mark.one_dispatch
 @pytest.mark.gpu
-def test_two_rank_step_equals_full_batch_step(gpu_device):
+@pytest.mark.parametrize("graphed", [False, True], ids=['eager-step', 'graphed-step'])
+def test_two_rank_step_equals_full_batch_step(gpu_device, graphed):
     """Two ranks (fresh child processes sharing the one GPU of the test box, gloo for the collective - RCCL needs a GPU
     per rank) each run forward + backward on THEIR shard through the HIP kernels, all-reduce the flat gradient bucket and
     take the fused Adam step; the result must equal the single-process step on the full batch (equal shards: the mean of
-    the shard means is the full-batch mean).  This executes `FlatAdam.step()` behind a real reduce."""
+    the shard means is the full-batch mean).  This executes `FlatAdam.step()` behind a real reduce.  graphed-step: the same
+    through `GraphedTrainStep(capture_optimizer=False)` - forward + loss + backward replayed from a hipGraph captured in
+    thread_local mode inside a live process group, the gloo all-reduce and the device-stepped Adam issued eagerly on the
+    gradients of the replay."""
     port = _free_port()
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GADAPT_DDP_CHECK_OUT=os.path.join(ROOT, 'gpurun_out'))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GADAPT_DDP_CHECK_OUT=os.path.join(ROOT, 'gpurun_out'),
+               GADAPT_DDP_GRAPHED='1' if graphed else '0')
     os.makedirs(env['GADAPT_DDP_CHECK_OUT'], exist_ok=True)
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                         '--master-port', str(port), os.path.join(ROOT, 'tools', 'ddp_step_check.py')],
@@ -178,6 +183,7 @@ def test_two_rank_step_equals_full_batch_step(gpu_device):
     assert d['grad_rel_err'] <= 1e-5, d          # averaged shard gradients vs the full-batch gradient
     assert d['param_max_abs_diff'] <= 1e-6, d    # after 3 Adam steps (lr 1e-3)
     assert d['ranks_identical'] is True          # replicas stay bit-identical after the reduce
+    assert d['graphed'] == graphed
 
 
 @pytest.mark.one_dispatch

@@ -41,12 +41,19 @@ def main():
 
     torch.manual_seed(0)                                          # identical replicas
     model = GNN(ds, opt).to(dev).train()
-    optim = FlatAdam(model.parameters(), lr=opt['lr'])
+    graphed = os.environ.get('GADAPT_DDP_GRAPHED') == '1'       # the step as GraphedTrainStep: forward + loss + backward replayed,
+    optim = FlatAdam(model.parameters(), lr=opt['lr'], capturable=graphed)   # all-reduce + Adam eager after each replay (gloo cannot be captured)
     first_sum = None
+    if graphed:
+        from g_adaptivity_amd import GraphedTrainStep
+        step = GraphedTrainStep(model, optim, capture_optimizer=backend == 'nccl' and os.environ.get('GADAPT_DDP_CAPTURE_OPT') == '1')
     for _ in range(steps):
-        optim.zero_grad()
-        mse_loss(model(shard), shard.x_phys).backward()
-        optim.step()                                              # all-reduce (SUM) + Adam with the 1/world scale folded in
+        if graphed:
+            step(shard)
+        else:
+            optim.zero_grad()
+            mse_loss(model(shard), shard.x_phys).backward()
+            optim.step()                                          # all-reduce (SUM) + Adam with the 1/world scale folded in
         if first_sum is None:
             first_sum = optim.grad_bucket.detach().clone()        # the reduced bucket of step 1
     torch.cuda.synchronize()
@@ -73,7 +80,7 @@ def main():
         gerr = ((avg - ref_first).abs().max() / ref_first.abs().max()).item()
         pdiff = (optim.bucket - ref_optim.bucket).abs().max().item()
         print(json.dumps({'world': world, 'backend': backend, 'bucket_floats': int(optim.bucket.numel()), 'grad_rel_err': gerr,
-                          'param_max_abs_diff': pdiff, 'ranks_identical': bool(identical), 'steps': steps}))
+                          'param_max_abs_diff': pdiff, 'ranks_identical': bool(identical), 'steps': steps, 'graphed': graphed}))
     dist.barrier()
     dist.destroy_process_group()
 
