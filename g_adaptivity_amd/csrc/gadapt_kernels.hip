@@ -42,12 +42,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_WAVES_BWD_S
 #define GADAPT_WAVES_BWD_S 2
 #endif
-#ifndef GADAPT_STAGGER_FWD
-#define GADAPT_STAGGER_FWD 0
-#endif
-#ifndef GADAPT_STAGGER_T
-#define GADAPT_STAGGER_T 0
-#endif
 // Hidden sizes from here on give the backward kernels one wave per SIMD (512 registers): at C = 128 the dA accumulators
 // (64) + projection blocks (32) + row buffers do not fit 256 registers and the spill traffic costs more than the second
 // resident workgroup brings.
@@ -75,9 +69,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GADAPT_FPL 8            // floats per lane at hidden >= 32.  16 (four lanes per node at hidden 64) measured: the row buffers
                                 // double, forward / target pass spill 36 / 117 registers (27.4 / 62.4 us), source pass 28.4 vs 26.2 us
 #endif
-#ifndef GADAPT_T_TWO_BUFFERS
-#define GADAPT_T_TWO_BUFFERS 0     // 1: one-wave target pass (hidden 128) with two row buffers in the edge walk; measured 128.0 vs 128.3 us
-#endif
 #ifndef GADAPT_T_RING_MAX_C
 #define GADAPT_T_RING_MAX_C 128   // target pass: largest hidden size that keeps the rolling LDS window of x rows
 #endif
@@ -98,9 +89,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
                                 // registers; with resident fragments the dense variant spills 25 registers: 51 us).  Step 0.365
                                 // against 0.356 ms: the dA phase costs more than it frees wherever it runs.
 #endif
-#ifndef GADAPT_T_MFMA_PRIO
-#define GADAPT_T_MFMA_PRIO 0    // s_setprio level of the target pass's matrix phases (0: leave the priority alone)
-#endif
 #ifndef GADAPT_T_STREAM
 #define GADAPT_T_STREAM 0        /* target pass: own g rows and dxd rows non-temporal.  Measured: the target pass gains 0.3 us, the source pass
                                     that follows LOSES 6 us (24.9 -> 31.0 at hidden 64): it reads dxd, and a normally written dxd is still in
@@ -118,9 +106,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 #ifndef GADAPT_T_ALTERNATE
 #define GADAPT_T_ALTERNATE 1     /* target pass: every other workgroup walks its chunk backwards (see the kernel) */
-#endif
-#ifndef GADAPT_DA_BPREFETCH
-#define GADAPT_DA_BPREFETCH 1
 #endif
 #ifndef GADAPT_DA_UNROLL
 #define GADAPT_DA_UNROLL 2      // k-steps of the dA loop unrolled together
