@@ -357,8 +357,8 @@ def test_grand_plus_conv_option_surface():
     assert sd['lin_beta.weight'].shape == (1, 96) and sd['sm_temp_a'].shape == (1, 4, 1)
     plain = GRAND_plusConv(hot_path_opt(), 8, 8, heads=1, concat=False, root_weight=False, bias=False)
     assert 'lin_beta.weight' not in plain.state_dict() and plain.state_dict()['lin_skip.weight'].shape == (8, 8) and not plain._general
-    with pytest.raises(NotImplementedError):
-        GRAND_plusConv(opt, 8, 8, edge_dim=3)
+    edged = GRAND_plusConv(opt, 8, 8, edge_dim=3)                   # lin_edge = Linear(edge_dim, H C, bias=False), GRAND_plus.py:165-166
+    assert edged.state_dict()['lin_edge.weight'].shape == (8, 3) and edged._general and 'lin_edge.weight' not in plain.state_dict()
     with pytest.raises(NotImplementedError):
         GRAND_plusConv(opt, 8, 8, heads=2)                          # Identity(x).view(-1, 2, 8) needs 16 input channels
     with pytest.raises(ValueError):
