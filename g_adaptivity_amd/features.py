@@ -46,5 +46,7 @@ def field_to_grid(field: torch.Tensor, mapping: Optional[torch.Tensor], mesh_dim
 
 
 def expand_to_nodes(per_mesh: torch.Tensor, batch: torch.Tensor) -> torch.Tensor:
-    """[B, k] -> [N, k]: every node gets its mesh's row (`repeat_interleave(bincount(batch))`, GNN.py:252-253)."""
-    return per_mesh.repeat_interleave(torch.bincount(batch), dim=0)
+    """[B, k] -> [N, k]: every node gets its mesh's row (`repeat_interleave(bincount(batch))`, GNN.py:252-253).  `batch` is the
+    sorted mesh index of every node, so the repeat IS the row gather `per_mesh[batch]` - which, unlike `bincount` +
+    `repeat_interleave` (data-dependent output size: a host synchronisation), can sit inside a captured hipGraph."""
+    return per_mesh.index_select(0, batch)

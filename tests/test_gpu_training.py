@@ -240,3 +240,34 @@ def test_graphed_train_step_with_eager_optimizer_step(gpu_device):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert not torch.equal(res[0][1], list(base.parameters())[1])
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_with_global_cnn_features(gpu_device):
+    """The captured iteration with `gnn_inc_glob_feat_f/uu` (GNN.py:240-268: the per-mesh CNN features, MIOpen convolutions,
+    gradients through d/dx0 of the block op).  Two things used to synchronise with the host inside the forward and would have
+    invalidated a capture: `batch.max().item()` (now the collated batch's own mesh count) and `repeat_interleave(bincount(batch))`
+    (now the row gather `per_mesh[batch]`).  MIOpen's weight-gradient kernels accumulate with atomics, so two EAGER runs already
+    differ in the last bits (measured 6e-8); the replayed run must sit in that band."""
+    from g_adaptivity_amd import DeviceMeshLoader, GraphedTrainStep
+    opt = hot_path_opt(mesh_dims=[12, 12], hidden_dim=32, num_layers=2, device=str(gpu_device), gnn_inc_glob_feat_f=True,
+                       gnn_inc_glob_feat_uu=True, lr=1e-3)
+    ds = MeshDataset([12, 12], 8, seed=0)
+    torch.manual_seed(0)
+    base = GNN(ds, opt).to(gpu_device).train()
+    state = copy.deepcopy(base.state_dict())
+    res = []
+    for graphed in (False, True):
+        m = GNN(ds, opt).to(gpu_device).train(); m.load_state_dict(copy.deepcopy(state))
+        o = FlatAdam(m.parameters(), lr=opt['lr'], capturable=True)
+        step = GraphedTrainStep(m, o)
+        for epoch in range(2):
+            for d in DeviceMeshLoader(ds, batch_size=4, shuffle=False, device=gpu_device):
+                (step if graphed else step.eager)(d)
+        torch.cuda.synchronize()
+        res.append({n: p.detach().clone() for n, p in m.named_parameters()})
+    moved = 0
+    for n, p0 in base.named_parameters():
+        assert (res[0][n] - res[1][n]).abs().max().item() <= 1e-6, n
+        moved += int((res[0][n] - p0).abs().max().item() > 1e-4)
+    assert moved >= 10                                               # conv weights / biases and the 16 CNN tensors were trained
