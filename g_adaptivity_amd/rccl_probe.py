@@ -29,7 +29,8 @@ def _child() -> int:
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    dist.init_process_group('nccl', device_id=dev)
+    import datetime
+    dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=int(os.environ.get('GADAPT_PROBE_TIMEOUT', 90))))
     n = 8320                                                      # the bucket of the metric workload: 2 (C^2 + C) floats at C = 64
     src = torch.zeros(n, device=dev)
     buf = torch.zeros(n, device=dev)
@@ -67,7 +68,9 @@ def rehearse(timeout: float = 180.0) -> bool:
     """Run the probe for THIS rank in a child process (call it on every rank, before the caller initialises its GPU or its
     process group).  True when the child reports success; ranks must still agree among themselves afterwards (all-reduce MIN of
     the flags) - a child that died on another rank makes its peers time out and report False too."""
-    env = dict(os.environ)
+    # (a child of a torch.distributed.run worker must not inherit the agent's rendezvous: with TORCHELASTIC_USE_AGENT_STORE set,
+    # rank 0 would wait for a store the agent hosts at the ORIGINAL port instead of opening one at the probe's port)
+    env = {k: v for k, v in os.environ.items() if not k.startswith('TORCHELASTIC_')}
     env.setdefault('MASTER_ADDR', '127.0.0.1')
     env['MASTER_PORT'] = str(int(env.get('MASTER_PORT', '29500')) + PORT_OFFSET)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')

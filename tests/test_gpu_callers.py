@@ -343,3 +343,24 @@ def test_allreduce_flat_captured_in_a_hipgraph_one_rank(gpu_device):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rccl_cabi_capture_probe.py')], capture_output=True, text=True,
                        timeout=300, cwd=ROOT)
     assert r.returncode == 0 and 'CABI_CAPTURE_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
+def test_rccl_rehearsal_from_torchrun_workers(gpu_device):
+    """`rehearse()` as `bench.py --gpus N` calls it: from torch.distributed.run workers, before they touch the GPU.  The children
+    must rendezvous on their own port (not on the elastic agent's store: TORCHELASTIC_* is stripped from their environment) and reach
+    RCCL; on this one-GPU box two ranks cannot form an RCCL group (one GPU per rank), so the verdict is False on both ranks - and
+    it must come quickly, not after a rendezvous timeout."""
+    import time
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GADAPT_BENCH_SHARE_GPU='1', GADAPT_PROBE_TIMEOUT='60')
+    t0 = time.time()
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'tools', 'rehearse_under_torchrun.py')],
+                       capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    took = time.time() - t0
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if 'rehearse ->' in l]
+    assert len(lines) == 2 and all('-> False' in l for l in lines), r.stdout[-1500:]
+    assert took < 120, f"rehearsal took {took:.0f} s: a rendezvous timeout, not an RCCL refusal"
