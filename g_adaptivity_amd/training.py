@@ -49,6 +49,13 @@ class GraphedTrainStep:
             raise TypeError("GraphedTrainStep needs FlatAdam(capturable=True): the step count must live on the device")
         if not model.training:
             raise RuntimeError("GraphedTrainStep captures the training iteration: call model.train() first")
+        import torch.distributed as dist
+        if (capture_optimizer and optimizer.data_parallel and dist.is_available() and dist.is_initialized() and dist.get_world_size(optimizer.group) > 1
+                and dist.get_backend(optimizer.group) != 'nccl'):
+            # a collective that synchronises with the host invalidates the capture, and that is not recoverable in-process on this
+            # ROCm (tools/capture_recovery_probe.py): refuse up front instead
+            raise ValueError(f"GraphedTrainStep(capture_optimizer=True): the '{dist.get_backend(optimizer.group)}' all-reduce of optimizer.step() "
+                             "cannot be captured in a hipGraph (only RCCL collectives can); pass capture_optimizer=False")
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.target_field, self.warmup = target_field, max(int(warmup), 1)
         self.capture_optimizer = bool(capture_optimizer)

@@ -44,6 +44,16 @@ def _worker(rank, world, port, out):
     assert optim.grad_bucket.numel() == 2 * (8 * 8 + 8)    # lin_skip / enc never get one
     n = optim.all_reduce()
     assert n == world
+    # a captured step must refuse a collective that cannot be captured (only RCCL's can) BEFORE it starts a capture: an invalidated
+    # capture is not recoverable in-process (the check needs no GPU: it precedes everything else the constructor does)
+    from g_adaptivity_amd import GraphedTrainStep
+    model.train()
+    try:
+        GraphedTrainStep(model, FlatAdam(model.parameters(), capturable=True))
+        refused = False
+    except ValueError as e:
+        refused = 'capture_optimizer=False' in str(e)
+    assert refused
     if rank == 0:
         out.put((optim.grad_bucket / n).clone())
     dist.barrier()
