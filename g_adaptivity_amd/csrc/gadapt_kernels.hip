@@ -144,7 +144,7 @@ static int check_launch(const char* what) {
     return GADAPT_OK;
 }
 extern "C" const char* gadapt_last_error(void) { return g_err; }
-extern "C" int gadapt_abi_version(void) { return 4; }
+extern "C" int gadapt_abi_version(void) { return 5; }   // 5: + gat_plus block, gather_fields, edge_vector_op (round 4; additions only)
 extern "C" int gadapt_clear_error(void) { g_err[0] = 0; return (int)hipGetLastError(); }
 extern "C" int gadapt_supported_hidden_dim(int c) {
     return c == 4 || c == 8 || c == 16 || c == 32 || c == 64 || c == 128;
