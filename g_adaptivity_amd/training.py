@@ -170,9 +170,9 @@ class GraphedTrainStep:
                 if src.data_ptr() != dst.data_ptr():         # loaders bound with `static_batch` write in place
                     dst.copy_(src.reshape(dst.shape), non_blocking=True)
         c.graph.replay()
+        for p, g in c.grads:                                 # `.grad` shows what THIS replay computed (each capture has its own tensors)
+            p.grad = g
         if not self.capture_optimizer:
-            for p, g in c.grads:
-                p.grad = g
             self.optimizer.step()                            # all-reduce + fused Adam
         return c.loss
 
