@@ -13,6 +13,10 @@ Extra objects on the JSON line:
   roofline     - dominant hot kernel: algorithmic bytes per launch / its measured
                  duration (HIP events on the launch stream, second instrumented pass of K steps).
   cpu_baseline - the CPU oracle (PyG-equivalent op sequence in plain torch) on the host cores, rank 0, N=1.
+  windows      - `value` / `ms_per_step` are the MEDIAN of --windows (5) timed windows of exactly K steps; min / max beside it.
+  value_dense_slots / ms_per_step_dense_slots - the same run's timing of the literal dense-slot flow.
+  train_loop   - N=1: the reference's training loop (src/run_GNN.py:95-131) on SHUFFLED, CHANGING batches through
+                 training.GraphedTrainStep + DeviceMeshLoader (the headline replays one static batch).
 """
 import argparse
 import json
@@ -133,6 +137,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--windows', type=int, default=5,
                     help='timed windows of --steps steps each; value / ms_per_step are the MEDIAN window (min and max reported beside it)')
+    ap.add_argument('--no-train-loop', action='store_true',
+                    help='skip the third measurement: the reference training loop on SHUFFLED, changing batches (GraphedTrainStep)')
     ap.add_argument('--no-companion', action='store_true',
                     help='skip the second timing of the other slot flow (dense when the headline is compact and vice versa)')
     args = ap.parse_args()
@@ -430,6 +436,37 @@ def main():
                                                      'against the fp32 matrix peak; the kernels execute 8 N C^2 per layer (composite '
                                                      'A = Wk^T Wq) as split bf16 / f16 products'}}
 
+    # ---- the reference's training loop on CHANGING batches (src/run_GNN.py:95-131): a dataset of 8 batches'
+    # worth of meshes on the device, shuffled every epoch by DeviceMeshLoader, every iteration one replay of the captured step
+    # (training.GraphedTrainStep), the loader gathering the next batch into the captured buffers.  Reported beside the headline,
+    # which replays ONE static batch: the difference is the batch assembly (one launch) and the Python loop.
+    train_loop = None
+    if rank == 0 and world == 1 and not args.no_train_loop and not args.no_graph and w['conv'] in ('GRAND', 'GRAND_plus', 'GAT_plus'):
+        from g_adaptivity_amd import DeviceMeshLoader, GraphedTrainStep
+        n_batches = 8
+        tds = MeshDataset([w['n'], w['n']], n_batches * w['batch'], seed=1)
+        torch.manual_seed(0)
+        tmodel = GNN(tds, opt).to(dev).train()
+        toptim = FlatAdam(tmodel.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=True)
+        tstep = GraphedTrainStep(tmodel, toptim, loss_fn=native_mse_loss)
+        loader = DeviceMeshLoader(tds, batch_size=w['batch'], shuffle=True, device=dev, fields=('x_comp', 'x_phys', 'f_tensor', 'uu_tensor'),
+                                  into=tstep.static_batch)
+        total = torch.zeros((), device=dev)
+        for batch in loader:                                          # first epoch: capture + warm-up
+            total += tstep(batch)
+        torch.cuda.synchronize()
+        epochs = max(2, (args.steps * max(args.windows, 1) + n_batches - 1) // n_batches)
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            for batch in loader:
+                total += tstep(batch)                                 # the loop's own per-step work: accumulate the loss on the device
+        torch.cuda.synchronize()
+        tl = time.perf_counter() - t0
+        train_loop = {'value': round(epochs * len(tds) / tl, 1), 'unit': 'meshes/s', 'ms_per_step': round(1e3 * tl / (epochs * n_batches), 4),
+                      'steps': epochs * n_batches, 'dataset_meshes': len(tds), 'loader': 'DeviceMeshLoader(shuffle=True, into=step.static_batch)',
+                      'step': 'GraphedTrainStep: zero_grad+forward+mse+backward+adam, one replay per batch'}
+        del tstep, tmodel, toptim, loader
+
     # ---- CPU baseline: the oracle on the host cores, same workload, bounded sample.  A quarter of the batch per step (the
     # cost is linear in the meshes), a short sweep over thread counts (index_add_ / scatter ops stop scaling early), then
     # >= 10 timed steps at the best count.
@@ -500,7 +537,7 @@ def main():
                        'global_batch': w['batch'] * world, 'mp_layers': w['layers'], 'hidden': w['hidden'],
                        'conv_type': w['conv'], 'parallelism': f'dp{world}',
                        'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'root_gradient': 'created per step (loss.backward())' if root is None else 'preallocated (unit_gradient)', 'slots': 'dense' if args.dense_slots else 'compact', 'slots_note': None if args.dense_slots else 'identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the [N,4] encoder output in forward and backward, layer 1 hands it the 4 gradient columns it reads, the last layer writes the [N,4] head the model returns (GNN.py:299) and takes the compact top gradient; --dense-slots runs the literal dense flow', 'launch': ('hipgraph+adam' if world == 1 else ('hipgraph+allreduce+adam' if capture_all else 'hipgraph, then allreduce+adam')) if graph is not None else 'eager'},
-            'roofline': roofline, 'roofline_mfma': roofline_mfma, 'kernels': kernels, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_mfma': roofline_mfma, 'kernels': kernels, 'cpu_baseline': cpu, 'train_loop': train_loop,
         }
         if companion is not None:                                     # same run, the other slot flow (see above)
             key = 'dense_slots' if companion['slots'] == 'dense' else 'compact_slots'
