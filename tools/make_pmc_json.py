@@ -23,6 +23,9 @@ N_SIMD, N_XCD = 1024, 8
 
 
 def name(n):
+    if 'gat::fwd' in n: return 'forward'                    # fused GAT_plus layer kernels (csrc/gadapt_gat.inc)
+    if 'gat::bwd_t' in n: return 'backward_target'
+    if 'gat::bwd_s' in n: return 'backward_source'
     if 'grand_fwd' in n or 'wide::fwd' in n: return 'forward'
     if "bwd_target" in n: return "backward_target"          # grand_bwd_target_kernel<...>, grand_bwd_target_compact_kernel<SUMS>
     if 'bwd_source' in n: return 'backward_source'          # grand_bwd_source_kernel<...>, grand_bwd_source4_kernel<C, GC>
