@@ -363,3 +363,32 @@ def test_grand_plus_conv_option_surface():
         GRAND_plusConv(opt, 8, 8, heads=2)                          # Identity(x).view(-1, 2, 8) needs 16 input channels
     with pytest.raises(ValueError):
         GRAND_plusConv(opt, 16, 8, heads=2, concat=False)           # `out - x`: [N,8] - [N,16]
+
+
+def test_device_mesh_loader_fields_and_static_sink_on_cpu():
+    """`DeviceMeshLoader(fields=..., into=...)` without a GPU (torch's index_select path): only the requested node fields are
+    carried; from the second batch of a size on, the gathers land in the static batch the sink returned and that object is
+    yielded; every batch equals the host collation of the same samples."""
+    import torch
+    from g_adaptivity_amd import DeviceMeshLoader, MeshDataset, collate
+    ds = MeshDataset([7, 7], 10, seed=2)
+    sinks = {}
+
+    def sink(batch):
+        s = batch.clone()
+        sinks[int(batch.x_comp.shape[0])] = s
+        return s
+
+    gen = torch.Generator(); gen.manual_seed(3)
+    loader = DeviceMeshLoader(ds, batch_size=4, shuffle=True, device='cpu', generator=gen, fields=('x_comp', 'x_phys', 'uu_tensor'), into=sink)
+    seen_static = 0
+    for epoch in range(2):
+        for b in loader:
+            assert not hasattr(b, 'f_tensor') and not hasattr(b, 'u_true_tensor')
+            want = collate([ds.samples[i] for i in b.idx.tolist()])
+            for k in ('x_comp', 'x_phys', 'uu_tensor'):
+                assert torch.equal(getattr(b, k), getattr(want, k)), k
+            assert torch.equal(b.edge_index, want.edge_index)
+            seen_static += int(any(b is s for s in sinks.values()))
+    assert set(sinks) == {4 * 49, 2 * 49}                           # one static batch per batch size (10 = 4 + 4 + 2)
+    assert seen_static == 6 - 2                                     # every batch but the first of each size IS the static object
