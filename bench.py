@@ -452,19 +452,31 @@ def main():
         loader = DeviceMeshLoader(tds, batch_size=w['batch'], shuffle=True, device=dev, fields=('x_comp', 'x_phys', 'f_tensor', 'uu_tensor'),
                                   into=tstep.static_batch)
         total = torch.zeros((), device=dev)
-        for batch in loader:                                          # first epoch: capture + warm-up
+        for batch in loader:                                          # first epoch: capture
             total += tstep(batch)
         torch.cuda.synchronize()
+        # warm-up: the GPU sat idle while the 256-mesh dataset was generated on the host, and its clocks take tens of milliseconds
+        # of work to come back (a 24-step timing right after the capture was seen at 3 ms per step, one run in five)
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.1:
+            for batch in loader:
+                total += tstep(batch)
+            torch.cuda.synchronize()
         epochs = max(2, (args.steps * max(args.windows, 1) + n_batches - 1) // n_batches)
+        from g_adaptivity_amd import graph as _gm
+        hashed0, epoch_ms = _gm.FP_STATS['hashed'], []
         t0 = time.perf_counter()
         for _ in range(epochs):
+            te = time.perf_counter()
             for batch in loader:
                 total += tstep(batch)                                 # the loop's own per-step work: accumulate the loss on the device
+            epoch_ms.append(round(1e3 * (time.perf_counter() - te), 3))   # (host issue time of the epoch: no synchronisation inside)
         torch.cuda.synchronize()
         tl = time.perf_counter() - t0
         train_loop = {'value': round(epochs * len(tds) / tl, 1), 'unit': 'meshes/s', 'ms_per_step': round(1e3 * tl / (epochs * n_batches), 4),
                       'steps': epochs * n_batches, 'dataset_meshes': len(tds), 'loader': 'DeviceMeshLoader(shuffle=True, into=step.static_batch)',
-                      'step': 'GraphedTrainStep: zero_grad+forward+mse+backward+adam, one replay per batch'}
+                      'step': 'GraphedTrainStep: zero_grad+forward+mse+backward+adam, one replay per batch',
+                      'captures': len(tstep._captured), 'topology_tensors_rehashed': _gm.FP_STATS['hashed'] - hashed0, 'epoch_issue_ms': epoch_ms[:8]}
         del tstep, tmodel, toptim, loader
 
     # ---- CPU baseline: the oracle on the host cores, same workload, bounded sample.  A quarter of the batch per step (the

@@ -85,6 +85,9 @@ def _fp_mix(v: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return z.bitwise_xor_(t)
 
 
+FP_STATS = {'hashed': 0}            # tensors hashed so far (memo misses): a loop that re-hashes every step is paying a host synchronisation
+
+
 def content_fingerprint(tensors) -> Tuple:
     """Order-sensitive checksums (int64 wrap-around arithmetic) of integer / bool tensors, on the device they live on: the sum
     of a per-element, position-dependent 64-bit hash (`_fp_mix`) and the plain sum.
@@ -100,6 +103,7 @@ def content_fingerprint(tensors) -> Tuple:
         else:
             todo.append(k)
     if todo:
+        FP_STATS['hashed'] += len(todo)
         sums = []
         for k in todo:
             v = tensors[k].detach().reshape(-1).to(torch.int64)
