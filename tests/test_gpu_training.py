@@ -278,3 +278,35 @@ def test_graphed_train_step_with_global_cnn_features(gpu_device):
         assert (res[0][n] - res[1][n]).abs().max().item() <= 1e-6, n
         moved += int((res[0][n] - p0).abs().max().item() > 1e-4)
     assert moved >= 10                                               # conv weights / biases and the 16 CNN tensors were trained
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss_name", ['l1_native', 'mse_torch'])
+def test_graphed_train_step_other_losses_and_eviction(gpu_device, loss_name):
+    """`GraphedTrainStep` with the native L1 loss (`F.l1_loss`, run_GNN.py:82) and with torch's own `F.mse_loss` (plain
+    `loss.backward()`, no preallocated root gradient), and with room for ONE captured topology only (`max_graphs=1`): alternating
+    batch sizes evict and re-capture every time - slower, never wrong.  Replayed training equals the eager loop bit for bit."""
+    from g_adaptivity_amd import DeviceMeshLoader, GraphedTrainStep, l1_loss
+    loss_fn = l1_loss if loss_name == 'l1_native' else F.mse_loss
+    opt = hot_path_opt(mesh_dims=[10, 10], hidden_dim=32, num_layers=2, lr=1e-3, device=str(gpu_device))
+    ds = MeshDataset([10, 10], 7, seed=4)                                # batches of 3, 3, 1
+    torch.manual_seed(2)
+    state = copy.deepcopy(GNN(ds, opt).state_dict())
+    res = []
+    for graphed in (False, True):
+        m = GNN(ds, opt).to(gpu_device).train(); m.load_state_dict(copy.deepcopy(state))
+        o = FlatAdam(m.parameters(), lr=opt['lr'], capturable=True)
+        step = GraphedTrainStep(m, o, loss_fn=loss_fn, max_graphs=1)
+        losses = []
+        for epoch in range(2):
+            for d in DeviceMeshLoader(ds, batch_size=3, shuffle=False, device=gpu_device):
+                losses.append((step if graphed else step.eager)(d).clone())
+        torch.cuda.synchronize()
+        if graphed:
+            assert len(step._captured) == 1
+        res.append(([p.detach().clone() for p in m.parameters()], losses))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    assert not torch.equal(res[0][0][1], state['conv_layers.0.lin_key.weight'].to(gpu_device))
