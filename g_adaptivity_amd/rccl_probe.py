@@ -30,7 +30,7 @@ def _child() -> int:
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     import datetime
-    dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=int(os.environ.get('GADAPT_PROBE_TIMEOUT', 90))))
+    dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=int(os.environ.get('GADAPT_PROBE_TIMEOUT', 60))))
     n = 8320                                                      # the bucket of the metric workload: 2 (C^2 + C) floats at C = 64
     src = torch.zeros(n, device=dev)
     buf = torch.zeros(n, device=dev)
@@ -64,7 +64,7 @@ def _child() -> int:
     return 1
 
 
-def rehearse(timeout: float = 180.0) -> bool:
+def rehearse(timeout: float = 120.0) -> bool:
     """Run the probe for THIS rank in a child process (call it on every rank, before the caller initialises its GPU or its
     process group).  True when the child reports success; ranks must still agree among themselves afterwards (all-reduce MIN of
     the flags) - a child that died on another rank makes its peers time out and report False too."""
