@@ -1,16 +1,11 @@
 # Builds the C-ABI shared library of the hot path for gfx950 (MI355X), in-tree.
 #   make            -> g_adaptivity_amd/libgadapt_hip.so
 #   make resources  -> per-kernel VGPR/SGPR/LDS/occupancy report
-#   make FUSED_BWD=1 -> the library with the alternative fused dense backward compiled in (off by default)
 HIPCC      ?= /opt/rocm/bin/hipcc
 ARCH       ?= gfx950
 CSRC       := g_adaptivity_amd/csrc
 LIB        := g_adaptivity_amd/libgadapt_hip.so
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wall -Wno-unused-variable -Wno-unused-but-set-variable
-# make FUSED_BWD=1: also build the alternative one-kernel dense backward (csrc/gadapt_fused_bwd.inc; measured slower, not in the default library)
-ifeq ($(FUSED_BWD),1)
-HIPFLAGS   += -DGADAPT_WITH_FUSED_BWD
-endif
 
 all: $(LIB)
 

@@ -96,3 +96,30 @@ extern "C" int gadapt_wide_window_host(const int32_t* rowptr, const int32_t* col
     *max_deg_out = ok ? longest : 0;
     return GADAPT_OK;
 }
+
+// Cross positions between the two ELL-8 copies (see include/gadapt_hip.h): for the edge in slot k of node i's in-row
+// (ELL-t position 8 i + k) the position of the same edge in its source's out-row (ELL-s position 8 src + k'), and the inverse.
+// The wide backward kernels exchange per-edge values between the two orientations through these (one kernel writes a value
+// where the other one reads it with a coalesced row load).  Rows longer than 8 are cut like the ELL copies themselves: such a
+// graph never qualifies for the wide kernels.
+extern "C" int gadapt_ell_cross_host(const int32_t* rowptr_t, const int32_t* col_t, const int32_t* tpos_s,
+                                     const int32_t* rowptr_s, const int32_t* col_s, const int32_t* perm_s,
+                                     int64_t n_nodes, int32_t* xpos_t_out, int32_t* xpos_s_out) {
+    if (!rowptr_t || !col_t || !tpos_s || !rowptr_s || !col_s || !perm_s || !xpos_t_out || !xpos_s_out || n_nodes <= 0)
+        return GADAPT_E_BADARG;
+    const int64_t n_pad = (n_nodes + 255) / 256 * 256;
+    for (int64_t k = 0; k < n_pad * 8; ++k) xpos_t_out[k] = xpos_s_out[k] = -1;
+    for (int64_t i = 0; i < n_nodes; ++i) {
+        const int32_t e0 = rowptr_t[i], d = rowptr_t[i + 1] - e0;
+        for (int32_t k = 0; k < d && k < 8; ++k) {
+            const int32_t src = col_t[e0 + k], ks = tpos_s[e0 + k] - rowptr_s[src];
+            xpos_t_out[8 * i + k] = (ks >= 0 && ks < 8) ? 8 * src + ks : -1;
+        }
+        const int32_t s0 = rowptr_s[i], ds = rowptr_s[i + 1] - s0;
+        for (int32_t k = 0; k < ds && k < 8; ++k) {
+            const int32_t dst = col_s[s0 + k], kt = perm_s[s0 + k] - rowptr_t[dst];
+            xpos_s_out[8 * i + k] = (kt >= 0 && kt < 8) ? 8 * dst + kt : -1;
+        }
+    }
+    return GADAPT_OK;
+}

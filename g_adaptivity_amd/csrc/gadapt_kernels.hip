@@ -144,7 +144,7 @@ static int check_launch(const char* what) {
     return GADAPT_OK;
 }
 extern "C" const char* gadapt_last_error(void) { return g_err; }
-extern "C" int gadapt_abi_version(void) { return 5; }   // 5: + gat_plus block, gather_fields, edge_vector_op (round 4; additions only)
+extern "C" int gadapt_abi_version(void) { return 6; }   // 6: + wide backward (gadapt_graph.xpos_t/xpos_s, ell_cross_host, block_backward_ws; round 5)
 extern "C" int gadapt_clear_error(void) { g_err[0] = 0; return (int)hipGetLastError(); }
 extern "C" int gadapt_supported_hidden_dim(int c) {
     return c == 4 || c == 8 || c == 16 || c == 32 || c == 64 || c == 128;
@@ -247,9 +247,7 @@ extern "C" int gadapt_profile_reset(void) {
 #include "gadapt_bwd_source.inc"
 #include "gadapt_small.inc"
 #include "gadapt_wide.inc"
-#ifdef GADAPT_WITH_FUSED_BWD
-#include "gadapt_fused_bwd.inc"
-#endif
+#include "gadapt_wide_bwd.inc"
 
 // ------------------------------------------------------------------------------------------------
 // launchers
@@ -379,30 +377,55 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
     }
     return check_launch("grand_fwd_kernel");
 }
-// The node pass + fused kernel of gadapt_fused_bwd.inc instead of the target / source pair for dense layers: measured slower
-// than the pair (docs/measurements.md), so it is NOT part of the default library.  `make FUSED_BWD=1` (-DGADAPT_WITH_FUSED_BWD)
-// builds it in; GADAPT_FUSED_BWD=1 in the environment or gadapt_debug_set_fused_backward(1) then select it
-// (tests/test_gpu_ops.py::test_fused_backward_matches_two_pass runs when the library was built with it).
-#ifdef GADAPT_WITH_FUSED_BWD
-static std::atomic<int> g_fused_bwd{-1};
-static bool fused_bwd_enabled() {
-    int v = g_fused_bwd.load(std::memory_order_relaxed);
+// The wide backward (gadapt_wide_bwd.inc) instead of the tiled target / source pair, for the layers it covers: hidden 64, a graph
+// that qualifies for the wide kernels in both orientations and carries the ELL cross positions, a workspace from the caller.
+// OFF by default: on the metric workload it measures level with the pair (edge + main kernel 12 + 46 us net against 31 + 23 us for the
+// compact-gradient pair; docs/measurements.md F).  GADAPT_WIDE_BWD=1 in the environment or gadapt_debug_set_wide_backward(1)
+// select it; tests/test_gpu_ops.py::test_wide_backward_matches_two_pass runs both on the same inputs.
+static std::atomic<int> g_wide_bwd{-1};
+static bool wide_bwd_enabled() {
+    int v = g_wide_bwd.load(std::memory_order_relaxed);
     if (v < 0) {
-        const char* e = getenv("GADAPT_FUSED_BWD");
+        const char* e = getenv("GADAPT_WIDE_BWD");
         v = (e && e[0] == '1') ? 1 : 0;
-        g_fused_bwd.store(v, std::memory_order_relaxed);
+        g_wide_bwd.store(v, std::memory_order_relaxed);
     }
-    return v == 1;
+    return v == 1 && wide_enabled();
 }
-extern "C" int gadapt_debug_set_fused_backward(int on) { g_fused_bwd.store(on ? 1 : 0, std::memory_order_relaxed); return GADAPT_OK; }
-#else
-extern "C" int gadapt_debug_set_fused_backward(int on) {
-    return on ? fail(GADAPT_E_BADARG, "gadapt_debug_set_fused_backward: this library was built without -DGADAPT_WITH_FUSED_BWD") : GADAPT_OK;
+extern "C" int gadapt_debug_set_wide_backward(int on) { g_wide_bwd.store(on ? 1 : 0, std::memory_order_relaxed); return GADAPT_OK; }
+extern "C" int64_t gadapt_wide_backward_ws_floats(int64_t n_nodes) {
+    if (n_nodes <= 0) return fail(GADAPT_E_BADARG, "wide_backward_ws_floats: bad node count");
+    return ((n_nodes + 255) / 256 * 256) * 8 * 2 * 2;            // adt + ads: [round_up(N,256)][8] float2 each
 }
+static bool wide_bwd_graph_ok(const gadapt_graph* g) {
+    return g->ell_t && g->ell_s && g->xpos_t && g->xpos_s && g->wide_deg_t > 0 && g->wide_deg_s > 0 && g->rowptr_s && g->col_s && g->perm_s;
+}
+// top layer of a block whose caller takes x[:, :dim]: compact upstream gradient [N,g_cols]
+static int launch_wide_bwd_compact(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha, const float* a,
+                                   const float* p0, const float* lp, float* part4, float* slab, int slab_rows, int accumulate,
+                                   float* g_out, int residual_only, int g_cols, float* wide_ws, hipStream_t st) {
+    const int64_t n_pad = ((int64_t)g->n_nodes + 255) / 256 * 256;
+    float* win = wide_ws;
+    float* wout = wide_ws + n_pad * 8;
+    const int n_steps = (g->n_nodes + wide::STEP - 1) / wide::STEP;
+    {
+        wide::BwdEArgs pe{x_in, g_in, alpha, lp, g->rowptr_t, g->ell_t, g->ell_s, g->xpos_t, g->xpos_s, win, wout, part4,
+                          g->n_nodes, g->n_edges, n_steps, g_cols};
+        ProfScope prof(7, st, 1);
+        hipLaunchKernelGGL(wide::bwd_edge_compact_kernel, dim3(n_steps), dim3(256), 0, st, pe);
+        if (int rc = check_launch("wide::bwd_edge_compact_kernel")) return rc;
+    }
+    wide::BwdMArgs pm{x_in, part4, win, wout, a, p0, lp, g->ell_t, g->ell_s, g_out, slab, slab_rows, accumulate,
+                      g->n_nodes, n_steps, g->wide_deg_t, g->wide_deg_s, nullptr};
+#ifdef GADAPT_STAMPS
+    pm.stamps = g_stamp_buf;                                     // region 0 (the forward kernels' - they ran earlier in the step)
 #endif
-#ifndef GADAPT_BWD_D_MAX_BLOCKS
-#define GADAPT_BWD_D_MAX_BLOCKS 1024
-#endif
+    ProfScope prof(8, st, 1);
+    constexpr int lds = wide::bwd_main_lds_bytes();
+    allow_lds(wide::bwd_main_kernel, lds);
+    hipLaunchKernelGGL(wide::bwd_main_kernel, dim3(wide_grid(n_steps)), dim3(512), lds, st, pm);
+    return check_launch("wide::bwd_main_kernel");
+}
 #ifndef GADAPT_BWD_OUT4
 #define GADAPT_BWD_OUT4 1            /* 0: layer 1 above a compact layer 0 runs the dense pair (A/B) */
 #endif
@@ -412,7 +435,7 @@ extern "C" int gadapt_debug_set_fused_backward(int on) {
 template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha,
                                        const float* a, const float* p0, const float* lp, float* edge_ws, float* dxd, float* slab,
                                        int accumulate, float* sums_out, float* g_out, int residual_only, int g_cols, int x_cols, hipStream_t st, float* sums_sc_out,
-                                       int out4 = 0, int g_stride = 0, int sums_partials = 0) {
+                                       int out4 = 0, int g_stride = 0, int sums_partials = 0, float* wide_ws = nullptr) {
     // out4: only columns 0..3 of g_out are wanted (dxd and g_out are [N,4]: D4 target pass + grand_bwd_source4_kernel).
     // g_stride: row pitch of g_in in floats for the compact-input launch (0 = C).
     using K = Cfg<C>;
@@ -434,30 +457,12 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
 #endif
     constexpr int lds_t = K::lds_bytes(1, K::RING_T + 1, 1), lds_s = K::lds_bytes(2);
     int rc;
-#ifdef GADAPT_WITH_FUSED_BWD
-    if constexpr (C == 32 || C == 64) {
-        // dense layer with a gradient to pass on: node pass for D + ONE fused kernel (gadapt_fused_bwd.inc) instead of the
-        // target / source pair; D [N] lives at the start of the (otherwise unused) dxd workspace
-        if (fused_bwd_enabled() && !g_cols && !x_cols && !sums_out && !out4 && g_out && g->rowptr_s && g->col_s && g->perm_s) {
-            {
-                BwdDArgs pd{x_in, g_in, alpha, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t), dxd, g->n_nodes, n_tiles, residual_only, g->n_edges};
-                ProfScope prof(5, st, 0);
-                constexpr int lds_d = K::lds_bytes(1, 0);
-                allow_lds(grand_bwd_dnode_kernel<C>, lds_d);
-                hipLaunchKernelGGL(grand_bwd_dnode_kernel<C>, dim3(grid_for(n_tiles, GADAPT_BWD_D_MAX_BLOCKS)), dim3(256), lds_d, st, pd);
-                if ((rc = check_launch("grand_bwd_dnode_kernel"))) return rc;
-            }
-            BwdFArgs pf{x_in, g_in, alpha, dxd, a, p0, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t),
-                        g->rowptr_s, g->col_s, g->perm_s, meta_for<K::TM>(g->meta_s), g_out, slab,
-                        g->n_nodes, n_tiles, accumulate, residual_only, g->n_edges};
-            ProfScope prof(6, st, 0);
-            constexpr int lds_f = fused_bwd_lds_bytes<C>();
-            allow_lds(grand_bwd_fused_kernel<C>, lds_f);
-            hipLaunchKernelGGL(grand_bwd_fused_kernel<C>, dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(256), lds_f, st, pf);
-            return check_launch("grand_bwd_fused_kernel");
-        }
+    if constexpr (C == 64) {
+        // (residual_only launches keep the pair: the edge kernel's part row would need the base factor of the caller's update)
+        if (wide_ws && g_out && g_cols && !x_cols && !sums_out && !out4 && !residual_only && wide_bwd_graph_ok(g) && wide_bwd_enabled())
+            return launch_wide_bwd_compact(g, x_in, g_in, alpha, a, p0, lp, dxd, slab, grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS)),
+                                           accumulate, g_out, residual_only, g_cols, wide_ws, st);
     }
-#endif
     // hidden 32 / 64 with a source pass to follow: the source pass accumulates dA / dp0 (see grand_bwd_source_kernel)
     constexpr bool CAN_MOVE_DA = (C == 32 || C == 64) && GADAPT_DA_IN_SOURCE;
     const bool da_in_s = CAN_MOVE_DA && g_out && !sums_out && !x_cols && !out4;
@@ -883,14 +888,14 @@ extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_
 static int layer_backward_cols(const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha, const float* a,
                                const float* p0, const float* layer_params, float* edge_ws, float* dxd_ws, float* slab, int accumulate,
                                float* sums_out, float* sums_sc_out, float* g_out, int g_cols, int x_cols, int c, hipStream_t st,
-                               int out4, int g_stride) {
+                               int out4, int g_stride, float* wide_ws) {
     GADAPT_DISPATCH_C(c, launch_bwd<CC>(g, x_in, g_in, alpha, a, p0, layer_params, edge_ws, dxd_ws, slab, accumulate, sums_out, g_out, 0, g_cols, x_cols, st, sums_sc_out,
-                                        out4, g_stride, 1));
+                                        out4, g_stride, 1, wide_ws));
 }
-extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all, const float* g_top, int g_top_cols, int n_layers,
-                                     const float* a, int64_t a_stride, const float* p0, int64_t p0_stride, const float* layer_params,
-                                     float* g_ws, float* dxd_ws, float* edge_ws, float* slab, float* d_layer_params, int want_d_scale, float* d_x0,
-                                     int c, void* stream) {
+extern "C" int gadapt_block_backward_ws(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all, const float* g_top, int g_top_cols, int n_layers,
+                                        const float* a, int64_t a_stride, const float* p0, int64_t p0_stride, const float* layer_params,
+                                        float* g_ws, float* dxd_ws, float* edge_ws, float* slab, float* d_layer_params, int want_d_scale, float* d_x0,
+                                        int c, void* stream, float* wide_ws) {
     if (int rc = check_graph(g, c)) return rc;
     if (!x_all || !alpha_all || !g_top || n_layers <= 0 || !a || !p0 || !layer_params || !g_ws || !dxd_ws || !edge_ws || !slab)
         return fail(GADAPT_E_BADARG, "block_backward: bad argument");
@@ -922,11 +927,19 @@ extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, 
         const int g_stride = (pair4 && l == 0) ? 4 : 0;
         int rc = layer_backward_cols(g, x_all + l * nc, g_cur, alpha_all + (size_t)l * g->n_edges, a + l * a_stride, p0 + l * p0_stride,
                                      layer_params + 2 * l, edge_ws, dxd_ws, slab_l, accumulate, d_dt, d_sc, g_next, g_cols, x_cols, c, st,
-                                     out4, g_stride);
+                                     out4, g_stride, wide_ws);
         if (rc) return rc;
         g_cur = g_next;
     }
     return GADAPT_OK;
+}
+
+extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all, const float* g_top, int g_top_cols, int n_layers,
+                                     const float* a, int64_t a_stride, const float* p0, int64_t p0_stride, const float* layer_params,
+                                     float* g_ws, float* dxd_ws, float* edge_ws, float* slab, float* d_layer_params, int want_d_scale, float* d_x0,
+                                     int c, void* stream) {
+    return gadapt_block_backward_ws(g, x_all, x0_cols, alpha_all, g_top, g_top_cols, n_layers, a, a_stride, p0, p0_stride, layer_params, g_ws, dxd_ws, edge_ws,
+                                    slab, d_layer_params, want_d_scale, d_x0, c, stream, nullptr);
 }
 
 #include "gadapt_sparse.inc"

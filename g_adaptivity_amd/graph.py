@@ -177,6 +177,14 @@ class MeshGraph:
                 raise _native.NativeError("gadapt_ell_build_host failed")
             ells[tag], wide_deg[tag] = ell.to(self.device), (int(md.value) if (WIDE_KERNELS and n >= WIDE_MIN_NODES) else 0)
         self._ells, self.wide_deg = ells, wide_deg
+        # cross positions between the two ELL copies: the wide backward hands per-edge values from one end of an edge to the other
+        self._xpos = None
+        if wide_deg['t'] > 0 and wide_deg['s'] > 0:
+            xt, xs = torch.empty(n_pad * 8, dtype=torch.int32), torch.empty(n_pad * 8, dtype=torch.int32)
+            if _native.lib().gadapt_ell_cross_host(rowptr_t.data_ptr(), col_t.data_ptr(), tpos_s.data_ptr(), rowptr_s.data_ptr(), col_s.data_ptr(),
+                                                   perm_s.data_ptr(), n, xt.data_ptr(), xs.data_ptr()) != 0:
+                raise _native.NativeError("gadapt_ell_cross_host failed")
+            self._xpos = (xt.to(self.device), xs.to(self.device))
         # 512-row window of the wide forward: row-major meshes with up to 128 nodes per mesh row that miss the 384-row one
         self.wide_big_deg = 0
         if WIDE_KERNELS and n >= WIDE_MIN_NODES and wide_deg['t'] == 0:
@@ -193,8 +201,14 @@ class MeshGraph:
                                     self.tpos_s.data_ptr(),
                                     (C.c_void_p * 3)(*[metas[('t', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]),
                                     (C.c_void_p * 3)(*[metas[('s', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]),
-                                    ells['t'].data_ptr(), ells['s'].data_ptr(), wide_deg['t'], wide_deg['s'], self.wide_big_deg)
+                                    ells['t'].data_ptr(), ells['s'].data_ptr(), wide_deg['t'], wide_deg['s'], self.wide_big_deg,
+                                    self._xpos[0].data_ptr() if self._xpos else None, self._xpos[1].data_ptr() if self._xpos else None)
         self.c_ref = C.byref(self.c_struct)
+
+    @property
+    def wide_backward_ws_floats(self) -> int:
+        """Floats of the workspace `gadapt_block_backward_ws` takes for the wide backward kernels; 0 = this graph does not qualify."""
+        return int(_native.lib().gadapt_wide_backward_ws_floats(self.num_nodes)) if self._xpos else 0
 
     @property
     def has_in(self) -> torch.Tensor:

@@ -94,6 +94,10 @@ typedef struct gadapt_graph {
     int32_t wide_deg_s;        /* same for the source orientation */
     int32_t wide_big_deg_t;    /* longest in-row if the target orientation qualifies for the 512-row window of the wide forward
                                   (gadapt_wide_window_host(halo 128, rows <= 7): meshes with up to 128 nodes per row), else 0 */
+    /* ABI 6, optional (NULL = absent): cross positions between the two ELL copies (gadapt_ell_cross_host), for the wide backward */
+    const int32_t* xpos_t;     /* device [round_up(N,256)][8]: ELL-s position (8*src + slot in src's out-row) of the edge in slot k of
+                                  node i's in-row; -1 = unused */
+    const int32_t* xpos_s;     /* device: ELL-t position (8*dst + slot in dst's in-row) of the edge in slot k of node j's out-row */
 } gadapt_graph;
 
 /* ELL-8 copy of one CSR orientation (host pointers).  The wide kernels (hidden size 64: one wave owns 32 consecutive
@@ -106,6 +110,14 @@ int gadapt_ell_build_host(const int32_t* rowptr, const int32_t* col, int64_t n_n
  * every neighbour of node i lies in rows [256*(i/256) - halo, 256*(i/256) + 256 + halo), else 0.  halo 128 / max_row 7 is what
  * the wide forward's 512-row window takes (row-major meshes with up to 128 nodes per mesh row: BASELINE config 5). */
 int gadapt_wide_window_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int halo, int max_row, int32_t* max_deg_out);
+/* Cross positions between the two ELL-8 copies (host pointers; outputs round_up(N,256)*8 int32 each, -1 = unused): xpos_t[8i+k]
+ * = where the edge in slot k of node i's in-row sits in its source's out-row (8*src + k'), xpos_s[8j+k] = where the edge in
+ * slot k of node j's out-row sits in its target's in-row.  The wide backward kernels hand per-edge values from one side of an
+ * edge to the other through them (autograd of MessagePassing.propagate, GRAND_plus.py:233-234: every edge quantity is needed
+ * grouped by target AND by source). */
+int gadapt_ell_cross_host(const int32_t* rowptr_t, const int32_t* col_t, const int32_t* tpos_s,
+                          const int32_t* rowptr_s, const int32_t* col_s, const int32_t* perm_s,
+                          int64_t n_nodes, int32_t* xpos_t_out, int32_t* xpos_s_out);
 
 /* ------------------------------------------------------------------ weights
  * A[o][c] = sum_r Wk[r][o] Wq[r][c],  p0[o] = sum_r Wk[r][o] bq[r].
@@ -208,6 +220,18 @@ int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols
                           const float* layer_params,
                           float* g_ws, float* dxd_ws, float* edge_ws, float* slab,
                           float* d_layer_params, int want_d_scale, float* d_x0, int c, void* stream);
+/* The same with a workspace for the WIDE backward kernels (hidden 64, graphs that qualify in both orientations and carry
+ * xpos_t / xpos_s): wide_ws (nullable) = gadapt_wide_backward_ws_floats(N) floats.  With it - and gadapt_debug_set_wide_backward(1) -
+ * the layers the wide kernels cover (today: the top layer of a block with a compact upstream gradient) run as an edge kernel + one
+ * main kernel (csrc/gadapt_wide_bwd.inc) instead of the tiled target / source pair; every other layer, and every call without the
+ * workspace, runs the pair.  Same results up to fp32 summation order. */
+int64_t gadapt_wide_backward_ws_floats(int64_t n_nodes);
+int gadapt_block_backward_ws(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all,
+                             const float* g_top, int g_top_cols, int n_layers,
+                             const float* a, int64_t a_stride, const float* p0, int64_t p0_stride,
+                             const float* layer_params,
+                             float* g_ws, float* dxd_ws, float* edge_ws, float* slab,
+                             float* d_layer_params, int want_d_scale, float* d_x0, int c, void* stream, float* wide_ws);
 /* partials: the workspace gadapt_block_backward filled ([2][L][n_rows], n_rows = gadapt_backward_slab_rows).  d_layer_params
  * [2,L]: row 0 = d dt_l, row 1 = d score_scale_l (zeros when want_d_scale = 0) - two contiguous rows, so a caller can hand out
  * the d dt row as the gradients of L one-element step parameters laid side by side. */
@@ -332,10 +356,10 @@ int gadapt_profile_reset(void);
 /* Dispatch share D of an event pair: n x one empty launch (kernel id 3, p1) and n x two empty launches (id 4, p2),
  * bracketed like the hot kernels; D = 2 p1 - p2. */
 int gadapt_profile_calibrate(int n, void* stream);
-/* Diagnostic switch: backward of a dense layer as a node pass (D_i per node) + ONE fused kernel instead of the target /
- * source pair (csrc/gadapt_fused_bwd.inc; hidden 32 / 64).  Off by default - it measured slower; same results
- * to fp32 reassociation. */
-int gadapt_debug_set_fused_backward(int on);
+/* Switch: 1 lets gadapt_block_backward_ws run the wide backward kernels in the layers they cover (when it is given a workspace);
+ * 0 (the default: the two measure level on the metric workload, docs/measurements.md F) keeps the tiled target / source pair
+ * everywhere.  GADAPT_WIDE_BWD=1 in the environment sets the initial value.  tests compare the two on the same inputs. */
+int gadapt_debug_set_wide_backward(int on);
 /* Diagnostic: runtime-reported workgroups per CU of {forward, backward target, backward source}. */
 int gadapt_debug_occupancy(int c, int* out3);
 

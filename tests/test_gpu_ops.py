@@ -687,55 +687,55 @@ def test_wide_kernels_rebase_large_scores(gpu_device):
 
 @pytest.mark.one_dispatch
 @pytest.mark.gpu
-@pytest.mark.parametrize("mesh_n,batch,hidden", [(16, 3, 64), (24, 2, 32), (64, 8, 64)], ids=['16x16-C64', '24x24-C32', '64x64-b8-C64'])
-def test_fused_backward_matches_two_pass(gpu_device, mesh_n, batch, hidden):
-    """The alternative backward of a dense layer (node pass for D_i + one fused kernel, csrc/gadapt_fused_bwd.inc; off by
-    default because it measured slower) against the target / source pair: same gradients up to fp32 reassociation, on mesh
-    batches and on a random graph with long rows and isolated nodes (loop paths of both edge walks)."""
+@pytest.mark.parametrize("mesh_n,batch,layers", [(16, 3, 4), (64, 2, 2), (64, 9, 4), (33, 5, 3)], ids=['16x16-b3', '64x64-b2-L2', '64x64-b9', '33x33-b5-L3'])
+def test_wide_backward_matches_two_pass(gpu_device, mesh_n, batch, layers, monkeypatch):
+    """The wide backward (edge kernel + main kernel, csrc/gadapt_wide_bwd.inc) against the tiled target / source pair on the same
+    inputs: parameter gradients at model level (compact slots: the top layer's compact upstream gradient) and d x0 + parameter
+    gradients at block-op level, up to fp32 reassociation.  Batches of several steps per workgroup, a ragged last step, meshes whose
+    rows do not align with the 256-node steps."""
+    import g_adaptivity_amd.graph as graph_mod
     from g_adaptivity_amd._native import lib
-    if lib().gadapt_debug_set_fused_backward(1) != 0:
-        pytest.skip("library built without -DGADAPT_WITH_FUSED_BWD (`make FUSED_BWD=1`): the fused dense backward is not in the default build")
-    lib().gadapt_debug_set_fused_backward(0)
-    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=hidden, num_layers=4, device=str(gpu_device), show_mesh_evol_plots='False')
+    monkeypatch.setattr(graph_mod, 'WIDE_MIN_NODES', 0)
+    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=64, num_layers=layers, device=str(gpu_device), show_mesh_evol_plots='False')
     ds = MeshDataset([mesh_n, mesh_n], batch, seed=9)
     data = collate(ds.samples).to(gpu_device)
     torch.manual_seed(5)
     model = GNN(ds, opt).to(gpu_device).train()
     res = {}
-    for fused in (0, 1):
-        lib().gadapt_debug_set_fused_backward(fused)
+    for wide in (0, 1):
+        Fn.set_wide_backward(wide)
         try:
             model.zero_grad()
             F.mse_loss(model(data), data.x_phys).backward()
             torch.cuda.synchronize()
-            res[fused] = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+            res[wide] = [p.grad.clone() for p in model.parameters() if p.grad is not None]
         finally:
-            lib().gadapt_debug_set_fused_backward(0)
+            Fn.set_wide_backward(False)
+    g = next(iter(model._graphs.values()))
+    assert g.wide_backward_ws_floats > 0, "the mesh batch must qualify for the wide backward, or this test compares the pair with itself"
     assert len(res[0]) == 4
     for a, b in zip(res[0], res[1]):
         if a.abs().max() > 0:
             assert rel_err(b, a)[0] <= 2e-5, rel_err(b, a)
-    # operator level on a random graph: d x through the block op (dense x0 gradient wanted -> layer 0 is a dense layer too)
-    C = hidden
-    n = 700
-    ei = torch.cat([_random_graph(n, 3000, 21), torch.tensor([[3] * 30, list(range(100, 130))]), torch.tensor([list(range(200, 240)), [11] * 40])], dim=1)
-    ei = ei[:, ei[1] != 17]
-    graph = MeshGraph(ei, n, gpu_device)
+    # operator level: d x0 wanted, compact upstream gradient through out_cols
+    C = 64
+    graph = g
+    n = graph.num_nodes
     wq, bq, wk, bk = [w.unsqueeze(0) for w in _random_layer(C, 22, gpu_device)]
-    lp = torch.tensor([[0.1, 1.0 / math.sqrt(C)]] * 3, device=gpu_device)
+    lp = torch.tensor([[0.1, 1.0 / math.sqrt(C)]] * layers, device=gpu_device)
     x0 = torch.randn(n, C, generator=torch.Generator().manual_seed(23)).to(gpu_device)
-    up = torch.randn(n, C, generator=torch.Generator().manual_seed(24)).to(gpu_device)
+    up = torch.randn(n, 2, generator=torch.Generator().manual_seed(24)).to(gpu_device)
     outs = {}
-    for fused in (0, 1):
-        lib().gadapt_debug_set_fused_backward(fused)
+    for wide in (0, 1):
+        Fn.set_wide_backward(wide)
         try:
             xr = x0.clone().requires_grad_(True)
             ps = [t.clone().requires_grad_(True) for t in (wq, bq, wk, bk)]
-            y, _ = Fn.grand_euler_block(xr, *ps, lp, graph, 3)
+            y, _ = Fn.grand_euler_block(xr, *ps, lp, graph, layers, out_cols=2)
             (y * up).sum().backward()
             torch.cuda.synchronize()
-            outs[fused] = [xr.grad.clone()] + [t.grad.clone() for t in ps[:3]]
+            outs[wide] = [xr.grad.clone()] + [t.grad.clone() for t in ps[:3]]
         finally:
-            lib().gadapt_debug_set_fused_backward(0)
+            Fn.set_wide_backward(False)
     for a, b in zip(outs[0], outs[1]):
         assert rel_err(b, a)[0] <= 2e-5, rel_err(b, a)

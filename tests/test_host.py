@@ -83,7 +83,7 @@ def test_every_declared_symbol_is_exported():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/gadapt_hip.h but not exported"
     assert declared == set(_native.PROTOTYPES), declared ^ set(_native.PROTOTYPES)
-    assert _native.lib().gadapt_abi_version() == 5
+    assert _native.lib().gadapt_abi_version() == 6
     # argument checks need no GPU: the gradient-exchange entry point refuses a null communicator before it looks for RCCL
     assert _native.lib().gadapt_allreduce_flat(None, None, 0, 0, None) == -1
     assert b'allreduce_flat' in _native.lib().gadapt_last_error()
@@ -392,3 +392,26 @@ def test_device_mesh_loader_fields_and_static_sink_on_cpu():
             seen_static += int(any(b is s for s in sinks.values()))
     assert set(sinks) == {4 * 49, 2 * 49}                           # one static batch per batch size (10 = 4 + 4 + 2)
     assert seen_static == 6 - 2                                     # every batch but the first of each size IS the static object
+
+
+def test_ell_cross_positions_pair_the_two_orientations():
+    """gadapt_ell_cross_host: the edge in slot k of node i's in-row and the same edge in its source's out-row point at each other."""
+    from g_adaptivity_amd import MeshDataset, collate, hot_path_opt, GNN
+    import g_adaptivity_amd.graph as graph_mod
+    ds = MeshDataset([9, 9], 3, seed=1)
+    data = collate(ds.samples)
+    ei = graph_mod.prepare_edge_index(data, 2, 9, True, False, 243)
+    g = MeshGraph(ei, 243, 'cpu')
+    assert g._xpos is not None and g.wide_backward_ws_floats == 256 * 8 * 4
+    xt, xs = g._xpos
+    et, es = g._ells['t'], g._ells['s']
+    rt, rs = g.rowptr_t.long(), g.rowptr_s.long()
+    seen = 0
+    for i in range(243):
+        for k in range(int(rt[i + 1] - rt[i])):
+            q = int(xt[8 * i + k])
+            src = int(et[8 * i + k])
+            assert q // 8 == src and int(es[q]) == i and int(xs[q]) == 8 * i + k
+            seen += 1
+        assert (xt[8 * i + int(rt[i + 1] - rt[i]):8 * i + 8] == -1).all()
+    assert seen == g.num_edges and (xt[8 * 243:] == -1).all() and (xs[8 * 243:] == -1).all()
