@@ -152,8 +152,26 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: start the N ranks as a CHILD job (one process per GPU under torch.distributed.run),
+            # relay its one JSON line and its exit code.  Before anything here has touched a GPU, and never through exec: this
+            # process only waits.
+            import socket
+            import subprocess
+            with socket.socket() as so:
+                so.bind(('127.0.0.1', 0))
+                port = so.getsockname()[1]
+            cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+                   '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            env = dict(os.environ)
+            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+            lines = [ln for ln in child.stdout.splitlines() if ln.startswith('{')]
+            if lines:
+                print(lines[-1])
+            sys.stdout.flush()
+            raise SystemExit(child.returncode if child.returncode else (0 if lines else 1))
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or plainly (the ranks are then started from here)")
     import torch.distributed as dist
     # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (never used by the driver): GADAPT_BENCH_SHARE_GPU=1
     # maps the ranks onto the GPUs that exist, GADAPT_BENCH_BACKEND=gloo moves the collectives off RCCL (which needs one GPU per rank)
@@ -314,6 +332,27 @@ def main():
     elapsed, windows = summarise(timed_windows(main_run['step']))     # the headline: the MEDIAN window
     meshes = w['batch'] * world * args.steps
     value = meshes / elapsed
+
+    # N > 1: what the gradient exchange costs per step (latency-bound, reported as us/step) - the collective
+    # the step issues (FlatAdam.all_reduce on the flat gradient bucket), alone on the stream, event pair around it (RCCL) or host
+    # clock around call + synchronisation (other backends); median of 30
+    allreduce_us = None
+    if world > 1 and optim.grad_bucket is not None:
+        samples = []
+        for _ in range(35):
+            barrier(); torch.cuda.synchronize()
+            if backend == 'nccl':
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); optim.all_reduce(); e1.record()
+                torch.cuda.synchronize()
+                samples.append(1e3 * e0.elapsed_time(e1))
+            else:
+                t0 = time.perf_counter(); optim.all_reduce(); torch.cuda.synchronize()
+                samples.append(1e6 * (time.perf_counter() - t0))
+        samples = sorted(samples[5:])
+        t = torch.tensor([samples[len(samples) // 2]], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce_us = round(float(t.item()), 2)
 
     # the other slot flow in the same run: the headline's compact slots follow the identity encoder's
     # zero-pad contract; the dense flow is the literal one SURVEY.md 8(d)'s bytes describe.  Fused GRAND kernels only.
@@ -556,6 +595,11 @@ def main():
                        'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'root_gradient': 'created per step (loss.backward())' if root is None else 'preallocated (unit_gradient)', 'slots': 'dense' if args.dense_slots else 'compact', 'slots_note': None if args.dense_slots else 'identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the [N,4] encoder output in forward and backward, layer 1 hands it the 4 gradient columns it reads, the last layer writes the [N,4] head the model returns (GNN.py:299) and takes the compact top gradient; --dense-slots runs the literal dense flow', 'launch': ('hipgraph+adam' if world == 1 else ('hipgraph+allreduce+adam' if capture_all else 'hipgraph, then allreduce+adam')) if graph is not None else 'eager'},
             'roofline': roofline, 'roofline_mfma': roofline_mfma, 'kernels': kernels, 'cpu_baseline': cpu, 'train_loop': train_loop,
         }
+        if world > 1:
+            line['allreduce_us_per_step'] = allreduce_us
+            line['rccl'] = {'world': world, 'backend': backend, 'captured': bool(graph is not None and capture_all),
+                            'bucket_bytes': None if optim.grad_bucket is None else 4 * optim.grad_bucket.numel(),
+                            'timing': 'HIP event pair around the collective alone on the stream' if backend == 'nccl' else 'host clock around call + synchronize'}
         if companion is not None:                                     # same run, the other slot flow (see above)
             key = 'dense_slots' if companion['slots'] == 'dense' else 'compact_slots'
             line['value_' + key], line['ms_per_step_' + key] = companion['value'], companion['ms_per_step']

@@ -52,6 +52,8 @@ class MeshData:
         for k in self.keys():
             v = getattr(self, k)
             out.__dict__[k] = v.clone() if torch.is_tensor(v) else copy.deepcopy(v)
+        if '_num_graphs' in self.__dict__:                   # the collation's graph count travels with the copy (a clone without it
+            out.__dict__['_num_graphs'] = self.__dict__['_num_graphs']   # falls back to batch.max(): a host synchronisation)
         return out
 
     @property
@@ -433,6 +435,9 @@ class DeviceMeshLoader:
             idx = order[s:s + self.batch_size]
             b = int(idx.numel())
             static = self._static.get(b)
+            owner = getattr(self.into, '__self__', None)              # GraphedTrainStep.static_batch: the step may have evicted the capture
+            if static is not None and owner is not None and hasattr(owner, 'owns') and not owner.owns(static):
+                static = self._static.pop(b, None) and None           # gather into fresh tensors below and ask the step again
             if static is not None:                                    # gathers land in the captured step's input buffers
                 self._gather(idx, [getattr(static, k) for k in self.fields])
                 static.idx = idx

@@ -41,6 +41,10 @@ class GraphedTrainStep:
     the collective is captured with the step.
 
     Returns the STATIC 0-d loss tensor of the captured graph (overwritten by the next call: accumulate or clone it).
+
+    Under data parallelism every rank must call the step once per iteration (as with any all-reduce); WHEN a rank captures is its
+    own business - a capture's warm-up issues no collective.  Hyper-parameters of the captured Adam launch (lr, betas, eps,
+    weight_decay) are kernel arguments: a change of `optimizer.param_groups[0]` drops the captures and the next call re-captures.
     """
 
     def __init__(self, model, optimizer: FlatAdam, loss_fn: Callable = mse_loss, target_field: str = 'x_phys', warmup: int = 2,
@@ -61,7 +65,8 @@ class GraphedTrainStep:
         self.capture_optimizer = bool(capture_optimizer)
         self.device = torch.device(model.opt['device'])
         self.max_graphs = max_graphs
-        self._captured: Dict[Tuple, _Captured] = {}
+        self._captured: Dict[Tuple, _Captured] = {}          # insertion order = recency (see _lookup)
+        self._hyper_captured: Optional[Tuple] = None
         self._side = torch.cuda.Stream(device=self.device)
         # the native one-launch losses take the preallocated root gradient (functional.unit_gradient): two launches fewer
         from .functional import l1_loss
@@ -126,14 +131,25 @@ class GraphedTrainStep:
         dev = self.device
         c = _Captured()
         c.static = data.clone().to(dev)                      # the graph reads these tensors by address
+        # clone() drops '_'-prefixed attributes; without the graph count the model would read `data.batch.max().item()` - a host
+        # synchronisation - inside the capture (1-D models with global features have no corner list to count instead)
+        if getattr(c.static, '_num_graphs', None) is None and getattr(data, 'batch', None) is not None:
+            c.static._num_graphs = int(data.num_graphs)      # (one synchronisation, here, outside the capture)
         cur = torch.cuda.current_stream(dev)
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             snap = self._snapshot()
-            for _ in range(self.warmup):                     # CSR cache, flat bucket, allocator: outside the capture
-                self._iteration(c.static)
-                if not self.capture_optimizer:
-                    self.optimizer.step()
+            # The warm-up runs WITHOUT the gradient all-reduce: its results are discarded (_restore), and a rank that meets a new
+            # topology - or re-captures one that was evicted - must not issue collectives its peers (replaying a cached graph)
+            # do not issue: they would pair with the wrong step.  Collectives stay one per call of __call__ on every rank.
+            dp, self.optimizer.data_parallel = self.optimizer.data_parallel, False
+            try:
+                for _ in range(self.warmup):                 # CSR cache, flat bucket, allocator: outside the capture
+                    self._iteration(c.static)
+                    if not self.capture_optimizer:
+                        self.optimizer.step()
+            finally:
+                self.optimizer.data_parallel = dp
             self._restore(snap)
         cur.wait_stream(self._side)
         torch.cuda.synchronize(dev)
@@ -153,14 +169,31 @@ class GraphedTrainStep:
         return c
 
     # ------------------------------------------------------------------ per step
-    def __call__(self, data) -> torch.Tensor:
+    def _hyper(self) -> Tuple:
+        """Optimizer hyper-parameters a captured Adam launch carries BY VALUE (kernel arguments of gadapt_adam_step_dev)."""
+        g = self.optimizer.param_groups[0]
+        return (float(g['lr']), tuple(float(b) for b in g['betas']), float(g['eps']), float(g['weight_decay']))
+
+    def _lookup(self, data) -> _Captured:
+        """The capture of `data`'s topology: least-recently-used eviction at `max_graphs`; captures whose Adam launch was recorded
+        with other hyper-parameters than the optimizer has now (an LR scheduler stepped, `param_groups` edited) are dropped first -
+        a replay would silently keep the old values."""
+        if self.capture_optimizer and self._captured:
+            hyper = self._hyper()
+            if hyper != self._hyper_captured:
+                self._captured.clear()
         key = self._key(data)
-        c = self._captured.get(key)
-        fresh = c is None
-        if fresh:
-            if len(self._captured) >= self.max_graphs:
-                self._captured.pop(next(iter(self._captured)))
-            c = self._captured[key] = self._capture(data)
+        c = self._captured.pop(key, None)
+        if c is None:
+            while len(self._captured) >= max(self.max_graphs, 1):
+                self._captured.pop(next(iter(self._captured)))       # the least recently used one
+            self._hyper_captured = self._hyper()
+            c = self._capture(data)
+        self._captured[key] = c                                      # (re-)inserted last = most recently used
+        return c
+
+    def __call__(self, data) -> torch.Tensor:
+        c = self._lookup(data)
         if data is not c.static:
             for name in INPUT_FIELDS + (self.target_field,):
                 src = getattr(data, name, None)
@@ -179,8 +212,8 @@ class GraphedTrainStep:
     def static_batch(self, data):
         """The static batch object of `data`'s topology (captured on first use).  A loader that writes its node fields straight
         into these tensors (`DeviceMeshLoader(..., into=step.static_batch)`) saves the per-step copies."""
-        key = self._key(data)
-        c = self._captured.get(key)
-        if c is None:
-            c = self._captured[key] = self._capture(data)
-        return c.static
+        return self._lookup(data).static
+
+    def owns(self, static) -> bool:
+        """True while `static` is the static batch of a live capture (a loader holding an evicted one must ask again)."""
+        return any(c.static is static for c in self._captured.values())

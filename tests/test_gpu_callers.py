@@ -224,6 +224,27 @@ def test_bench_two_ranks_rehearsal(gpu_device, capture_allreduce):
         assert 'GADAPT_BENCH_CAPTURE_ALLREDUCE=1 ignored' in r.stderr
 
 
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_its_own_ranks(gpu_device):
+    """Plain `python bench.py --gpus 2` - how the driver invokes `--gpus 1` - must start the two ranks itself (a child
+    torch.distributed.run before anything touches a GPU) and relay ONE JSON line with n_gpus 2, the all-reduce time per step and
+    the collective's description.  Rehearsed on the one GPU of the test box (shared GPU, gloo collectives), as above."""
+    import math
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(GADAPT_BENCH_SHARE_GPU='1', GADAPT_BENCH_BACKEND='gloo')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2', '--windows', '2', '--no-companion'],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['scaling'] == 'weak'
+    assert math.isfinite(d['value']) and d['value'] > 0
+    assert d['rccl']['world'] == 2 and d['rccl']['backend'] == 'gloo' and d['rccl']['captured'] is False and d['rccl']['bucket_bytes'] == 4 * (2 * 64 * 64 + 2 * 64)
+    assert d['allreduce_us_per_step'] is not None and math.isfinite(d['allreduce_us_per_step']) and d['allreduce_us_per_step'] > 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("hidden", [16, 64])
 def test_mixed_size_batch_parity(gpu_device, hidden):

@@ -310,3 +310,38 @@ def test_graphed_train_step_other_losses_and_eviction(gpu_device, loss_name):
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
     assert not torch.equal(res[0][0][1], state['conv_layers.0.lin_key.weight'].to(gpu_device))
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_1d_global_features_and_lr_change(gpu_device):
+    """(a) a 1-D model with global CNN features has no corner list to count the meshes from - the static batch of a
+    capture must carry the collation's graph count, or the captured forward would synchronise with the host (`batch.max().item()`)
+    and invalidate the capture; (b) the captured Adam launch carries lr by value - an LR change must re-capture, not be ignored;
+    (c) captures are kept in least-recently-used order.  Replayed training equals the eager loop throughout."""
+    from g_adaptivity_amd import DeviceMeshLoader, GraphedTrainStep
+    opt = hot_path_opt(mesh_dims=[21], hidden_dim=16, num_layers=2, device=str(gpu_device), gnn_inc_glob_feat_f=True,
+                       gnn_inc_glob_feat_uu=True, lr=1e-3)
+    ds = MeshDataset([21], 10, seed=3)                                   # batches of 4, 4, 2
+    torch.manual_seed(0)
+    base = GNN(ds, opt).to(gpu_device).train()
+    state = copy.deepcopy(base.state_dict())
+    res, steps = [], []
+    for graphed in (False, True):
+        m = GNN(ds, opt).to(gpu_device).train(); m.load_state_dict(copy.deepcopy(state))
+        o = FlatAdam(m.parameters(), lr=opt['lr'], capturable=True)
+        step = GraphedTrainStep(m, o, max_graphs=2)
+        for epoch in range(3):
+            if epoch == 2:
+                o.param_groups[0]['lr'] = 5e-3                           # what an LR scheduler does
+            for d in DeviceMeshLoader(ds, batch_size=4, shuffle=False, device=gpu_device):
+                (step if graphed else step.eager)(d)
+        torch.cuda.synchronize()
+        res.append({n: p.detach().clone() for n, p in m.named_parameters()})
+        steps.append(step)
+    for n in res[0]:
+        assert (res[0][n] - res[1][n]).abs().max().item() <= 1e-6, n    # (MIOpen's weight gradients use atomics: last-bit band)
+    g = steps[1]
+    assert len(g._captured) == 2 and g._hyper_captured[0] == 5e-3        # re-captured at the new learning rate
+    keys = list(g._captured)
+    g(next(iter(DeviceMeshLoader(ds, batch_size=4, shuffle=False, device=gpu_device))))   # a hit moves the key to the recent end
+    assert list(g._captured)[-1] == keys[0] and len(g._captured) == 2
