@@ -248,6 +248,7 @@ extern "C" int gadapt_profile_reset(void) {
 #include "gadapt_small.inc"
 #include "gadapt_wide.inc"
 #include "gadapt_wide_bwd.inc"
+#include "gadapt_smallmesh.inc"
 
 // ------------------------------------------------------------------------------------------------
 // launchers
@@ -940,6 +941,53 @@ extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, 
                                      int c, void* stream) {
     return gadapt_block_backward_ws(g, x_all, x0_cols, alpha_all, g_top, g_top_cols, n_layers, a, a_stride, p0, p0_stride, layer_params, g_ws, dxd_ws, edge_ws,
                                     slab, d_layer_params, want_d_scale, d_x0, c, stream, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one-launch evaluation forward of a batch of small meshes (gadapt_smallmesh.inc)
+// ------------------------------------------------------------------------------------------------
+extern "C" int64_t gadapt_small_forward_lds_bytes(int max_mesh_nodes, int max_mesh_edges, int c) {
+    // one node per thread: 1024 nodes per mesh at most (512 at hidden 32: a row, its projection and its aggregate are 96 registers)
+    if (max_mesh_nodes <= 0 || max_mesh_edges < 0 || max_mesh_nodes > (c == 32 ? 512 : 1024)) return -1;
+    int64_t fl;
+    switch (c) {
+        case 4: fl = smallmesh::lds_floats<4>(max_mesh_nodes, max_mesh_edges); break;
+        case 8: fl = smallmesh::lds_floats<8>(max_mesh_nodes, max_mesh_edges); break;
+        case 16: fl = smallmesh::lds_floats<16>(max_mesh_nodes, max_mesh_edges); break;
+        case 32: fl = smallmesh::lds_floats<32>(max_mesh_nodes, max_mesh_edges); break;
+        default: return -1;
+    }
+    return 4 * fl <= 160 * 1024 ? 4 * fl : -1;
+}
+template <int C> static void launch_small(const smallmesh::Args& p, int n_meshes, int lds, hipStream_t st) {
+    auto go = [&](auto kern, int nt) { allow_lds(kern, lds); hipLaunchKernelGGL(kern, dim3(n_meshes), dim3(nt), lds, st, p); };
+    const int nt = smallmesh::threads_for(p.max_nodes);
+    if (nt == 256) go(smallmesh::fwd_kernel<C, 256>, 256);
+    else if (nt == 512) go(smallmesh::fwd_kernel<C, 512>, 512);
+    else if constexpr (C < 32) go(smallmesh::fwd_kernel<C, 1024>, 1024);
+}
+extern "C" int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_ptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
+                                    const float* x_comp, int dim, const float* f, const float* uu, const float* enc_w, int n_feat,
+                                    const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
+                                    const float* layer_params, int n_layers, float* out, int out_cols, float* alpha_all, int c, void* stream) {
+    if (!g || !g->rowptr_t || !g->col_t || !mesh_ptr || n_meshes <= 0 || !x_comp || !enc_w || !wq || !bq || !wk || !layer_params || !out)
+        return fail(GADAPT_E_BADARG, "small_forward: null pointer");
+    if (dim < 1 || dim > 4 || n_feat != dim + (f ? 1 : 0) + (uu ? 1 : 0) || n_feat > smallmesh::MAXF || n_layers <= 0 || n_layers > smallmesh::MAX_LAYERS
+        || out_cols < 1 || out_cols > c)
+        return fail(GADAPT_E_BADARG, "small_forward: 1..4 coordinates, encoder columns = coordinates + extras, at most 64 layers, 1 <= out_cols <= hidden");
+    const int64_t lds = gadapt_small_forward_lds_bytes(max_mesh_nodes, max_mesh_edges, c);
+    if (lds < 0) return fail(GADAPT_E_BADARG, "small_forward: hidden in {4,8,16,32}, at most 1024 nodes per mesh (512 at hidden 32), rows + CSR slice within 160 KB of LDS");
+    smallmesh::Args p{x_comp, f, uu, enc_w, dim, n_feat, wq, bq, wk, w_stride, b_stride, layer_params, g->rowptr_t, g->col_t, mesh_ptr,
+                      out, out_cols, alpha_all, n_layers, g->n_edges, max_mesh_nodes, max_mesh_edges};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(9, st, 0);
+    switch (c) {
+        case 4: launch_small<4>(p, n_meshes, (int)lds, st); break;
+        case 8: launch_small<8>(p, n_meshes, (int)lds, st); break;
+        case 16: launch_small<16>(p, n_meshes, (int)lds, st); break;
+        default: launch_small<32>(p, n_meshes, (int)lds, st); break;
+    }
+    return check_launch("smallmesh::fwd_kernel");
 }
 
 #include "gadapt_sparse.inc"

@@ -386,6 +386,45 @@ def encode_features(x_comp: torch.Tensor, f_tensor: Optional[torch.Tensor], uu_t
     return x0
 
 
+# One-launch evaluation forward of a batch of small meshes (csrc/gadapt_smallmesh.inc); False keeps the per-layer launches
+# everywhere (tests compare the two).
+SMALL_MESH_FORWARD = os.environ.get('GADAPT_SMALL_MESH', '1') != '0'
+
+
+def small_forward_policy(c: int, max_nodes: int) -> bool:
+    """Sizes at which the one-launch forward is the faster one (tools/sweep_small_mesh.py): one node per thread, so wide rows on
+    large meshes run long serial chains in a single workgroup."""
+    return c <= 8 or (c == 16 and max_nodes <= 256)
+
+
+def small_forward_fits(graph: MeshGraph, part, c: int) -> bool:
+    """True when gadapt_small_forward takes this partition at hidden size c (rows + CSR slice of the largest mesh within the LDS)
+    and the size is one where it pays."""
+    return part is not None and c in (4, 8, 16, 32) and small_forward_policy(c, part[2]) \
+        and lib().gadapt_small_forward_lds_bytes(part[2], part[3], c) > 0
+
+
+@torch.no_grad()
+def small_forward(graph: MeshGraph, part, x_comp, f_tensor, uu_tensor, enc_weight, wq, bq, wk, layer_params, num_layers: int,
+                  out_cols: int, want_alpha: bool = False):
+    """x_phys [N,out_cols] (and alpha [L,E] in target-CSR order, or None) of encoder + L Euler steps + head in ONE launch, one
+    workgroup per mesh (`src/GNN.py:225-299` for batches of small meshes: the reference's own sizes).  Inference only: nothing is
+    kept for a backward.  wq / bq / wk: [S,C,C] / [S,C], S = 1 (shared conv) or L; layer_params [L,2] = (dt, score scale)."""
+    _require_gpu(x_comp, 'x_comp')
+    n, dim = x_comp.shape
+    c, S = wq.shape[1], wq.shape[0]
+    dev = x_comp.device
+    mesh_ptr, n_meshes, max_nodes, max_edges = part
+    out = torch.empty(n, out_cols, device=dev, dtype=torch.float32)
+    alpha = torch.empty(num_layers, max(graph.num_edges, 1), device=dev, dtype=torch.float32) if want_alpha else None
+    check(lib().gadapt_small_forward(graph.c_ref, ptr(mesh_ptr), n_meshes, max_nodes, max_edges, ptr(x_comp.contiguous()), dim,
+                                     ptr(f_tensor), ptr(uu_tensor), ptr(enc_weight.contiguous()), enc_weight.shape[1],
+                                     ptr(wq.contiguous()), ptr(bq.contiguous()), ptr(wk.contiguous()), c * c if S > 1 else 0, c if S > 1 else 0,
+                                     ptr(layer_params.contiguous()), num_layers, ptr(out), out_cols, ptr(alpha), c, current_stream(dev)),
+          'gadapt_small_forward')
+    return out, alpha
+
+
 _loss_scratch = {}
 
 

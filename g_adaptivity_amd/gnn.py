@@ -234,6 +234,47 @@ class GNN(nn.Module):
                 and o.get('gat_plus_type') in ('GAT_res_lap', 'GAT_lin') and o['non_lin'] in Fn.NONLIN_CODES
                 and o.get('fused_gat_plus', True) and not (self.training and o.get('dropout', 0.0) > 0))
 
+    # ------------------------------------------------------------------ one-launch forward of small-mesh batches
+    def _small_plan(self, data, graph, x_comp, f, uu):
+        """Everything `functional.small_forward` needs besides the node fields, or None when the batch / the model state does not
+        qualify: evaluation (autograd off), fusable conv, frozen bias-free Linear encoder on fp32 fields, hidden <= 32, meshes that
+        are contiguous node ranges and fit a workgroup (graph.mesh_partition, functional.small_forward_fits)."""
+        o = self.opt
+        if not (Fn.SMALL_MESH_FORWARD and self._fusable() and not torch.is_grad_enabled() and o['hidden_dim'] <= 32
+                and isinstance(self.enc, nn.Linear) and self.enc.bias is None and x_comp.dtype == torch.float32
+                and all(t is None or (t.dtype == torch.float32 and t.dim() == 1 and t.is_contiguous()) for t in (f, uu))
+                and o['loss_type'] in ('mesh_loss', 'modular')):
+            return None
+        part = graph.mesh_partition(getattr(data, 'batch', None))
+        if not Fn.small_forward_fits(graph, part, o['hidden_dim']):
+            return None
+        dev = x_comp.device
+        first = self.conv_layers[0]
+        if o['share_conv']:
+            wq, bq, wk = (t.detach().unsqueeze(0) for t in (first.lin_query.weight, first.lin_query.bias, first.lin_key.weight))
+        else:
+            wq = torch.stack([l.lin_query.weight.detach() for l in self.conv_layers])
+            bq = torch.stack([l.lin_query.bias.detach() for l in self.conv_layers])
+            wk = torch.stack([l.lin_key.weight.detach() for l in self.conv_layers])
+        lp = self._layer_params(dev)
+        if o.get('learn_step'):                                            # _layer_params returned the [L] scales alone
+            lp = torch.stack([torch.cat([s_.detach().reshape(1) for s_ in self.steps]), lp.detach()], dim=1)
+        store = o['conv_type'] == 'GRAND' or isinstance(o.get('show_mesh_evol_plots'), bool)
+        ident = isinstance(self.dec, nn.Identity)
+        return {'graph': graph, 'part': part, 'wq': wq.contiguous(), 'bq': bq.contiguous(), 'wk': wk.contiguous(), 'lp': lp.detach().contiguous(),
+                'enc_w': self.enc.weight.detach().contiguous(), 'store': store, 'ident': ident, 'out_cols': self.dim if ident else o['hidden_dim']}
+
+    def _small_run(self, plan, x_comp, f, uu):
+        x, alpha = Fn.small_forward(plan['graph'], plan['part'], x_comp, f, uu, plan['enc_w'], plan['wq'], plan['bq'], plan['wk'], plan['lp'],
+                                    self.opt['num_layers'], plan['out_cols'], want_alpha=plan['store'])
+        if plan['store']:                                                  # GRAND_plus.py:253-256, :381
+            for l, layer in enumerate(self.conv_layers):
+                layer.stored_ei, layer._stored = plan['graph'].edge_index, (plan['graph'], alpha[l])
+        if not plan['ident']:
+            x = self.dec(x) if self.dec is not None else x                 # GNN.py:298
+            x = x[:, :self.dim]                                            # GNN.py:299
+        return x
+
     # ------------------------------------------------------------------ forward
     def forward(self, data):
         o = self.opt
@@ -282,6 +323,16 @@ class GNN(nn.Module):
         x_all, sliced, x0_cols = None, False, 0
         feats, coeffs = None, None
         first = self.conv_layers[0]
+        # ---- small meshes, evaluation: encoder + all layers + head as ONE launch, one workgroup per mesh (the reference's own
+        # sizes: params.py:37,56,107,130-134; utils_eval.py:193-201, utils_eval_Burgers.py:282-300)
+        if fusable and not glob:
+            plan = self._small_plan(data, graph, x_comp, f, uu)
+            if plan is not None:
+                x = self._small_run(plan, x_comp, f, uu)
+                if not self.training and not torch.cuda.is_current_stream_capturing():
+                    torch.cuda.current_stream(dev).synchronize()           # the stamp is read as a latency (utils_eval.py:201)
+                self.end_MLmodel = time.time()                             # GNN.py:301
+                return x
         # weight-shared conv (GNN.py:131-140): its composite coefficients ride in the encoder's launch
         conv_w = (first.lin_query.weight, first.lin_query.bias, first.lin_key.weight) \
             if (fusable and o['share_conv'] and o['hidden_dim'] in Fn._native.SUPPORTED_HIDDEN) else None

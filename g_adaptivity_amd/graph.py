@@ -192,6 +192,8 @@ class MeshGraph:
             if _native.lib().gadapt_wide_window_host(rowptr_t.data_ptr(), col_t.data_ptr(), n, 128, 7, C.addressof(md)) != 0:
                 raise _native.NativeError("gadapt_wide_window_host failed")
             self.wide_big_deg = int(md.value)
+        self._cpu_csr_t = (rowptr_t, col_t)                 # host copies for mesh_partition()
+        self._partitions: Dict[Tuple, Optional[Tuple]] = {}
         self.edge_index = edge_index                        # as given (original order/device)
         self.rowptr_t, self.col_t, self.eid_t = (t.to(self.device) for t in (rowptr_t, col_t, eid_t))
         self.rowptr_s, self.col_s, self.perm_s, self.tpos_s = (t.to(self.device) for t in (rowptr_s, col_s, perm_s, tpos_s))
@@ -204,6 +206,40 @@ class MeshGraph:
                                     ells['t'].data_ptr(), ells['s'].data_ptr(), wide_deg['t'], wide_deg['s'], self.wide_big_deg,
                                     self._xpos[0].data_ptr() if self._xpos else None, self._xpos[1].data_ptr() if self._xpos else None)
         self.c_ref = C.byref(self.c_struct)
+
+    def mesh_partition(self, batch: Optional[torch.Tensor]):
+        """(mesh_ptr int32 [B+1] on the device, n_meshes, max nodes per mesh, max in-edges per mesh) when the meshes of the batch are
+        contiguous node ranges that no edge leaves - what PyG collation produces (`batch` non-decreasing, edge_index offset per
+        graph) - else None.  `batch=None`: the whole graph is one mesh.  Checked once per `batch` content (one host
+        synchronisation), then a dictionary lookup: the one-launch small-mesh forward (csrc/gadapt_smallmesh.inc) needs it."""
+        key = () if batch is None else content_fingerprint([batch])
+        if key in self._partitions:
+            return self._partitions[key]
+        n = self.num_nodes
+        rowptr, col = self._cpu_csr_t
+        part = None
+        if batch is None:
+            ptr_ = torch.tensor([0, n], dtype=torch.int64)
+            ok = True
+        else:
+            b = batch.detach().to('cpu', torch.int64).reshape(-1)
+            ok = b.numel() == n and n > 0 and bool((b[1:] >= b[:-1]).all()) and int(b[0]) == 0
+            if ok:
+                counts = torch.bincount(b)
+                ok = bool((counts > 0).all())
+                ptr_ = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)])
+                if ok and self.num_edges:
+                    deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+                    dst = torch.repeat_interleave(torch.arange(n, dtype=torch.int64), deg)
+                    ok = bool((b[col[:self.num_edges].to(torch.int64)] == b[dst]).all())
+        if ok:
+            rp = rowptr.to(torch.int64)
+            e_per = rp[ptr_[1:]] - rp[ptr_[:-1]]
+            part = (ptr_.to(torch.int32).to(self.device), int(ptr_.numel() - 1), int((ptr_[1:] - ptr_[:-1]).max()), int(e_per.max()))
+        if len(self._partitions) > 8:
+            self._partitions.clear()
+        self._partitions[key] = part
+        return part
 
     @property
     def wide_backward_ws_floats(self) -> int:

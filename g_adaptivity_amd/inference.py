@@ -6,6 +6,10 @@ Burgers rollout re-invokes it every time step on the same mesh with a new `uu_te
 host's launch path.  `GraphedForward` captures `model(data)` once (eval mode, no autograd) into a hipGraph over static
 input buffers; every later call copies the new node fields into those buffers and replays the graph: one launch from the
 host, no Python in between.  The topology (edge list, masks, node count) is fixed by the captured batch.
+
+Small meshes (the reference's own sizes) do better still: their whole forward is ONE kernel (csrc/gadapt_smallmesh.inc), so there is
+nothing to capture - `GraphedForward` then launches that kernel directly on the caller's field tensors: no static buffers, no copies,
+no graph launch (`direct` is True).
 """
 from __future__ import annotations
 
@@ -23,7 +27,23 @@ class GraphedForward:
             raise RuntimeError("GraphedForward captures the evaluation forward: call model.eval() first")
         self.model = model
         dev = torch.device(model.opt['device'])
+        self.device = dev
+        self.direct, self._plan = False, None
         self.static = data.clone().to(dev)                 # the graph reads these tensors by address
+        o = model.opt
+        if not o.get('gnn_normalize') and not (o.get('gnn_inc_glob_feat_f') or o.get('gnn_inc_glob_feat_uu')):
+            with torch.no_grad():
+                xc = self.static.x_comp if self.static.x_comp.dim() == 2 else self.static.x_comp.unsqueeze(-1)
+                graph = model._graph(self.static, xc.shape[0], dev)
+                f = self.static.f_tensor if o['gnn_inc_feat_f'] else None
+                uu = self.static.uu_tensor if o['gnn_inc_feat_uu'] else None
+                self._plan = model._small_plan(self.static, graph, xc, f, uu)
+        if self._plan is not None:                         # one kernel per call: launched directly, nothing to capture
+            self.direct = True
+            self._use_f, self._use_uu = bool(o['gnn_inc_feat_f']), bool(o['gnn_inc_feat_uu'])
+            self._last = {}
+            self._prepare_direct()
+            return
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.no_grad(), torch.cuda.stream(side):
@@ -34,13 +54,72 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph, stream=side):
             self.out = model(self.static)
-        self.device = dev
         self._last = {}                                    # field -> (source tensor, its version) of the last copy
+
+    # ------------------------------------------------------------------ small meshes: one kernel, launched directly
+    def _prepare_direct(self):
+        """The argument list of gadapt_small_forward, built once: per call only the three field pointers and the stream change."""
+        from . import _native
+        from .functional import current_stream
+        pl, m = self._plan, self.model
+        graph, (mesh_ptr, n_meshes, max_nodes, max_edges) = pl['graph'], pl['part']
+        n = graph.num_nodes
+        c, S, L = pl['wq'].shape[1], pl['wq'].shape[0], m.opt['num_layers']
+        self.out = torch.empty(n, pl['out_cols'], device=self.device, dtype=torch.float32)
+        self._alpha = torch.empty(L, max(graph.num_edges, 1), device=self.device, dtype=torch.float32) if pl['store'] else None
+        dim = m.dim
+        n_feat = pl['enc_w'].shape[1]
+        self._fn = _native.lib().gadapt_small_forward
+        self._stream = current_stream
+        self._args = [graph.c_ref, mesh_ptr.data_ptr(), n_meshes, max_nodes, max_edges, None, dim, None, None, pl['enc_w'].data_ptr(), n_feat,
+                      pl['wq'].data_ptr(), pl['bq'].data_ptr(), pl['wk'].data_ptr(), c * c if S > 1 else 0, c if S > 1 else 0, pl['lp'].data_ptr(), L,
+                      self.out.data_ptr(), pl['out_cols'], None if self._alpha is None else self._alpha.data_ptr(), c, None]
+        self._n = n
+        if pl['store']:                                    # GRAND_plus.py:253-256, :381: the layers show the static attention tensor
+            for l, layer in enumerate(m.conv_layers):
+                layer.stored_ei, layer._stored = graph.edge_index, (graph, self._alpha[l])
+
+    def _field(self, name, data, fields, want):
+        if not want:
+            return None
+        src = fields.get(name, getattr(data, name, None) if data is not None else None)
+        if src is None:
+            src = getattr(self.static, name)
+        else:
+            setattr(self.static, name, src)                # a field not passed next time keeps its last value, as a copy would
+        if src.dtype != torch.float32 or not src.is_contiguous() or src.device != self.device:
+            src = src.to(self.device, torch.float32).contiguous()
+            setattr(self.static, name, src)
+        if src.numel() != (self._n * self.model.dim if name == 'x_comp' else self._n):
+            raise ValueError(f"{name}: {tuple(src.shape)} does not fit the {self._n} nodes this forward was prepared for")
+        return src
+
+    def _direct_call(self, data, fields, sync):
+        a = self._args
+        xc = self._field('x_comp', data, fields, True)
+        f = self._field('f_tensor', data, fields, self._use_f)
+        uu = self._field('uu_tensor', data, fields, self._use_uu)
+        a[5], a[7], a[8] = xc.data_ptr(), None if f is None else f.data_ptr(), None if uu is None else uu.data_ptr()
+        a[22] = self._stream(self.device)
+        rc = self._fn(*a)
+        if rc != 0:
+            from . import _native
+            _native.check(rc, 'gadapt_small_forward')
+        if sync:
+            torch.cuda.current_stream(self.device).synchronize()
+        self.model.end_MLmodel = time.time()               # same stamp the eager forward leaves (GNN.py:301)
+        out = self.out
+        if not self._plan['ident']:
+            out = self.model.dec(out) if self.model.dec is not None else out   # GNN.py:298
+            out = out[:, :self.model.dim]                  # GNN.py:299
+        return out
 
     @torch.no_grad()
     def __call__(self, data=None, *, sync: bool = True, **fields) -> torch.Tensor:
         """New node fields either as a batch object (`x_comp`, `f_tensor`, `uu_tensor` are read) or as keywords.
         Returns the static output tensor (overwritten by the next call; clone it to keep it)."""
+        if self.direct:
+            return self._direct_call(data, fields, sync)
         for name in FIELDS:
             src = fields.get(name, getattr(data, name, None) if data is not None else None)
             if src is None:

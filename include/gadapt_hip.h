@@ -232,6 +232,22 @@ int gadapt_block_backward_ws(const gadapt_graph* g, const float* x_all, int x0_c
                              const float* layer_params,
                              float* g_ws, float* dxd_ws, float* edge_ws, float* slab,
                              float* d_layer_params, int want_d_scale, float* d_x0, int c, void* stream, float* wide_ws);
+/* ------------------------------------------------------------------ small meshes: the whole evaluation forward in ONE launch
+ * The reference's own sizes (params.py:37,56,107,130-134: 11x11 ... 23x23 meshes, hidden 8, 4 layers; evaluation one sample per call,
+ * utils_eval.py:128-130,193-201; the Burgers rollout, utils_eval_Burgers.py:282-300): encoder (GNN.py:225-239,270), composite
+ * coefficients, the L Euler steps (GNN.py:273-291 on GRAND_plus.py:225-343) and the head x[:, :out_cols] (GNN.py:299) by ONE workgroup
+ * per mesh - the meshes of a batch are disconnected components, so only workgroup barriers are needed.  mesh_ptr [n_meshes+1]
+ * (device): first node of each mesh; every edge must stay inside its mesh; max_mesh_nodes / max_mesh_edges: the largest mesh
+ * (<= 1024 nodes, 512 at hidden 32: one node per thread; rows + CSR slice must fit 160 KB: gadapt_small_forward_lds_bytes returns the bytes, or -1).  hidden c in
+ * {4, 8, 16, 32}.  x_comp [N,dim], f / uu [N] nullable, enc_w [c, n_feat] the frozen bias-free encoder weight; wq / bq / wk advance by
+ * w_stride / b_stride floats per layer (0 = shared); layer_params [L,2] = (dt, score scale).  out [N,out_cols]; alpha_all nullable
+ * [L,E] (target-CSR order).  No activations are kept: inference only. */
+int64_t gadapt_small_forward_lds_bytes(int max_mesh_nodes, int max_mesh_edges, int c);
+int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_ptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
+                         const float* x_comp, int dim, const float* f, const float* uu, const float* enc_w, int n_feat,
+                         const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
+                         const float* layer_params, int n_layers, float* out, int out_cols, float* alpha_all, int c, void* stream);
+
 /* partials: the workspace gadapt_block_backward filled ([2][L][n_rows], n_rows = gadapt_backward_slab_rows).  d_layer_params
  * [2,L]: row 0 = d dt_l, row 1 = d score_scale_l (zeros when want_d_scale = 0) - two contiguous rows, so a caller can hand out
  * the d dt row as the gradients of L one-element step parameters laid side by side. */

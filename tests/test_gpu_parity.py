@@ -5,7 +5,11 @@ within 1e-4 relative, measured against the oracle's fp64 twin.  ONE rule for eve
 
     error(HIP, fp64)  <=  max(1e-4, 1.5 x noise)
 
-where `noise` is the fp32 ORACLE's own error against its fp64 twin.  Some shapes cannot reach 1e-4 in fp32 at all: the 1-D case
+where `noise` is the fp32 ORACLE's own error against its fp64 twin (round 5: the band below is consulted only in a NOISY case - one where
+that single-run noise reaches half the floor, 5e-5, on some parameter; a case whose oracle is quiet must meet the 1e-4 floor - and
+every comparison is RECORDED:
+`gpurun_out/r05_parity.json` -> committed as `profiles/r05_parity.json`: per case, kernel dispatch and parameter the error against
+fp64, the single-run noise, the band if it was computed, and which rule admitted it).  Some shapes cannot reach 1e-4 in fp32 at all: the 1-D case
 (|grad| ~ 1e-6) and above all BASELINE config 4 (64x64, 6 layers, hidden 128: |grad| ~ 1e-10, the remainder of sums that cancel to
 1 part in 1e3..1e4).  There the fp32 result is a draw from a band, for the reference too: its edge order is the iteration order of
 a Python set (`src/data.py:430-441`), so its scatter sums run in another order every run.  Measured (tools/diag_accumulation.py,
@@ -25,6 +29,24 @@ from helpers import edge_order_band, hip_model_like, make_case, oracle_fp64_twin
 
 COORD_TOL = 1e-5
 GRAD_TOL = 1e-4
+
+import json   # noqa: E402
+import os     # noqa: E402
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PARITY_LOG = os.path.join(_ROOT, 'gpurun_out', 'r05_parity.json')
+
+
+def _record(case_id, rows, coord):
+    """Append one case's margins to gpurun_out/r05_parity.json (rewritten whole each time: the file stays valid JSON)."""
+    os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+    try:
+        log = json.load(open(PARITY_LOG))
+    except Exception:
+        log = {'rule': 'e64 <= max(1e-4, 1.5 * noise); noise = fp32 oracle vs its fp64 twin (one run); the worst of five edge orders '
+                       '("band") only in a noisy case: one whose single-run noise reaches 5e-5 (half the floor) on some parameter', 'grad_tol': GRAD_TOL, 'coord_tol': COORD_TOL, 'cases': {}}
+    log['cases'][case_id] = {'coordinates': coord, 'gradients': rows}
+    with open(PARITY_LOG, 'w') as fh:
+        json.dump(log, fh, indent=1, sort_keys=True)
 
 CASES = [
     # mesh_dims, batch, hidden, layers, conv_type, extra opt
@@ -122,8 +144,9 @@ for _c, _id in zip(CASES, IDS):
 @pytest.mark.one_dispatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("mesh_dims,batch,hidden,layers,conv_type,extra,wide_min_nodes", PARAMS, ids=PARAM_IDS)
-def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra, wide_min_nodes):
+def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra, wide_min_nodes, request):
     keep, _graph_mod.WIDE_MIN_NODES = _graph_mod.WIDE_MIN_NODES, wide_min_nodes
+    rows = []
     try:
         oracle, o64, model, ref, ref64, out = _run(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra)
         g = next(iter(model._graphs.values()))
@@ -165,19 +188,40 @@ def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, c
             f"output vs oracle: normwise {norm:.2e}, elementwise vs fp64 {elem64:.2e} (fp32 oracle: {noise_elem:.2e})"
     assert rel_err(out, ref64)[0] <= COORD_TOL
     n_layers = len({id(l) for l in model.conv_layers})
+    meas = []
     for li in range(n_layers):
         lo, l64, lh = oracle.conv_layers[li], o64.conv_layers[li], model.conv_layers[li]
         for name in ('lin_query.weight', 'lin_query.bias', 'lin_key.weight'):
             g32 = dict(lo.named_parameters())[name].grad
             g64 = dict(l64.named_parameters())[name].grad
             gh = dict(lh.named_parameters())[name].grad
-            e64, e32, noise = rel_err(gh, g64)[0], rel_err(gh, g32)[0], rel_err(g32, g64)[0]
-            if e64 > max(GRAD_TOL, 1.5 * noise):             # outside ONE oracle run's error: compare with the oracle's run-to-run band
-                if not band:
-                    band.update(edge_order_band(oracle, o64, model._test_batch[0].to('cpu'), model._test_batch[1].cpu()))
-                noise = max(noise, band[f'conv_layers.{li}.{name}'])
-            assert e64 <= max(GRAD_TOL, 1.5 * noise), f"layer {li} {name}.grad vs fp64 oracle: {e64:.2e} (fp32 oracle, worst of its edge orders: {noise:.2e})"
-            assert e32 <= GRAD_TOL + 2 * noise, f"layer {li} {name}.grad vs fp32 oracle: {e32:.2e} (oracle rounding {noise:.2e})"
+            meas.append((li, name, rel_err(gh, g64)[0], rel_err(gh, g32)[0], rel_err(g32, g64)[0]))
+    # A case is NOISY when the fp32 oracle's own single run misses fp64 by at least half the floor on some parameter: its gradients
+    # are then the remainder of a cancellation and one fp32 run - the reference's too - is a draw from a band (module docstring;
+    # tools/diag_wide_accuracy.py: on config 5's shape the SAME batch with another weight seed moves the oracle's error from 2e-7 to
+    # 5e-4, and which forward kernel lands closer to fp64 changes from seed to seed).  Only a noisy case may consult the band of
+    # the oracle's edge orders; a quiet case must meet the 1e-4 floor against one oracle run.
+    noisy_case = max(m[4] for m in meas) >= 0.5 * GRAD_TOL
+    coord = {'normwise': norm, 'elementwise': elem, 'vs_fp64_normwise': rel_err(out, ref64)[0]}
+    failures = []
+    for li, name, e64, e32, noise in meas:
+        single, band_val = noise, None
+        rule = 'floor' if e64 <= GRAD_TOL else 'noise'
+        if e64 > max(GRAD_TOL, 1.5 * noise) and noisy_case:
+            if not band:
+                band.update(edge_order_band(oracle, o64, model._test_batch[0].to('cpu'), model._test_batch[1].cpu()))
+            band_val = band[f'conv_layers.{li}.{name}']
+            noise = max(noise, band_val)
+            rule = 'band'
+        ok = e64 <= max(GRAD_TOL, 1.5 * noise) and e32 <= GRAD_TOL + 2 * noise
+        rows.append({'parameter': f'conv_layers.{li}.{name}', 'e64': e64, 'e32': e32, 'noise_single_run': single, 'band': band_val,
+                     'bound': max(GRAD_TOL, 1.5 * noise), 'rule': rule, 'noisy_case': bool(noisy_case), 'passed': bool(ok)})
+        if not ok:
+            failures.append(f"layer {li} {name}.grad: {e64:.2e} vs fp64, {e32:.2e} vs fp32 oracle (fp32 oracle, {'worst of its edge orders' if rule == 'band' else 'one run'}: {noise:.2e})")
+    _record(request.node.callspec.id, rows, coord)
+    assert not failures, failures
+    for li in range(n_layers):
+        lh, l64 = model.conv_layers[li], o64.conv_layers[li]
         # d/d lin_key.bias vanishes analytically (softmax shift invariance); the oracle's is rounding noise
         assert lh.lin_key.bias.grad.abs().max().item() == 0.0
         assert l64.lin_key.bias.grad.abs().max().item() <= 1e-9 * max(l64.lin_query.bias.grad.abs().max().item(), 1e-30) + 1e-18

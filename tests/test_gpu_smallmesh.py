@@ -1,0 +1,104 @@
+"""One-launch evaluation forward of small-mesh batches (csrc/gadapt_smallmesh.inc): the reference's own sizes
+(`src/params.py:37,56,107,130-134`: 11x11 ... 23x23 meshes, hidden 8, four layers; 1-D Burgers on 21 nodes, `params.py:137-159`),
+evaluated as `src/utils_eval.py:193-201` / `src/utils_eval_Burgers.py:282-300` do - against the CPU oracle and against the per-layer
+launches on the same inputs."""
+import ctypes as C
+
+import pytest
+import torch
+
+from helpers import hip_model_like, make_case, rel_err
+
+CASES = [
+    # mesh_dims, batch, hidden, layers, conv_type, extra
+    ((11, 11), 1, 8, 4, 'GRAND_plus', {}),                       # the shipped default, one sample per call
+    ((11, 11), 5, 8, 4, 'GRAND_plus', {}),
+    ((15, 15), 3, 16, 3, 'GRAND_plus', {}),
+    ((21,), 1, 8, 3, 'GRAND', {'gnn_inc_feat_f': False}),        # Burgers features (params.py:148,155)
+    ((21,), 4, 8, 1, 'GRAND', {}),
+    ((23, 23), 2, 8, 4, 'GRAND_plus', {}),                       # the largest shipped mesh (512-thread workgroups)
+    ((19, 19), 2, 32, 2, 'GRAND_plus', {}),                      # the widest rows the kernel takes (policy forced: see the test)
+    ((13, 13), 3, 8, 3, 'GRAND_plus', {'share_conv': False, 'learn_step': True}),
+    ((12, 12), 2, 4, 2, 'GRAND_plus', {'softmax_temp_type': 'fixed', 'softmax_temp': 2.0}),
+    ((10, 10), 2, 16, 2, 'GRAND_plus', {'fix_boundary': False, 'self_loops': True}),
+]
+IDS = [f"{'x'.join(map(str, c[0]))}-b{c[1]}-C{c[2]}-L{c[3]}-{c[4]}" + ('-' + ','.join(c[5]) if c[5] else '') for c in CASES]
+
+
+def _launches(kernel_id):
+    from g_adaptivity_amd._native import lib
+    tot, cnt = C.c_double(0.0), C.c_int(0)
+    lib().gadapt_profile_read(kernel_id, C.byref(tot), C.byref(cnt))
+    return cnt.value
+
+
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh_dims,batch,hidden,layers,conv_type,extra", CASES, ids=IDS)
+def test_small_mesh_forward_parity(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra, monkeypatch):
+    import g_adaptivity_amd.functional as Fn
+    from g_adaptivity_amd._native import lib
+    opt, ds, data, oracle = make_case(mesh_dims, batch, hidden, layers, conv_type, **extra)
+    model = hip_model_like(oracle, ds, opt, gpu_device).eval()
+    oracle.eval()
+    d = data.clone().to(gpu_device)
+    monkeypatch.setattr(Fn, 'small_forward_policy', lambda c, max_nodes: True)   # every size the kernel takes, not only where it is the faster one
+    with torch.no_grad():
+        ref = oracle(data)
+        lib().gadapt_profile_reset(); lib().gadapt_profile_enable(1)
+        try:
+            out = model(d)
+            torch.cuda.synchronize()
+            assert _launches(9) == 1 and _launches(0) == 0, "the evaluation forward of a small-mesh batch must be the one-launch kernel"
+            alpha_small = [l.stored_alpha.clone() for l in model.conv_layers] if conv_type == 'GRAND' else None
+            lib().gadapt_profile_reset()
+            keep, Fn.SMALL_MESH_FORWARD = Fn.SMALL_MESH_FORWARD, False
+            try:
+                per_layer = model(d)
+                torch.cuda.synchronize()
+                assert _launches(9) == 0 and _launches(0) == layers
+                alpha_layers = [l.stored_alpha.clone() for l in model.conv_layers] if conv_type == 'GRAND' else None
+            finally:
+                Fn.SMALL_MESH_FORWARD = keep
+        finally:
+            lib().gadapt_profile_enable(0); lib().gadapt_profile_reset()
+    norm, elem = rel_err(out, ref)
+    assert norm <= 1e-5 and elem <= 1e-5, f"x_phys vs fp32 oracle: normwise {norm:.2e} elementwise {elem:.2e}"
+    assert rel_err(out, per_layer)[0] <= 2e-6, rel_err(out, per_layer)
+    if alpha_small is not None:                                   # stored_alpha (GRAND_plus.py:253-256,381): same attention either way
+        for a, b in zip(alpha_small, alpha_layers):
+            assert rel_err(a, b)[0] <= 1e-5
+
+
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
+def test_small_mesh_dispatch_limits(gpu_device):
+    """Training (autograd on) and meshes too large for a workgroup's LDS keep the per-layer launches; a batch whose `batch` vector is
+    not what collation produces (meshes interleaved) is refused by the partition check, not mis-computed."""
+    import g_adaptivity_amd.functional as Fn
+    from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt
+    from g_adaptivity_amd._native import lib
+    opt = hot_path_opt(mesh_dims=[11, 11], hidden_dim=8, num_layers=2, device=str(gpu_device))
+    ds = MeshDataset([11, 11], 2, seed=0)
+    data = collate(ds.samples).to(gpu_device)
+    model = GNN(ds, opt).to(gpu_device)
+    lib().gadapt_profile_reset(); lib().gadapt_profile_enable(1)
+    try:
+        model.train()
+        model(data).sum().backward()                              # autograd on: the block op (activations kept)
+        torch.cuda.synchronize()
+        assert _launches(9) == 0 and _launches(0) == 2
+        lib().gadapt_profile_reset()
+        big = hot_path_opt(mesh_dims=[64, 64], hidden_dim=8, num_layers=2, device=str(gpu_device))
+        dsb = MeshDataset([64, 64], 1, seed=0)
+        mb = GNN(dsb, big).to(gpu_device).eval()
+        with torch.no_grad():
+            mb(collate(dsb.samples).to(gpu_device))               # 4096 nodes: more than a workgroup takes
+        torch.cuda.synchronize()
+        assert _launches(9) == 0 and _launches(0) == 2
+    finally:
+        lib().gadapt_profile_enable(0); lib().gadapt_profile_reset()
+    g = next(iter(model._graphs.values()))
+    assert g.mesh_partition(data.batch) is not None
+    shuffled = data.batch.clone(); shuffled[0], shuffled[-1] = 1, 0
+    assert g.mesh_partition(shuffled) is None

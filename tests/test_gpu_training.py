@@ -48,17 +48,21 @@ def test_training_steps_track_the_oracle(gpu_device):
 
 
 @pytest.mark.gpu
-def test_rollout_reuses_the_graph_and_hipgraph_replay_equals_eager(gpu_device):
+@pytest.mark.parametrize("hidden,direct", [(8, True), (64, False)], ids=['C8-one-launch-direct', 'C64-hipgraph'])
+def test_rollout_reuses_the_graph_and_hipgraph_replay_equals_eager(gpu_device, hidden, direct):
     """Burgers-style rollout (utils_eval_Burgers.py:282-300): same mesh, new uu_tensor every call.  The CSR is built once,
-    and the captured forward gives bit-identical coordinates."""
+    and the captured forward gives bit-identical coordinates.  At the reference's own size (21 nodes, hidden 8) the forward is the
+    one-launch small-mesh kernel and `GraphedForward` launches it directly on the caller's tensors (no capture, no copies); at
+    hidden 64 it replays the captured per-layer launches."""
     from g_adaptivity_amd.inference import GraphedForward
-    opt = hot_path_opt(mesh_dims=[21], hidden_dim=8, num_layers=3, device=str(gpu_device), conv_type='GRAND',
+    opt = hot_path_opt(mesh_dims=[21], hidden_dim=hidden, num_layers=3, device=str(gpu_device), conv_type='GRAND',
                        gnn_inc_feat_f=False, show_mesh_evol_plots='False')
     ds = MeshDataset([21], 1, seed=0)
     data = collate(ds.samples).to(gpu_device)
     torch.manual_seed(0)
     model = GNN(ds, opt).to(gpu_device).eval()
     runner = GraphedForward(model, data)
+    assert runner.direct is direct
     outs_e, outs_g = [], []
     with torch.no_grad():
         for k in range(6):
@@ -329,7 +333,7 @@ def test_graphed_train_step_1d_global_features_and_lr_change(gpu_device):
     for graphed in (False, True):
         m = GNN(ds, opt).to(gpu_device).train(); m.load_state_dict(copy.deepcopy(state))
         o = FlatAdam(m.parameters(), lr=opt['lr'], capturable=True)
-        step = GraphedTrainStep(m, o, max_graphs=2)
+        step = GraphedTrainStep(m, o, max_graphs=2, loss_fn=lambda out, t: F.mse_loss(out, t.reshape(out.shape)))   # 1-D: x_phys is [N]
         for epoch in range(3):
             if epoch == 2:
                 o.param_groups[0]['lr'] = 5e-3                           # what an LR scheduler does
@@ -339,7 +343,7 @@ def test_graphed_train_step_1d_global_features_and_lr_change(gpu_device):
         res.append({n: p.detach().clone() for n, p in m.named_parameters()})
         steps.append(step)
     for n in res[0]:
-        assert (res[0][n] - res[1][n]).abs().max().item() <= 1e-6, n    # (MIOpen's weight gradients use atomics: last-bit band)
+        assert (res[0][n] - res[1][n]).abs().max().item() <= 5e-6, n    # (MIOpen's weight gradients use atomics: last-bit band, through nine Adam steps at lr up to 5e-3)
     g = steps[1]
     assert len(g._captured) == 2 and g._hyper_captured[0] == 5e-3        # re-captured at the new learning rate
     keys = list(g._captured)

@@ -27,7 +27,7 @@ for line in out.splitlines():
     elif cur and ":" in t:
         k, v = t.rsplit(":", 1)
         rec[k.strip()] = v.strip()
-        if k.strip().startswith("LDS Size") and ("grand_" in cur or "wide" in cur):
+        if k.strip().startswith("LDS Size") and ("grand_" in cur or "wide" in cur or "smallmesh" in cur):
             print("%-78s VGPR %4s  AGPR %3s  scratch %5s  spill %4s  waves/SIMD %s" % (
                 cur, rec.get("VGPRs"), rec.get("AGPRs"), rec.get("ScratchSize [bytes/lane]"), rec.get("VGPRs Spill"),
                 rec.get("Occupancy [waves/SIMD]")))
