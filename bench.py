@@ -144,6 +144,8 @@ def main():
                     help='timed windows of --steps steps each; value / ms_per_step are the MEDIAN window (min and max reported beside it)')
     ap.add_argument('--no-train-loop', action='store_true',
                     help='skip the third measurement: the reference training loop on SHUFFLED, changing batches (GraphedTrainStep)')
+    ap.add_argument('--no-gat-plus', action='store_true',
+                    help="skip the extra timing of conv_type='GAT_plus' on the same mesh batch (default workload, one GPU only)")
     ap.add_argument('--no-companion', action='store_true',
                     help='skip the second timing of the other slot flow (dense when the headline is compact and vice versa)')
     args = ap.parse_args()
@@ -227,7 +229,7 @@ def main():
     # value, two launches fewer - the one-element fill and the multiplication by it); --plain-backward: the literal call
     root = None if (args.plain_backward or args.torch_loss) else unit_gradient(dev)
 
-    def build_runner(dense_slots):
+    def build_runner(dense_slots, w=w):
         """model + optimizer + step() for one slot flow; the step is a replayed hipGraph unless --no-graph / capture fails."""
         opt = hot_path_opt(mesh_dims=[w['n'], w['n']], hidden_dim=w['hidden'], num_layers=w['layers'], conv_type=w['conv'],
                            gnn_inc_feat_f=w['f'], gnn_inc_feat_uu=w['uu'], device=str(dev), loss_type='mesh_loss',
@@ -363,6 +365,20 @@ def main():
         companion = {'slots': 'compact' if args.dense_slots else 'dense', 'value': round(meshes / c_el, 1),
                      'ms_per_step': round(1e3 * c_el / args.steps, 4), 'windows': c_win,
                      'launch': 'hipgraph' if other['graph'] is not None else 'eager'}
+        del other
+        torch.cuda.synchronize()
+
+    # the same mesh batch through the other trainable conv of the operator factory (GNN.py:120-121: conv_type='GAT_plus', the fused block
+    # of csrc/gadapt_gat.inc), same step, same timing protocol, fewer windows: on the default line so the driver's record carries it
+    gat_plus = None
+    if rank == 0 and world == 1 and not args.no_gat_plus and args.workload == 'poisson2d_64x64_b32_L4_C64' and not args.dense_slots:
+        wg = WORKLOADS['poisson2d_64x64_b32_L4_C64_GAT_plus']
+        other = build_runner(False, wg)
+        keep_windows, args.windows = args.windows, min(args.windows, 3)
+        g_el, g_win = summarise(timed_windows(other['step']))
+        args.windows = keep_windows
+        gat_plus = {'workload': 'poisson2d_64x64_b32_L4_C64_GAT_plus', 'value': round(wg['batch'] * args.steps / g_el, 1), 'unit': 'meshes/s',
+                    'ms_per_step': round(1e3 * g_el / args.steps, 4), 'windows': g_win, 'launch': 'hipgraph+adam' if other['graph'] is not None else 'eager'}
         del other
         torch.cuda.synchronize()
 
@@ -594,6 +610,7 @@ def main():
                        'conv_type': w['conv'], 'parallelism': f'dp{world}',
                        'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'root_gradient': 'created per step (loss.backward())' if root is None else 'preallocated (unit_gradient)', 'slots': 'dense' if args.dense_slots else 'compact', 'slots_note': None if args.dense_slots else 'identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the [N,4] encoder output in forward and backward, layer 1 hands it the 4 gradient columns it reads, the last layer writes the [N,4] head the model returns (GNN.py:299) and takes the compact top gradient; --dense-slots runs the literal dense flow', 'launch': ('hipgraph+adam' if world == 1 else ('hipgraph+allreduce+adam' if capture_all else 'hipgraph, then allreduce+adam')) if graph is not None else 'eager'},
             'roofline': roofline, 'roofline_mfma': roofline_mfma, 'kernels': kernels, 'cpu_baseline': cpu, 'train_loop': train_loop,
+            'gat_plus': gat_plus,
         }
         if world > 1:
             line['allreduce_us_per_step'] = allreduce_us

@@ -107,6 +107,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_T_ALTERNATE
 #define GADAPT_T_ALTERNATE 1     /* target pass: every other workgroup walks its chunk backwards (see the kernel) */
 #endif
+#ifndef GADAPT_T_DIFF
+#define GADAPT_T_DIFF 1           /* target pass: softmax backward on the differences x_k - x_i (see consume() in gadapt_bwd_target.inc) */
+#endif
 #ifndef GADAPT_DA_UNROLL
 #define GADAPT_DA_UNROLL 2      // k-steps of the dA loop unrolled together
 #endif
@@ -969,7 +972,7 @@ template <int C> static void launch_small(const smallmesh::Args& p, int n_meshes
 extern "C" int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_ptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
                                     const float* x_comp, int dim, const float* f, const float* uu, const float* enc_w, int n_feat,
                                     const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
-                                    const float* layer_params, int n_layers, float* out, int out_cols, float* alpha_all, int c, void* stream) {
+                                    const float* layer_params, int n_layers, float* out, int out_cols, float* alpha_all, float* x_all, int c, void* stream) {
     if (!g || !g->rowptr_t || !g->col_t || !mesh_ptr || n_meshes <= 0 || !x_comp || !enc_w || !wq || !bq || !wk || !layer_params || !out)
         return fail(GADAPT_E_BADARG, "small_forward: null pointer");
     if (dim < 1 || dim > 4 || n_feat != dim + (f ? 1 : 0) + (uu ? 1 : 0) || n_feat > smallmesh::MAXF || n_layers <= 0 || n_layers > smallmesh::MAX_LAYERS
@@ -978,9 +981,9 @@ extern "C" int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_p
     const int64_t lds = gadapt_small_forward_lds_bytes(max_mesh_nodes, max_mesh_edges, c);
     if (lds < 0) return fail(GADAPT_E_BADARG, "small_forward: hidden in {4,8,16,32}, at most 1024 nodes per mesh (512 at hidden 32), rows + CSR slice within 160 KB of LDS");
     smallmesh::Args p{x_comp, f, uu, enc_w, dim, n_feat, wq, bq, wk, w_stride, b_stride, layer_params, g->rowptr_t, g->col_t, mesh_ptr,
-                      out, out_cols, alpha_all, n_layers, g->n_edges, max_mesh_nodes, max_mesh_edges};
+                      out, out_cols, alpha_all, n_layers, g->n_edges, max_mesh_nodes, max_mesh_edges, x_all, g->n_nodes};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    ProfScope prof(9, st, 0);
+    ProfScope prof(9, st, x_all ? 32 : 0);
     switch (c) {
         case 4: launch_small<4>(p, n_meshes, (int)lds, st); break;
         case 8: launch_small<8>(p, n_meshes, (int)lds, st); break;
@@ -988,6 +991,52 @@ extern "C" int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_p
         default: launch_small<32>(p, n_meshes, (int)lds, st); break;
     }
     return check_launch("smallmesh::fwd_kernel");
+}
+
+extern "C" int64_t gadapt_small_backward_lds_bytes(int max_mesh_nodes, int max_mesh_edges, int c) {
+    if (max_mesh_nodes <= 0 || max_mesh_edges < 0 || max_mesh_edges > 65000 || max_mesh_nodes > (c == 32 ? 512 : 1024)) return -1;
+    int64_t fl;
+    switch (c) {
+        case 4: fl = smallmesh::bwd_lds_floats<4>(max_mesh_nodes, max_mesh_edges); break;
+        case 8: fl = smallmesh::bwd_lds_floats<8>(max_mesh_nodes, max_mesh_edges); break;
+        case 16: fl = smallmesh::bwd_lds_floats<16>(max_mesh_nodes, max_mesh_edges); break;
+        case 32: fl = smallmesh::bwd_lds_floats<32>(max_mesh_nodes, max_mesh_edges); break;
+        default: return -1;
+    }
+    return 4 * fl <= 160 * 1024 ? 4 * fl : -1;
+}
+template <int C> static void launch_small_bwd(const smallmesh::BwdArgs& p, int n_meshes, int lds, hipStream_t st) {
+    auto go = [&](auto kern, int nt) { allow_lds(kern, lds); hipLaunchKernelGGL(kern, dim3(n_meshes), dim3(nt), lds, st, p); };
+    const int nt = smallmesh::threads_for(p.max_nodes);
+    if (nt == 256) go(smallmesh::bwd_kernel<C, 256>, 256);
+    else if (nt == 512) go(smallmesh::bwd_kernel<C, 512>, 512);
+    else if constexpr (C < 32) go(smallmesh::bwd_kernel<C, 1024>, 1024);
+}
+extern "C" int gadapt_small_backward(const gadapt_graph* g, const int32_t* mesh_ptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
+                                     const float* x_all, const float* alpha_all, const float* g_top, int g_cols,
+                                     const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
+                                     const float* layer_params, int n_layers, float* slab, int c, void* stream) {
+    if (!g || !g->rowptr_t || !g->col_t || !g->rowptr_s || !g->col_s || !g->perm_s || !mesh_ptr || n_meshes <= 0 || !x_all || !alpha_all || !g_top
+        || !wq || !bq || !wk || !layer_params || !slab)
+        return fail(GADAPT_E_BADARG, "small_backward: null pointer");
+    if (g_cols < 1 || g_cols > c || n_layers <= 0 || n_layers > smallmesh::MAX_LAYERS) return fail(GADAPT_E_BADARG, "small_backward: 1 <= g_cols <= hidden, at most 64 layers");
+    const int64_t lds = gadapt_small_backward_lds_bytes(max_mesh_nodes, max_mesh_edges, c);
+    if (lds < 0) return fail(GADAPT_E_BADARG, "small_backward: hidden in {4,8,16,32}, at most 1024 nodes per mesh (512 at hidden 32), three row tiles + both CSR slices within 160 KB of LDS");
+    // slab: [S][n_meshes][C*C + C] - one row set per conv, what gadapt_slab_reduce_coeffs_backward takes per conv
+    smallmesh::BwdArgs p{x_all, alpha_all, g_top, g_cols, wq, bq, wk, w_stride, b_stride, layer_params, g->rowptr_t, g->col_t, g->rowptr_s, g->col_s, g->perm_s,
+                         mesh_ptr, slab, w_stride ? (int64_t)n_meshes * (c * c + c) : 0, n_layers, g->n_edges, max_mesh_nodes, max_mesh_edges, g->n_nodes, nullptr};
+#ifdef GADAPT_STAMPS
+    p.dbg = reinterpret_cast<float*>(g_stamp_buf);
+#endif
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(10, st, 0);
+    switch (c) {
+        case 4: launch_small_bwd<4>(p, n_meshes, (int)lds, st); break;
+        case 8: launch_small_bwd<8>(p, n_meshes, (int)lds, st); break;
+        case 16: launch_small_bwd<16>(p, n_meshes, (int)lds, st); break;
+        default: launch_small_bwd<32>(p, n_meshes, (int)lds, st); break;
+    }
+    return check_launch("smallmesh::bwd_kernel");
 }
 
 #include "gadapt_sparse.inc"

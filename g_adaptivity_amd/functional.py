@@ -404,25 +404,85 @@ def small_forward_fits(graph: MeshGraph, part, c: int) -> bool:
         and lib().gadapt_small_forward_lds_bytes(part[2], part[3], c) > 0
 
 
-@torch.no_grad()
-def small_forward(graph: MeshGraph, part, x_comp, f_tensor, uu_tensor, enc_weight, wq, bq, wk, layer_params, num_layers: int,
-                  out_cols: int, want_alpha: bool = False):
-    """x_phys [N,out_cols] (and alpha [L,E] in target-CSR order, or None) of encoder + L Euler steps + head in ONE launch, one
-    workgroup per mesh (`src/GNN.py:225-299` for batches of small meshes: the reference's own sizes).  Inference only: nothing is
-    kept for a backward.  wq / bq / wk: [S,C,C] / [S,C], S = 1 (shared conv) or L; layer_params [L,2] = (dt, score scale)."""
-    _require_gpu(x_comp, 'x_comp')
+def small_backward_fits(graph: MeshGraph, part, c: int) -> bool:
+    return small_forward_fits(graph, part, c) and lib().gadapt_small_backward_lds_bytes(part[2], part[3], c) > 0
+
+
+def _small_launch(graph, part, x_comp, f_tensor, uu_tensor, enc_weight, wq, bq, wk, layer_params, num_layers, out_cols, want_alpha, keep):
     n, dim = x_comp.shape
     c, S = wq.shape[1], wq.shape[0]
     dev = x_comp.device
     mesh_ptr, n_meshes, max_nodes, max_edges = part
     out = torch.empty(n, out_cols, device=dev, dtype=torch.float32)
-    alpha = torch.empty(num_layers, max(graph.num_edges, 1), device=dev, dtype=torch.float32) if want_alpha else None
-    check(lib().gadapt_small_forward(graph.c_ref, ptr(mesh_ptr), n_meshes, max_nodes, max_edges, ptr(x_comp.contiguous()), dim,
-                                     ptr(f_tensor), ptr(uu_tensor), ptr(enc_weight.contiguous()), enc_weight.shape[1],
-                                     ptr(wq.contiguous()), ptr(bq.contiguous()), ptr(wk.contiguous()), c * c if S > 1 else 0, c if S > 1 else 0,
-                                     ptr(layer_params.contiguous()), num_layers, ptr(out), out_cols, ptr(alpha), c, current_stream(dev)),
+    alpha = torch.empty(num_layers, max(graph.num_edges, 1), device=dev, dtype=torch.float32) if (want_alpha or keep) else None
+    x_all = torch.empty(num_layers, n, c, device=dev, dtype=torch.float32) if keep else None
+    check(lib().gadapt_small_forward(graph.c_ref, ptr(mesh_ptr), n_meshes, max_nodes, max_edges, ptr(x_comp), dim,
+                                     ptr(f_tensor), ptr(uu_tensor), ptr(enc_weight), enc_weight.shape[1],
+                                     ptr(wq), ptr(bq), ptr(wk), c * c if S > 1 else 0, c if S > 1 else 0,
+                                     ptr(layer_params), num_layers, ptr(out), out_cols, ptr(alpha), ptr(x_all), c, current_stream(dev)),
           'gadapt_small_forward')
+    return out, alpha, x_all
+
+
+@torch.no_grad()
+def small_forward(graph: MeshGraph, part, x_comp, f_tensor, uu_tensor, enc_weight, wq, bq, wk, layer_params, num_layers: int,
+                  out_cols: int, want_alpha: bool = False):
+    """x_phys [N,out_cols] (and alpha [L,E] in target-CSR order, or None) of encoder + L Euler steps + head in ONE launch, one
+    workgroup per mesh (`src/GNN.py:225-299` for batches of small meshes: the reference's own sizes).  Inference: nothing is
+    kept for a backward (`small_block` is the differentiable form).  wq / bq / wk: [S,C,C] / [S,C], S = 1 (shared conv) or L;
+    layer_params [L,2] = (dt, score scale)."""
+    _require_gpu(x_comp, 'x_comp')
+    out, alpha, _ = _small_launch(graph, part, x_comp.contiguous(), f_tensor, uu_tensor, enc_weight.contiguous(), wq.contiguous(), bq.contiguous(),
+                                  wk.contiguous(), layer_params.contiguous(), num_layers, out_cols, want_alpha, False)
     return out, alpha
+
+
+class _SmallMeshBlock(torch.autograd.Function):
+    """Encoder + L Euler steps + head of a small-mesh batch as ONE launch forward and ONE launch backward (csrc/gadapt_smallmesh.inc),
+    differentiable wrt the conv parameters (the encoder is frozen, `src/GNN.py:82,89`; the node fields carry no gradient).  The
+    parameter gradients come back as slices of one flat tensor laid out like `_GrandEulerBlock`'s ([dWq | dbq | dWk | dbk]), so
+    `FlatAdam` adopts it as its bucket."""
+
+    @staticmethod
+    def forward(ctx, wq, bq, wk, bk, x_comp, f_tensor, uu_tensor, enc_weight, layer_params, graph, part, num_layers, out_cols):
+        for t, n_ in ((x_comp, 'x_comp'), (wq, 'lin_query.weight'), (bq, 'lin_query.bias'), (wk, 'lin_key.weight')):
+            _require_gpu(t, n_)
+        wq, bq, wk, lp = wq.contiguous(), bq.contiguous(), wk.contiguous(), layer_params.contiguous()
+        out, alpha, x_all = _small_launch(graph, part, x_comp.contiguous(), f_tensor, uu_tensor, enc_weight.contiguous(), wq, bq, wk, lp,
+                                          num_layers, out_cols, True, True)
+        ctx.graph, ctx.part, ctx.L, ctx.out_cols = graph, part, int(num_layers), int(out_cols)
+        ctx.save_for_backward(x_all, alpha, wq, bq, wk, lp)
+        ctx.mark_non_differentiable(alpha)
+        return out, alpha
+
+    @staticmethod
+    def backward(ctx, g_out, _g_alpha):
+        x_all, alpha, wq, bq, wk, lp = ctx.saved_tensors
+        graph, (mesh_ptr, n_meshes, max_nodes, max_edges), L = ctx.graph, ctx.part, ctx.L
+        S, c = wq.shape[0], wq.shape[1]
+        dev, st = g_out.device, current_stream(g_out.device)
+        g_top = g_out.contiguous()
+        row = c * c + c
+        slab = torch.empty(S, n_meshes, row, device=dev, dtype=torch.float32)
+        check(lib().gadapt_small_backward(graph.c_ref, ptr(mesh_ptr), n_meshes, max_nodes, max_edges, ptr(x_all), ptr(alpha), ptr(g_top),
+                                          ctx.out_cols, ptr(wq), ptr(bq), ptr(wk), c * c if S > 1 else 0, c if S > 1 else 0, ptr(lp), L,
+                                          ptr(slab), c, st), 'gadapt_small_backward')
+        flat = torch.empty(S * (2 * c * c + 2 * c), device=dev, dtype=torch.float32)
+        cuts = [0, S * c * c, S * (c * c + c), S * (2 * c * c + c), S * (2 * c * c + 2 * c)]
+        d_wq, d_wk = flat[cuts[0]:cuts[1]].view(S, c, c), flat[cuts[2]:cuts[3]].view(S, c, c)
+        d_bq, d_bk = flat[cuts[1]:cuts[2]].view(S, c), flat[cuts[3]:cuts[4]].view(S, c)
+        scratch = torch.empty(32 * row, device=dev, dtype=torch.float32)
+        for s_ in range(S):
+            check(lib().gadapt_slab_reduce_coeffs_backward(ptr(slab[s_]), n_meshes, ptr(scratch), ptr(wq[s_]), ptr(bq[s_]), ptr(wk[s_]),
+                                                           ptr(d_wq[s_]), ptr(d_bq[s_]), ptr(d_wk[s_]), ptr(d_bk[s_]), c, st, None, L, 0, None),
+                  'gadapt_slab_reduce_coeffs_backward')
+        return d_wq, d_bq, d_wk, d_bk, None, None, None, None, None, None, None, None, None
+
+
+def small_block(graph: MeshGraph, part, x_comp, f_tensor, uu_tensor, enc_weight, wq, bq, wk, bk, layer_params, num_layers: int, out_cols: int):
+    """Differentiable one-launch block for small-mesh batches: returns (x_phys [N,out_cols], alpha [L,E])."""
+    return _SmallMeshBlock.apply(wq, bq, wk, bk, x_comp, f_tensor, uu_tensor, enc_weight.detach(), layer_params.detach(), graph, part,
+                                 num_layers, out_cols)
 
 
 _loss_scratch = {}

@@ -236,37 +236,48 @@ class GNN(nn.Module):
 
     # ------------------------------------------------------------------ one-launch forward of small-mesh batches
     def _small_plan(self, data, graph, x_comp, f, uu):
-        """Everything `functional.small_forward` needs besides the node fields, or None when the batch / the model state does not
-        qualify: evaluation (autograd off), fusable conv, frozen bias-free Linear encoder on fp32 fields, hidden <= 32, meshes that
-        are contiguous node ranges and fit a workgroup (graph.mesh_partition, functional.small_forward_fits)."""
+        """Everything `functional.small_forward` / `small_block` need besides the node fields, or None when the batch / the model
+        state does not qualify: fusable conv, frozen bias-free Linear encoder on fp32 fields, hidden <= 32, meshes that are
+        contiguous node ranges and fit a workgroup (graph.mesh_partition, functional.small_forward_fits).  With autograd on
+        (training) also: fixed steps and temperature (the one-launch backward returns the conv gradients only)."""
         o = self.opt
-        if not (Fn.SMALL_MESH_FORWARD and self._fusable() and not torch.is_grad_enabled() and o['hidden_dim'] <= 32
-                and isinstance(self.enc, nn.Linear) and self.enc.bias is None and x_comp.dtype == torch.float32
-                and all(t is None or (t.dtype == torch.float32 and t.dim() == 1 and t.is_contiguous()) for t in (f, uu))
-                and o['loss_type'] in ('mesh_loss', 'modular')):
+        train = torch.is_grad_enabled()
+        if not (Fn.SMALL_MESH_FORWARD and self._fusable() and o['hidden_dim'] <= 32
+                and isinstance(self.enc, nn.Linear) and self.enc.bias is None and not self.enc.weight.requires_grad and x_comp.dtype == torch.float32
+                and all(t is None or (t.dtype == torch.float32 and t.dim() == 1 and t.is_contiguous() and not t.requires_grad) for t in (f, uu))
+                and not x_comp.requires_grad and o['loss_type'] in ('mesh_loss', 'modular')):
+            return None
+        if train and (o.get('learn_step') or o.get('softmax_temp_type') == 'learnable_a'):
             return None
         part = graph.mesh_partition(getattr(data, 'batch', None))
-        if not Fn.small_forward_fits(graph, part, o['hidden_dim']):
+        if not (Fn.small_backward_fits if train else Fn.small_forward_fits)(graph, part, o['hidden_dim']):
             return None
         dev = x_comp.device
         first = self.conv_layers[0]
+        keep = (lambda t: t) if train else (lambda t: t.detach())
         if o['share_conv']:
-            wq, bq, wk = (t.detach().unsqueeze(0) for t in (first.lin_query.weight, first.lin_query.bias, first.lin_key.weight))
+            wq, bq, wk, bk = (keep(t).unsqueeze(0) for t in (first.lin_query.weight, first.lin_query.bias, first.lin_key.weight, first.lin_key.bias))
         else:
-            wq = torch.stack([l.lin_query.weight.detach() for l in self.conv_layers])
-            bq = torch.stack([l.lin_query.bias.detach() for l in self.conv_layers])
-            wk = torch.stack([l.lin_key.weight.detach() for l in self.conv_layers])
+            wq = torch.stack([keep(l.lin_query.weight) for l in self.conv_layers])
+            bq = torch.stack([keep(l.lin_query.bias) for l in self.conv_layers])
+            wk = torch.stack([keep(l.lin_key.weight) for l in self.conv_layers])
+            bk = torch.stack([keep(l.lin_key.bias) for l in self.conv_layers])
         lp = self._layer_params(dev)
         if o.get('learn_step'):                                            # _layer_params returned the [L] scales alone
             lp = torch.stack([torch.cat([s_.detach().reshape(1) for s_ in self.steps]), lp.detach()], dim=1)
         store = o['conv_type'] == 'GRAND' or isinstance(o.get('show_mesh_evol_plots'), bool)
         ident = isinstance(self.dec, nn.Identity)
-        return {'graph': graph, 'part': part, 'wq': wq.contiguous(), 'bq': bq.contiguous(), 'wk': wk.contiguous(), 'lp': lp.detach().contiguous(),
-                'enc_w': self.enc.weight.detach().contiguous(), 'store': store, 'ident': ident, 'out_cols': self.dim if ident else o['hidden_dim']}
+        return {'graph': graph, 'part': part, 'wq': wq.contiguous(), 'bq': bq.contiguous(), 'wk': wk.contiguous(), 'bk': bk, 'lp': lp.detach().contiguous(),
+                'enc_w': self.enc.weight.detach().contiguous(), 'store': store, 'ident': ident, 'out_cols': self.dim if ident else o['hidden_dim'],
+                'train': train}
 
     def _small_run(self, plan, x_comp, f, uu):
-        x, alpha = Fn.small_forward(plan['graph'], plan['part'], x_comp, f, uu, plan['enc_w'], plan['wq'], plan['bq'], plan['wk'], plan['lp'],
-                                    self.opt['num_layers'], plan['out_cols'], want_alpha=plan['store'])
+        if plan['train']:
+            x, alpha = Fn.small_block(plan['graph'], plan['part'], x_comp, f, uu, plan['enc_w'], plan['wq'], plan['bq'], plan['wk'], plan['bk'],
+                                      plan['lp'], self.opt['num_layers'], plan['out_cols'])
+        else:
+            x, alpha = Fn.small_forward(plan['graph'], plan['part'], x_comp, f, uu, plan['enc_w'], plan['wq'], plan['bq'], plan['wk'], plan['lp'],
+                                        self.opt['num_layers'], plan['out_cols'], want_alpha=plan['store'])
         if plan['store']:                                                  # GRAND_plus.py:253-256, :381
             for l, layer in enumerate(self.conv_layers):
                 layer.stored_ei, layer._stored = plan['graph'].edge_index, (plan['graph'], alpha[l])

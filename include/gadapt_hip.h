@@ -246,7 +246,18 @@ int64_t gadapt_small_forward_lds_bytes(int max_mesh_nodes, int max_mesh_edges, i
 int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_ptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
                          const float* x_comp, int dim, const float* f, const float* uu, const float* enc_w, int n_feat,
                          const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
-                         const float* layer_params, int n_layers, float* out, int out_cols, float* alpha_all, int c, void* stream);
+                         const float* layer_params, int n_layers, float* out, int out_cols, float* alpha_all, float* x_all, int c, void* stream);
+/* x_all (nullable) [L,N,c]: when given, the input rows of every layer are kept for gadapt_small_backward (training; alpha_all must
+ * be given too).
+ * Backward of the same block in ONE launch, one workgroup per mesh (autograd of GRAND_plus.py:225-343 + GNN.py:288-291 through the
+ * L layers; the encoder is frozen, GNN.py:82,89, so nothing is owed below layer 0): g_top = dL/dx_L[:, :g_cols] (zero beyond).
+ * slab: [S][n_meshes][c*c + c] floats - per conv (S = 1 shared, L per-layer) one partial row per mesh (dA then dp0), the layout
+ * gadapt_slab_reduce_coeffs_backward(slab + s * n_meshes * (c*c + c), n_meshes, ...) sums and chains to the Linear parameters. */
+int64_t gadapt_small_backward_lds_bytes(int max_mesh_nodes, int max_mesh_edges, int c);
+int gadapt_small_backward(const gadapt_graph* g, const int32_t* mesh_ptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
+                          const float* x_all, const float* alpha_all, const float* g_top, int g_cols,
+                          const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
+                          const float* layer_params, int n_layers, float* slab, int c, void* stream);
 
 /* partials: the workspace gadapt_block_backward filled ([2][L][n_rows], n_rows = gadapt_backward_slab_rows).  d_layer_params
  * [2,L]: row 0 = d dt_l, row 1 = d score_scale_l (zeros when want_d_scale = 0) - two contiguous rows, so a caller can hand out

@@ -134,21 +134,47 @@ def _n_nodes(c):
     return n
 
 
+def _small_mesh_case(c):
+    """Cases the one-launch small-mesh kernels take in training (csrc/gadapt_smallmesh.inc; functional.small_forward_policy): run
+    once through them and once through the per-layer launches, so both are compared with the oracle directly."""
+    per_mesh = 1
+    for d in c[0]:
+        per_mesh *= d
+    ex = c[5]
+    return (c[2] <= 8 or (c[2] == 16 and per_mesh <= 256)) and ex.get('residual', True) and not ex.get('learn_step') \
+        and ex.get('softmax_temp_type') != 'learnable_a' and not (c[4] == 'GRAND' and ex.get('non_lin', 'identity') != 'identity')
+
+
 PARAMS, PARAM_IDS = [], []
 for _c, _id in zip(CASES, IDS):
-    PARAMS.append(_c + (0,)); PARAM_IDS.append(_id)
+    PARAMS.append(_c + (0, True)); PARAM_IDS.append(_id)
     if _c[2] == 64 and len(_c[0]) == 2 and _c[0][0] <= 64 and _n_nodes(_c) < PRODUCTION_WIDE_MIN_NODES:
-        PARAMS.append(_c + (PRODUCTION_WIDE_MIN_NODES,)); PARAM_IDS.append(_id + '-production-kernel-choice')
+        PARAMS.append(_c + (PRODUCTION_WIDE_MIN_NODES, True)); PARAM_IDS.append(_id + '-production-kernel-choice')
+    if _small_mesh_case(_c):
+        PARAMS.append(_c + (0, False)); PARAM_IDS.append(_id + '-per-layer-launches')
 
 
 @pytest.mark.one_dispatch
 @pytest.mark.gpu
-@pytest.mark.parametrize("mesh_dims,batch,hidden,layers,conv_type,extra,wide_min_nodes", PARAMS, ids=PARAM_IDS)
-def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra, wide_min_nodes, request):
+@pytest.mark.parametrize("mesh_dims,batch,hidden,layers,conv_type,extra,wide_min_nodes,small_mesh", PARAMS, ids=PARAM_IDS)
+def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra, wide_min_nodes, small_mesh, request):
+    import ctypes as C
+    import g_adaptivity_amd.functional as Fn
+    from g_adaptivity_amd._native import lib
     keep, _graph_mod.WIDE_MIN_NODES = _graph_mod.WIDE_MIN_NODES, wide_min_nodes
+    keep_small, Fn.SMALL_MESH_FORWARD = Fn.SMALL_MESH_FORWARD, small_mesh
     rows = []
     try:
-        oracle, o64, model, ref, ref64, out = _run(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra)
+        lib().gadapt_profile_reset(); lib().gadapt_profile_enable(1)
+        try:
+            oracle, o64, model, ref, ref64, out = _run(gpu_device, mesh_dims, batch, hidden, layers, conv_type, extra)
+            tot, cnt = C.c_double(0.0), C.c_int(0)
+            lib().gadapt_profile_read(10, C.byref(tot), C.byref(cnt))      # kernel id 10: the one-launch small-mesh backward
+            took_small = cnt.value > 0
+        finally:
+            lib().gadapt_profile_enable(0); lib().gadapt_profile_reset()
+        assert took_small == (small_mesh and _small_mesh_case((mesh_dims, batch, hidden, layers, conv_type, extra))), \
+            "which kernels ran is not what the case's id says"
         g = next(iter(model._graphs.values()))
         if wide_min_nodes:                                  # production choice below the limit: the tiled forward must have run
             assert g.wide_deg['t'] == 0
@@ -176,6 +202,7 @@ def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, c
                     assert torch.equal(p_.grad, first[n_]), f"{n_}.grad differs between two identical runs"
     finally:
         _graph_mod.WIDE_MIN_NODES = keep
+        Fn.SMALL_MESH_FORWARD = keep_small
     band = {}                                               # the oracle's edge-order band, computed at most once and only if needed
     norm, elem = rel_err(out, ref)
     if extra.get('residual', True):

@@ -73,8 +73,9 @@ def test_small_mesh_forward_parity(gpu_device, mesh_dims, batch, hidden, layers,
 @pytest.mark.one_dispatch
 @pytest.mark.gpu
 def test_small_mesh_dispatch_limits(gpu_device):
-    """Training (autograd on) and meshes too large for a workgroup's LDS keep the per-layer launches; a batch whose `batch` vector is
-    not what collation produces (meshes interleaved) is refused by the partition check, not mis-computed."""
+    """Training (autograd on) runs the one-launch forward + one-launch backward pair; learnable steps and meshes too large for a
+    workgroup's LDS keep the per-layer launches; a batch whose `batch` vector is not what collation produces (meshes interleaved) is
+    refused by the partition check, not mis-computed."""
     import g_adaptivity_amd.functional as Fn
     from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt
     from g_adaptivity_amd._native import lib
@@ -85,9 +86,14 @@ def test_small_mesh_dispatch_limits(gpu_device):
     lib().gadapt_profile_reset(); lib().gadapt_profile_enable(1)
     try:
         model.train()
-        model(data).sum().backward()                              # autograd on: the block op (activations kept)
+        model(data).sum().backward()                              # autograd on: forward keeps the layer inputs, one launch each way
         torch.cuda.synchronize()
-        assert _launches(9) == 0 and _launches(0) == 2
+        assert _launches(9) == 1 and _launches(10) == 1 and _launches(0) == 0 and _launches(1) == 0
+        lib().gadapt_profile_reset()
+        ls = GNN(ds, hot_path_opt(mesh_dims=[11, 11], hidden_dim=8, num_layers=2, device=str(gpu_device), learn_step=True)).to(gpu_device).train()
+        ls(data).sum().backward()                                 # learnable steps: d dt comes from the per-layer kernels
+        torch.cuda.synchronize()
+        assert _launches(9) == 0 and _launches(10) == 0 and _launches(0) == 2
         lib().gadapt_profile_reset()
         big = hot_path_opt(mesh_dims=[64, 64], hidden_dim=8, num_layers=2, device=str(gpu_device))
         dsb = MeshDataset([64, 64], 1, seed=0)
