@@ -404,8 +404,17 @@ def small_forward_fits(graph: MeshGraph, part, c: int) -> bool:
         and lib().gadapt_small_forward_lds_bytes(part[2], part[3], c) > 0
 
 
+def small_training_policy(c: int, max_nodes: int) -> bool:
+    """Training: the one-launch pair wins where a step is bound by the host's launch path - eager loops on the reference's own sizes
+    (11 x 11 meshes / 1-D, hidden 8: +20..45 % meshes/s).  Inside a hipGraph capture launches cost nothing and the per-layer kernels,
+    which spread a batch over all CUs instead of one workgroup per mesh, replay faster (tools/gpu_small_train.sh: 23 x 23 meshes
+    176k against 70k meshes/s) - the caller checks for a capture; larger meshes and wider rows keep the per-layer kernels."""
+    return c <= 8 and max_nodes <= 128
+
+
 def small_backward_fits(graph: MeshGraph, part, c: int) -> bool:
-    return small_forward_fits(graph, part, c) and lib().gadapt_small_backward_lds_bytes(part[2], part[3], c) > 0
+    return part is not None and c in (4, 8, 16, 32) and small_training_policy(c, part[2]) \
+        and lib().gadapt_small_forward_lds_bytes(part[2], part[3], c) > 0 and lib().gadapt_small_backward_lds_bytes(part[2], part[3], c) > 0
 
 
 def _small_launch(graph, part, x_comp, f_tensor, uu_tensor, enc_weight, wq, bq, wk, layer_params, num_layers, out_cols, want_alpha, keep):

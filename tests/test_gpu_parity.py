@@ -55,6 +55,7 @@ CASES = [
     ((11, 11), 3, 4, 2, 'GRAND_plus', {}),
     ((15, 15), 2, 16, 3, 'GRAND_plus', {}),
     ((12, 12), 3, 32, 2, 'GRAND_plus', {}),
+    ((23, 23), 2, 8, 3, 'GRAND_plus', {}),    # the largest shipped mesh at the shipped width (params.py:64): per-layer kernels, and the one-launch pair forced
     ((32, 32), 2, 64, 4, 'GRAND_plus', {}),   # BASELINE config 2 shape (small batch)
     ((20, 20), 2, 128, 2, 'GRAND', {}),       # config 4 shape (hidden 128)
     ((13, 13), 5, 64, 3, 'GRAND_plus', {'share_conv': False}),
@@ -141,7 +142,7 @@ def _small_mesh_case(c):
     for d in c[0]:
         per_mesh *= d
     ex = c[5]
-    return (c[2] <= 8 or (c[2] == 16 and per_mesh <= 256)) and ex.get('residual', True) and not ex.get('learn_step') \
+    return c[2] <= 8 and per_mesh <= 128 and ex.get('residual', True) and not ex.get('learn_step') \
         and ex.get('softmax_temp_type') != 'learnable_a' and not (c[4] == 'GRAND' and ex.get('non_lin', 'identity') != 'identity')
 
 
@@ -152,6 +153,9 @@ for _c, _id in zip(CASES, IDS):
         PARAMS.append(_c + (PRODUCTION_WIDE_MIN_NODES, True)); PARAM_IDS.append(_id + '-production-kernel-choice')
     if _small_mesh_case(_c):
         PARAMS.append(_c + (0, False)); PARAM_IDS.append(_id + '-per-layer-launches')
+    elif _c[2] <= 16 and _n_nodes(_c) // _c[1] <= 1024 and _c[5].get('residual', True) and not _c[5].get('learn_step') \
+            and _c[5].get('softmax_temp_type') != 'learnable_a' and not (_c[4] == 'GRAND' and _c[5].get('non_lin', 'identity') != 'identity'):
+        PARAMS.append(_c + (0, None)); PARAM_IDS.append(_id + '-one-launch-forced')          # sizes the kernels take but the policy skips
 
 
 @pytest.mark.one_dispatch
@@ -163,6 +167,9 @@ def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, c
     from g_adaptivity_amd._native import lib
     keep, _graph_mod.WIDE_MIN_NODES = _graph_mod.WIDE_MIN_NODES, wide_min_nodes
     keep_small, Fn.SMALL_MESH_FORWARD = Fn.SMALL_MESH_FORWARD, small_mesh
+    keep_pol = Fn.small_training_policy
+    if small_mesh is None:                                  # larger small meshes: force the one-launch pair past its speed policy
+        Fn.SMALL_MESH_FORWARD, Fn.small_training_policy = True, (lambda c, max_nodes: c <= 16)
     rows = []
     try:
         lib().gadapt_profile_reset(); lib().gadapt_profile_enable(1)
@@ -173,7 +180,7 @@ def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, c
             took_small = cnt.value > 0
         finally:
             lib().gadapt_profile_enable(0); lib().gadapt_profile_reset()
-        assert took_small == (small_mesh and _small_mesh_case((mesh_dims, batch, hidden, layers, conv_type, extra))), \
+        assert took_small == bool(small_mesh is None or (small_mesh and _small_mesh_case((mesh_dims, batch, hidden, layers, conv_type, extra)))), \
             "which kernels ran is not what the case's id says"
         g = next(iter(model._graphs.values()))
         if wide_min_nodes:                                  # production choice below the limit: the tiled forward must have run
@@ -203,6 +210,7 @@ def test_forward_backward_parity(gpu_device, mesh_dims, batch, hidden, layers, c
     finally:
         _graph_mod.WIDE_MIN_NODES = keep
         Fn.SMALL_MESH_FORWARD = keep_small
+        Fn.small_training_policy = keep_pol
     band = {}                                               # the oracle's edge-order band, computed at most once and only if needed
     norm, elem = rel_err(out, ref)
     if extra.get('residual', True):
