@@ -242,6 +242,8 @@ class GNN(nn.Module):
         (training) also: fixed steps and temperature (the one-launch backward returns the conv gradients only)."""
         o = self.opt
         train = torch.is_grad_enabled()
+        if not x_comp.is_cuda:                                             # (the per-layer path raises the no-CPU-fallback error)
+            return None
         if not (Fn.SMALL_MESH_FORWARD and self._fusable() and o['hidden_dim'] <= 32
                 and isinstance(self.enc, nn.Linear) and self.enc.bias is None and not self.enc.weight.requires_grad and x_comp.dtype == torch.float32
                 and all(t is None or (t.dtype == torch.float32 and t.dim() == 1 and t.is_contiguous() and not t.requires_grad) for t in (f, uu))
