@@ -405,11 +405,11 @@ def small_forward_fits(graph: MeshGraph, part, c: int) -> bool:
 
 
 def small_training_policy(c: int, max_nodes: int) -> bool:
-    """Training: the one-launch pair wins where a step is bound by the host's launch path - eager loops on the reference's own sizes
-    (11 x 11 meshes / 1-D, hidden 8: +20..45 % meshes/s).  Inside a hipGraph capture launches cost nothing and the per-layer kernels,
-    which spread a batch over all CUs instead of one workgroup per mesh, replay faster (tools/gpu_small_train.sh: 23 x 23 meshes
-    176k against 70k meshes/s) - the caller checks for a capture; larger meshes and wider rows keep the per-layer kernels."""
-    return c <= 8 and max_nodes <= 128
+    """Training sizes at which the one-launch forward + one-launch backward pair is the faster step (tools/gpu_small_train.sh, captured
+    step, meshes/s against the per-layer kernels: 11 x 11, batch 8: 128k / 95k; batch 64: 957k / 715k; 23 x 23, batch 16: 195k / 177k).
+    Hidden 16 keeps the per-layer kernels: its weight-gradient contraction has more elements (272) than a 256-thread workgroup has
+    threads and runs one serial chain per element."""
+    return c <= 8
 
 
 def small_backward_fits(graph: MeshGraph, part, c: int) -> bool:

@@ -249,8 +249,8 @@ class GNN(nn.Module):
                 and all(t is None or (t.dtype == torch.float32 and t.dim() == 1 and t.is_contiguous() and not t.requires_grad) for t in (f, uu))
                 and not x_comp.requires_grad and o['loss_type'] in ('mesh_loss', 'modular')):
             return None
-        if train and (o.get('learn_step') or o.get('softmax_temp_type') == 'learnable_a' or torch.cuda.is_current_stream_capturing()):
-            return None                                                    # (a captured step replays the per-layer kernels: see small_training_policy)
+        if train and (o.get('learn_step') or o.get('softmax_temp_type') == 'learnable_a'):
+            return None
         part = graph.mesh_partition(getattr(data, 'batch', None))
         if not (Fn.small_backward_fits if train else Fn.small_forward_fits)(graph, part, o['hidden_dim']):
             return None

@@ -108,3 +108,51 @@ def test_small_mesh_dispatch_limits(gpu_device):
     assert g.mesh_partition(data.batch) is not None
     shuffled = data.batch.clone(); shuffled[0], shuffled[-1] = 1, 0
     assert g.mesh_partition(shuffled) is None
+
+
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
+def test_small_mesh_training_step_graphed_equals_eager_and_tracks_the_oracle(gpu_device):
+    """The reference's training loop at its own size (11 x 11 meshes, hidden 8, four layers; run_GNN.py:99-131) on the one-launch pair:
+    the captured step (`GraphedTrainStep`) is bit-identical to the eager loop, the forward + backward are two launches, and three
+    epochs of Adam stay on the CPU oracle's trajectory."""
+    import copy
+    import torch.nn.functional as F
+    from g_adaptivity_amd import DeviceMeshLoader, GNN, GraphedTrainStep, MeshDataset, hot_path_opt
+    from g_adaptivity_amd.optim import FlatAdam
+    from g_adaptivity_amd._native import lib
+    from oracle.pyg_restatement import OracleGNN
+    from g_adaptivity_amd import collate
+    opt = hot_path_opt(mesh_dims=[11, 11], hidden_dim=8, num_layers=4, lr=1e-3, decay=0.0, device=str(gpu_device))
+    ds = MeshDataset([11, 11], 10, seed=2)                                  # batches of 4, 4, 2
+    torch.manual_seed(0)
+    base = GNN(ds, opt).to(gpu_device).train()
+    state = copy.deepcopy(base.state_dict())
+    res = []
+    for graphed in (False, True):
+        m = GNN(ds, opt).to(gpu_device).train(); m.load_state_dict(copy.deepcopy(state))
+        o = FlatAdam(m.parameters(), lr=opt['lr'], capturable=True)
+        step = GraphedTrainStep(m, o)
+        lib().gadapt_profile_reset(); lib().gadapt_profile_enable(1)
+        for epoch in range(3):
+            for d in DeviceMeshLoader(ds, batch_size=4, shuffle=False, device=gpu_device):
+                (step if graphed else step.eager)(d)
+        torch.cuda.synchronize()
+        lib().gadapt_profile_enable(0)
+        if not graphed:
+            assert _launches(9) == 9 and _launches(10) == 9 and _launches(0) == 0 and _launches(1) == 0
+        lib().gadapt_profile_reset()
+        res.append({n: p.detach().clone() for n, p in m.named_parameters()})
+    for n in res[0]:
+        assert torch.equal(res[0][n], res[1][n]), n
+    oopt = dict(opt); oopt['device'] = 'cpu'
+    oracle = OracleGNN(ds, oopt).train()
+    oracle.load_state_dict({k: v.cpu() for k, v in state.items()})
+    oo = torch.optim.Adam([p for p in oracle.parameters() if p.requires_grad], lr=opt['lr'])
+    for epoch in range(3):
+        for s in range(0, 10, 4):
+            d = collate(ds.samples[s:s + 4])
+            oo.zero_grad(); F.mse_loss(oracle(d), d.x_phys).backward(); oo.step()
+    for n, p in oracle.named_parameters():
+        if p.requires_grad and not n.endswith('lin_skip.weight'):
+            assert (res[1][n].cpu() - p.detach()).abs().max().item() <= 2e-5, n

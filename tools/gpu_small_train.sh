@@ -1,12 +1,14 @@
 mkdir -p gpurun_out
 {
-for cfg in "--mesh 11 --hidden 8 --num_train 512 --batch_size 8" "--mesh 11 --hidden 8 --num_train 2048 --batch_size 64" "--mesh 23 --hidden 8 --num_train 512 --batch_size 16" "--mesh 15 --hidden 16 --num_train 512 --batch_size 16"; do
-  for sm in 1 0; do
-    echo "== $cfg GADAPT_SMALL_MESH=$sm"
-    GADAPT_SMALL_MESH=$sm timeout -k 10 120 python examples/train_mesh_loss.py $cfg --epochs 4 2>&1 | grep -v amdgpu.ids | tail -3
-    echo "== $cfg GADAPT_SMALL_MESH=$sm --eager"
-    GADAPT_SMALL_MESH=$sm timeout -k 10 120 python examples/train_mesh_loss.py $cfg --epochs 3 --eager 2>&1 | grep -v amdgpu.ids | tail -1
-  done
+for cfg in "--mesh 11 --hidden 8 --num_train 512 --batch_size 8" "--mesh 11 --hidden 8 --num_train 2048 --batch_size 64" "--mesh 23 --hidden 8 --num_train 512 --batch_size 16"; do
+  echo "== $cfg : captured step, per-layer kernels"
+  GADAPT_SMALL_MESH=0 timeout -k 10 120 python examples/train_mesh_loss.py $cfg --epochs 4 2>&1 | grep -v amdgpu.ids | tail -1
+  echo "== $cfg : captured step, one-launch pair"
+  timeout -k 10 120 python examples/train_mesh_loss.py $cfg --epochs 4 2>&1 | grep -v amdgpu.ids | tail -1
+  echo "== $cfg : eager loop, per-layer kernels"
+  GADAPT_SMALL_MESH=0 timeout -k 10 120 python examples/train_mesh_loss.py $cfg --epochs 3 --eager 2>&1 | grep -v amdgpu.ids | tail -1
+  echo "== $cfg : eager loop, one-launch pair"
+  timeout -k 10 120 python examples/train_mesh_loss.py $cfg --epochs 3 --eager 2>&1 | grep -v amdgpu.ids | tail -1
 done
 } > gpurun_out/train_small.log 2>&1
-cat gpurun_out/train_small.log
+grep -E "^==|meshes/s" gpurun_out/train_small.log | sed -e 's/; losses.*//'
