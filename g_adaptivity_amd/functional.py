@@ -406,7 +406,7 @@ def small_forward_fits(graph: MeshGraph, part, c: int) -> bool:
 
 def small_training_policy(c: int, max_nodes: int) -> bool:
     """Training sizes at which the one-launch forward + one-launch backward pair is the faster step (tools/gpu_small_train.sh, captured
-    step, meshes/s against the per-layer kernels: 11 x 11, batch 8: 128k / 95k; batch 64: 957k / 715k; 23 x 23, batch 16: 195k / 177k).
+    step, meshes/s against the per-layer kernels: 11 x 11, batch 8: 134k / 93k; batch 64: 1015k / 713k; 23 x 23, batch 16: 202k / 178k).
     Hidden 16 keeps the per-layer kernels: its weight-gradient contraction has more elements (272) than a 256-thread workgroup has
     threads and runs one serial chain per element."""
     return c <= 8
