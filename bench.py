@@ -39,6 +39,11 @@ WORKLOADS = {
     # not a BASELINE.json shape: the other hidden sizes of the fused kernels on the metric mesh batch (tuning runs)
     'poisson2d_64x64_b32_L4_C32': dict(n=64, batch=32, layers=4, hidden=32, conv='GRAND_plus', f=True, uu=True),
     'poisson2d_64x64_b32_L4_C8': dict(n=64, batch=32, layers=4, hidden=8, conv='GRAND_plus', f=True, uu=True),
+    # the two halves of what separates config 5 from the metric workload (docs/measurements.md G): twice the nodes at the metric's
+    # 64-node mesh rows, and the metric's node count at config 5's 128-node mesh rows
+    'poisson2d_64x64_b64_L4_C64': dict(n=64, batch=64, layers=4, hidden=64, conv='GRAND_plus', f=True, uu=True),
+    'poisson2d_128x128_b8_L4_C64': dict(n=128, batch=8, layers=4, hidden=64, conv='GRAND_plus', f=True, uu=True),
+    'poisson2d_128x128_b16_L4_C64': dict(n=128, batch=16, layers=4, hidden=64, conv='GRAND_plus', f=True, uu=True),
     # the metric mesh batch through the other trainable paths of the operator surface:
     # learn_step=True (GNN.py:179-180,288-289: the SUMS instantiations of the target pass + the d dt reduction) and
     # conv_type='GAT_plus' (GRAND_plus.py:386-416: the generic CSR primitives of gadapt_sparse.inc)

@@ -84,6 +84,7 @@ PROTOTYPES = {
     'gadapt_profile_reset': (_I, []),
     'gadapt_profile_calibrate': (_I, [_I, _P]),
     'gadapt_debug_set_wide_backward': (_I, [_I]),
+    'gadapt_debug_set_backward_inplace': (_I, [_I]),
     'gadapt_debug_occupancy': (_I, [_I, C.POINTER(C.c_int)]),
 }
 

@@ -401,6 +401,19 @@ extern "C" int64_t gadapt_wide_backward_ws_floats(int64_t n_nodes) {
     if (n_nodes <= 0) return fail(GADAPT_E_BADARG, "wide_backward_ws_floats: bad node count");
     return ((n_nodes + 255) / 256 * 256) * 8 * 2 * 2;            // adt + ads: [round_up(N,256)][8] float2 each
 }
+// Block backward: the source pass writes g_out over the dxd rows it has just read (same row, same lanes: read-then-write), so a
+// layer pair touches two [N,C] buffers instead of three.  GADAPT_BWD_INPLACE=0 / gadapt_debug_set_backward_inplace(0): separate buffers.
+static std::atomic<int> g_bwd_inplace{-1};
+static bool bwd_inplace_enabled() {
+    int v = g_bwd_inplace.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("GADAPT_BWD_INPLACE");
+        v = (e && e[0] == '0') ? 0 : 1;
+        g_bwd_inplace.store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+extern "C" int gadapt_debug_set_backward_inplace(int on) { g_bwd_inplace.store(on ? 1 : 0, std::memory_order_relaxed); return GADAPT_OK; }
 static bool wide_bwd_graph_ok(const gadapt_graph* g) {
     return g->ell_t && g->ell_s && g->xpos_t && g->xpos_s && g->wide_deg_t > 0 && g->wide_deg_s > 0 && g->rowptr_s && g->col_s && g->perm_s;
 }
@@ -929,8 +942,10 @@ extern "C" int gadapt_block_backward_ws(const gadapt_graph* g, const float* x_al
         const bool pair4 = GADAPT_BWD_OUT4 && x0_cols && c >= 8 && n_layers >= 2 && !(n_layers == 2 && g_top_cols > 0 && d_layer_params);
         const int out4 = (pair4 && l == 1) ? 1 : 0;
         const int g_stride = (pair4 && l == 0) ? 4 : 0;
+        // dense layers that hand their result to the next layer of the block: dxd lives in the g_out buffer (see bwd_inplace_enabled)
+        const bool inplace = bwd_inplace_enabled() && l > 0 && g_next && !out4 && !(wide_ws && wide_bwd_enabled());
         int rc = layer_backward_cols(g, x_all + l * nc, g_cur, alpha_all + (size_t)l * g->n_edges, a + l * a_stride, p0 + l * p0_stride,
-                                     layer_params + 2 * l, edge_ws, dxd_ws, slab_l, accumulate, d_dt, d_sc, g_next, g_cols, x_cols, c, st,
+                                     layer_params + 2 * l, edge_ws, inplace ? g_next : dxd_ws, slab_l, accumulate, d_dt, d_sc, g_next, g_cols, x_cols, c, st,
                                      out4, g_stride, wide_ws);
         if (rc) return rc;
         g_cur = g_next;

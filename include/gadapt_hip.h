@@ -387,6 +387,11 @@ int gadapt_profile_calibrate(int n, void* stream);
  * 0 (the default: the two measure level on the metric workload, docs/measurements.md F) keeps the tiled target / source pair
  * everywhere.  GADAPT_WIDE_BWD=1 in the environment sets the initial value.  tests compare the two on the same inputs. */
 int gadapt_debug_set_wide_backward(int on);
+/* Switch: 1 (the default; GADAPT_BWD_INPLACE=0 in the environment starts with 0) lets gadapt_block_backward_ws keep a dense
+ * layer's dxd rows in the buffer its source pass then writes g_out to - every lane group reads its dxd row before it stores the
+ * same row of g_out - so a layer pair touches two [N,C] work buffers instead of three (dxd_ws then only serves layer 0 and the
+ * 4-column pair).  Results are bit-identical either way (tests/test_gpu_ops.py::test_block_backward_inplace_is_bit_identical). */
+int gadapt_debug_set_backward_inplace(int on);
 /* Diagnostic: runtime-reported workgroups per CU of {forward, backward target, backward source}. */
 int gadapt_debug_occupancy(int c, int* out3);
 

@@ -739,3 +739,34 @@ def test_wide_backward_matches_two_pass(gpu_device, mesh_n, batch, layers, monke
             Fn.set_wide_backward(False)
     for a, b in zip(outs[0], outs[1]):
         assert rel_err(b, a)[0] <= 2e-5, rel_err(b, a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,mesh_n,batch,layers,learn", [(64, 64, 3, 4, False), (64, 33, 5, 3, True), (32, 20, 4, 3, False), (128, 16, 2, 3, False), (8, 15, 3, 4, False)],
+                         ids=['C64-64x64', 'C64-33x33-learn-step', 'C32', 'C128', 'C8'])
+def test_block_backward_inplace_is_bit_identical(gpu_device, hidden, mesh_n, batch, layers, learn, monkeypatch):
+    """gadapt_block_backward_ws with the source pass writing g_out over the dxd rows it has read (the default) against separate
+    buffers: the same launches on the same values, so every gradient is bit-identical."""
+    import g_adaptivity_amd.functional as Fn_mod
+    from g_adaptivity_amd._native import lib
+    monkeypatch.setattr(Fn_mod, 'SMALL_MESH_FORWARD', False)
+    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=hidden, num_layers=layers, device=str(gpu_device), show_mesh_evol_plots='False')
+    if learn:
+        opt['learn_step'] = True
+    ds = MeshDataset([mesh_n, mesh_n], batch, seed=4)
+    data = collate(ds.samples).to(gpu_device)
+    torch.manual_seed(6)
+    model = GNN(ds, opt).to(gpu_device).train()
+    res = {}
+    for on in (0, 1):
+        lib().gadapt_debug_set_backward_inplace(on)
+        try:
+            model.zero_grad()
+            F.mse_loss(model(data), data.x_phys).backward()
+            torch.cuda.synchronize()
+            res[on] = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+        finally:
+            lib().gadapt_debug_set_backward_inplace(1)
+    assert len(res[0]) >= 4
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
