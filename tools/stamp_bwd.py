@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from g_adaptivity_amd import _native, MeshDataset, collate, hot_path_opt, GNN
 handle = C.CDLL(_native.LIB_PATH)
 dev = torch.device('cuda:0')
-n, B, Cc, L = 64, 32, int(os.environ.get("STAMP_C", "64")), 4
+n, B, Cc, L = int(os.environ.get("STAMP_N", "64")), int(os.environ.get("STAMP_B", "32")), int(os.environ.get("STAMP_C", "64")), 4
 opt = hot_path_opt(mesh_dims=[n, n], hidden_dim=Cc, num_layers=L, device='cuda:0', show_mesh_evol_plots='False')
 ds = MeshDataset([n, n], B, seed=0); data = collate(ds.samples).to(dev)
 model = GNN(ds, opt).to(dev).train()
@@ -41,3 +41,12 @@ for name, s, names in (('backward_target (last launch = layer 0)', allb[1], ['st
             if ok2.any():
                 line += f"  | gap to next tile {np.median(nxt[ok2] - seg[ok2, nst - 1]):.0f}"
         print(line)
+    if 'target' in name:
+        ent, pro, end = s[:, 30], s[:, 29], s[:, 31]
+        ok = (ent > 0) & (end > 0)
+        first = s[:, 0]
+        ntile = int(os.environ.get("STAMP_TILES", "4"))
+        last = s[:, (ntile - 1) * 8 + 7]
+        print(f"  workgroup: entry -> prologue done {np.median(pro[ok] - ent[ok]):.0f}  -> first tile start {np.median(first[ok] - pro[ok]):.0f}  "
+              f"last stamped tile end -> slab row flushed {np.median(end[ok] - last[ok]):.0f}  | entry -> end {np.median(end[ok] - ent[ok]):.0f}")
+        print(f"  launch: first entry -> last end {end[ok].max() - ent[ok].min():.0f} cycles; entry spread (max - min) {ent[ok].max() - ent[ok].min():.0f}; end spread {end[ok].max() - end[ok].min():.0f}")
