@@ -64,9 +64,9 @@ PROTOTYPES = {
     'gadapt_block_backward_ws': (_I, [_G, _P, _I, _P, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     'gadapt_wide_backward_ws_floats': (_L, [_L]),
     'gadapt_small_forward_lds_bytes': (_L, [_I, _I, _I]),
-    'gadapt_small_forward': (_I, [_G, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _L, _L, _P, _I, _P, _I, _P, _P, _I, _P]),
+    'gadapt_small_forward': (_I, [_G, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _L, _L, _P, _I, _P, _I, _P, _P, _I, _P]),
     'gadapt_small_backward_lds_bytes': (_L, [_I, _I, _I]),
-    'gadapt_small_backward': (_I, [_G, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _L, _L, _P, _I, _P, _I, _P]),
+    'gadapt_small_backward': (_I, [_G, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _L, _L, _P, _I, _P, _I, _P]),
     'gadapt_layer_params_reduce': (_I, [_P, _I, _I, _I, _P, _P]),
     'gadapt_mesh_loss_seed': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
     'gadapt_pad_columns': (_I, [_P, _P, _L, _I, _I, _P]),

@@ -979,12 +979,27 @@ extern "C" int64_t gadapt_small_forward_lds_bytes(int max_mesh_nodes, int max_me
 }
 template <int C> static void launch_small(const smallmesh::Args& p, int n_meshes, int lds, hipStream_t st) {
     auto go = [&](auto kern, int nt) { allow_lds(kern, lds); hipLaunchKernelGGL(kern, dim3(n_meshes), dim3(nt), lds, st, p); };
-    const int nt = smallmesh::threads_for(p.max_nodes);
-    if (nt == 256) go(smallmesh::fwd_kernel<C, 256>, 256);
-    else if (nt == 512) go(smallmesh::fwd_kernel<C, 512>, 512);
-    else if constexpr (C < 32) go(smallmesh::fwd_kernel<C, 1024>, 1024);
+    // lanes per node: as many as the workgroup has threads for (hidden 32: 512 threads at most - a row is 32 registers)
+    const int nodes = p.max_nodes;
+    if constexpr (C == 16) {                                    // 128 registers at 1024 threads would spill: 512 threads from 129 nodes on
+        if (nodes <= 64) go(smallmesh::fwd_kernel<C, 256, 4>, 256);
+        else if (nodes <= 128) go(smallmesh::fwd_kernel<C, 512, 4>, 512);
+        else if (nodes <= 256) go(smallmesh::fwd_kernel<C, 512, 2>, 512);
+        else if (nodes <= 512) go(smallmesh::fwd_kernel<C, 512, 1>, 512);
+        else go(smallmesh::fwd_kernel<C, 1024, 1>, 1024);
+    } else if constexpr (C < 32) {
+        if (nodes <= 64) go(smallmesh::fwd_kernel<C, 256, 4>, 256);
+        else if (nodes <= 128) go(smallmesh::fwd_kernel<C, 512, 4>, 512);
+        else if (nodes <= 256) go(smallmesh::fwd_kernel<C, 1024, 4>, 1024);
+        else if (nodes <= 512) go(smallmesh::fwd_kernel<C, 1024, 2>, 1024);
+        else go(smallmesh::fwd_kernel<C, 1024, 1>, 1024);
+    } else {
+        if (nodes <= 128) go(smallmesh::fwd_kernel<C, 256, 2>, 256);
+        else if (nodes <= 256) go(smallmesh::fwd_kernel<C, 512, 2>, 512);
+        else go(smallmesh::fwd_kernel<C, 512, 1>, 512);
+    }
 }
-extern "C" int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_ptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
+extern "C" int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_ptr, const int32_t* mesh_eptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
                                     const float* x_comp, int dim, const float* f, const float* uu, const float* enc_w, int n_feat,
                                     const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
                                     const float* layer_params, int n_layers, float* out, int out_cols, float* alpha_all, float* x_all, int c, void* stream) {
@@ -995,7 +1010,7 @@ extern "C" int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_p
         return fail(GADAPT_E_BADARG, "small_forward: 1..4 coordinates, encoder columns = coordinates + extras, at most 64 layers, 1 <= out_cols <= hidden");
     const int64_t lds = gadapt_small_forward_lds_bytes(max_mesh_nodes, max_mesh_edges, c);
     if (lds < 0) return fail(GADAPT_E_BADARG, "small_forward: hidden in {4,8,16,32}, at most 1024 nodes per mesh (512 at hidden 32), rows + CSR slice within 160 KB of LDS");
-    smallmesh::Args p{x_comp, f, uu, enc_w, dim, n_feat, wq, bq, wk, w_stride, b_stride, layer_params, g->rowptr_t, g->col_t, mesh_ptr,
+    smallmesh::Args p{x_comp, f, uu, enc_w, dim, n_feat, wq, bq, wk, w_stride, b_stride, layer_params, g->rowptr_t, g->col_t, mesh_ptr, mesh_eptr, n_meshes,
                       out, out_cols, alpha_all, n_layers, g->n_edges, max_mesh_nodes, max_mesh_edges, x_all, g->n_nodes};
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope prof(9, st, x_all ? 32 : 0);
@@ -1022,12 +1037,20 @@ extern "C" int64_t gadapt_small_backward_lds_bytes(int max_mesh_nodes, int max_m
 }
 template <int C> static void launch_small_bwd(const smallmesh::BwdArgs& p, int n_meshes, int lds, hipStream_t st) {
     auto go = [&](auto kern, int nt) { allow_lds(kern, lds); hipLaunchKernelGGL(kern, dim3(n_meshes), dim3(nt), lds, st, p); };
-    const int nt = smallmesh::threads_for(p.max_nodes);
-    if (nt == 256) go(smallmesh::bwd_kernel<C, 256>, 256);
-    else if (nt == 512) go(smallmesh::bwd_kernel<C, 512>, 512);
-    else if constexpr (C < 32) go(smallmesh::bwd_kernel<C, 1024>, 1024);
+    // lanes per node as in launch_small, within 512 threads (1024-thread workgroups have no registers for the layer-ahead requests)
+    const int nodes = p.max_nodes;
+    if constexpr (C < 32) {
+        if (nodes <= 64) go(smallmesh::bwd_kernel<C, 256, 4>, 256);
+        else if (nodes <= 128) go(smallmesh::bwd_kernel<C, 512, 4>, 512);
+        else if (nodes <= 256) go(smallmesh::bwd_kernel<C, 512, 2>, 512);
+        else if (nodes <= 512) go(smallmesh::bwd_kernel<C, 512, 1>, 512);
+        else go(smallmesh::bwd_kernel<C, 1024, 1>, 1024);
+    } else {
+        if (nodes <= 256) go(smallmesh::bwd_kernel<C, 256, 1>, 256);
+        else go(smallmesh::bwd_kernel<C, 512, 1>, 512);
+    }
 }
-extern "C" int gadapt_small_backward(const gadapt_graph* g, const int32_t* mesh_ptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
+extern "C" int gadapt_small_backward(const gadapt_graph* g, const int32_t* mesh_ptr, const int32_t* mesh_eptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
                                      const float* x_all, const float* alpha_all, const float* g_top, int g_cols,
                                      const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
                                      const float* layer_params, int n_layers, float* slab, int c, void* stream) {
@@ -1039,7 +1062,7 @@ extern "C" int gadapt_small_backward(const gadapt_graph* g, const int32_t* mesh_
     if (lds < 0) return fail(GADAPT_E_BADARG, "small_backward: hidden in {4,8,16,32}, at most 1024 nodes per mesh (512 at hidden 32), three row tiles + both CSR slices within 160 KB of LDS");
     // slab: [S][n_meshes][C*C + C] - one row set per conv, what gadapt_slab_reduce_coeffs_backward takes per conv
     smallmesh::BwdArgs p{x_all, alpha_all, g_top, g_cols, wq, bq, wk, w_stride, b_stride, layer_params, g->rowptr_t, g->col_t, g->rowptr_s, g->col_s, g->perm_s,
-                         mesh_ptr, slab, w_stride ? (int64_t)n_meshes * (c * c + c) : 0, n_layers, g->n_edges, max_mesh_nodes, max_mesh_edges, g->n_nodes, nullptr};
+                         mesh_ptr, slab, w_stride ? (int64_t)n_meshes * (c * c + c) : 0, n_layers, g->n_edges, max_mesh_nodes, max_mesh_edges, g->n_nodes, mesh_eptr, n_meshes, nullptr};
 #ifdef GADAPT_STAMPS
     p.dbg = reinterpret_cast<float*>(g_stamp_buf);
 #endif

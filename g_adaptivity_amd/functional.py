@@ -389,12 +389,16 @@ def encode_features(x_comp: torch.Tensor, f_tensor: Optional[torch.Tensor], uu_t
 # One-launch evaluation forward of a batch of small meshes (csrc/gadapt_smallmesh.inc); False keeps the per-layer launches
 # everywhere (tests compare the two).
 SMALL_MESH_FORWARD = os.environ.get('GADAPT_SMALL_MESH', '1') != '0'
+SMALL_MESH_FORCE = os.environ.get('GADAPT_SMALL_MESH', '1') == '2'      # experiments: every size the kernels take, whatever the policies say
 
 
 def small_forward_policy(c: int, max_nodes: int) -> bool:
-    """Sizes at which the one-launch forward is the faster one (tools/sweep_small_mesh.py): one node per thread, so wide rows on
-    large meshes run long serial chains in a single workgroup."""
-    return c <= 8 or (c == 16 and max_nodes <= 256)
+    """Sizes at which the one-launch forward is the faster one (tools/gpu_small_c16.sh / tools/sweep_small_mesh.py, time between HIP
+    events around the replayed forward, one-launch against per-layer: hidden 8: 14.6 / 28.8 us at 11 x 11 ... 29.1 / 29.5 at 31 x 31;
+    hidden 16: 22.4 / 33.6 at 11 x 11, 29.8 / 34.2 at 19 x 19, 51.3 / 34.3 at 23 x 23; hidden 32: 35.4 / 37.9 at 11 x 11, 52.5 / 38.8 at
+    15 x 15).  A workgroup has at most 1024 threads: from 257 nodes on a node has fewer than four lanes, from 513 on one, and the wide
+    rows then run long serial chains."""
+    return SMALL_MESH_FORCE or c <= 8 or (c == 16 and max_nodes <= 384) or (c == 32 and max_nodes <= 128)
 
 
 def small_forward_fits(graph: MeshGraph, part, c: int) -> bool:
@@ -405,11 +409,11 @@ def small_forward_fits(graph: MeshGraph, part, c: int) -> bool:
 
 
 def small_training_policy(c: int, max_nodes: int) -> bool:
-    """Training sizes at which the one-launch forward + one-launch backward pair is the faster step (tools/gpu_small_train.sh, captured
-    step, meshes/s against the per-layer kernels: 11 x 11, batch 8: 134k / 93k; batch 64: 1015k / 713k; 23 x 23, batch 16: 202k / 178k).
-    Hidden 16 keeps the per-layer kernels: its weight-gradient contraction has more elements (272) than a 256-thread workgroup has
-    threads and runs one serial chain per element."""
-    return c <= 8
+    """Training sizes at which the one-launch forward + one-launch backward pair is the faster step (tools/gpu_small_train.sh,
+    tools/gpu_small_c16.sh: captured step, meshes/s against the per-layer kernels.  Hidden 8: 11 x 11, batch 8: 164k / 94k; batch 64:
+    1 240k / 715k; 23 x 23, batch 16: 203k / 178k.  Hidden 16: 11 x 11, batch 8: 115k / 91k; 15 x 15, batch 64: 707k / 624k; 20 x 20,
+    batch 16: 135k / 172k.  Hidden 32: 44k / 73k at 11 x 11 - its backward holds a 32 x 32 contraction per mesh in one workgroup)."""
+    return SMALL_MESH_FORCE or c <= 8 or (c == 16 and max_nodes <= 256)
 
 
 def small_backward_fits(graph: MeshGraph, part, c: int) -> bool:
@@ -425,7 +429,7 @@ def _small_launch(graph, part, x_comp, f_tensor, uu_tensor, enc_weight, wq, bq, 
     out = torch.empty(n, out_cols, device=dev, dtype=torch.float32)
     alpha = torch.empty(num_layers, max(graph.num_edges, 1), device=dev, dtype=torch.float32) if (want_alpha or keep) else None
     x_all = torch.empty(num_layers, n, c, device=dev, dtype=torch.float32) if keep else None
-    check(lib().gadapt_small_forward(graph.c_ref, ptr(mesh_ptr), n_meshes, max_nodes, max_edges, ptr(x_comp), dim,
+    check(lib().gadapt_small_forward(graph.c_ref, ptr(mesh_ptr[0]), ptr(mesh_ptr[1]), n_meshes, max_nodes, max_edges, ptr(x_comp), dim,
                                      ptr(f_tensor), ptr(uu_tensor), ptr(enc_weight), enc_weight.shape[1],
                                      ptr(wq), ptr(bq), ptr(wk), c * c if S > 1 else 0, c if S > 1 else 0,
                                      ptr(layer_params), num_layers, ptr(out), out_cols, ptr(alpha), ptr(x_all), c, current_stream(dev)),
@@ -473,7 +477,7 @@ class _SmallMeshBlock(torch.autograd.Function):
         g_top = g_out.contiguous()
         row = c * c + c
         slab = torch.empty(S, n_meshes, row, device=dev, dtype=torch.float32)
-        check(lib().gadapt_small_backward(graph.c_ref, ptr(mesh_ptr), n_meshes, max_nodes, max_edges, ptr(x_all), ptr(alpha), ptr(g_top),
+        check(lib().gadapt_small_backward(graph.c_ref, ptr(mesh_ptr[0]), ptr(mesh_ptr[1]), n_meshes, max_nodes, max_edges, ptr(x_all), ptr(alpha), ptr(g_top),
                                           ctx.out_cols, ptr(wq), ptr(bq), ptr(wk), c * c if S > 1 else 0, c if S > 1 else 0, ptr(lp), L,
                                           ptr(slab), c, st), 'gadapt_small_backward')
         flat = torch.empty(S * (2 * c * c + 2 * c), device=dev, dtype=torch.float32)

@@ -208,7 +208,8 @@ class MeshGraph:
         self.c_ref = C.byref(self.c_struct)
 
     def mesh_partition(self, batch: Optional[torch.Tensor]):
-        """(mesh_ptr int32 [B+1] on the device, n_meshes, max nodes per mesh, max in-edges per mesh) when the meshes of the batch are
+        """(mesh_ptr int32 [2, B+1] on the device - row 0 the first node, row 1 the first in-edge of each mesh -, n_meshes, max nodes
+        per mesh, max in-edges per mesh) when the meshes of the batch are
         contiguous node ranges that no edge leaves - what PyG collation produces (`batch` non-decreasing, edge_index offset per
         graph) - else None.  `batch=None`: the whole graph is one mesh.  Checked once per `batch` content (one host
         synchronisation), then a dictionary lookup: the one-launch small-mesh forward (csrc/gadapt_smallmesh.inc) needs it."""
@@ -235,7 +236,7 @@ class MeshGraph:
         if ok:
             rp = rowptr.to(torch.int64)
             e_per = rp[ptr_[1:]] - rp[ptr_[:-1]]
-            part = (ptr_.to(torch.int32).to(self.device), int(ptr_.numel() - 1), int((ptr_[1:] - ptr_[:-1]).max()), int(e_per.max()))
+            part = (torch.stack([ptr_, rp[ptr_]]).to(torch.int32).contiguous().to(self.device), int(ptr_.numel() - 1), int((ptr_[1:] - ptr_[:-1]).max()), int(e_per.max()))
         if len(self._partitions) > 8:
             self._partitions.clear()
         self._partitions[key] = part

@@ -71,7 +71,7 @@ class GraphedForward:
         n_feat = pl['enc_w'].shape[1]
         self._fn = _native.lib().gadapt_small_forward
         self._stream = current_stream
-        self._args = [graph.c_ref, mesh_ptr.data_ptr(), n_meshes, max_nodes, max_edges, None, dim, None, None, pl['enc_w'].data_ptr(), n_feat,
+        self._args = [graph.c_ref, mesh_ptr[0].data_ptr(), mesh_ptr[1].data_ptr(), n_meshes, max_nodes, max_edges, None, dim, None, None, pl['enc_w'].data_ptr(), n_feat,
                       pl['wq'].data_ptr(), pl['bq'].data_ptr(), pl['wk'].data_ptr(), c * c if S > 1 else 0, c if S > 1 else 0, pl['lp'].data_ptr(), L,
                       self.out.data_ptr(), pl['out_cols'], None if self._alpha is None else self._alpha.data_ptr(), None, c, None]
         self._n = n
@@ -99,8 +99,8 @@ class GraphedForward:
         xc = self._field('x_comp', data, fields, True)
         f = self._field('f_tensor', data, fields, self._use_f)
         uu = self._field('uu_tensor', data, fields, self._use_uu)
-        a[5], a[7], a[8] = xc.data_ptr(), None if f is None else f.data_ptr(), None if uu is None else uu.data_ptr()
-        a[23] = self._stream(self.device)
+        a[6], a[8], a[9] = xc.data_ptr(), None if f is None else f.data_ptr(), None if uu is None else uu.data_ptr()
+        a[24] = self._stream(self.device)
         rc = self._fn(*a)
         if rc != 0:
             from . import _native

@@ -237,13 +237,16 @@ int gadapt_block_backward_ws(const gadapt_graph* g, const float* x_all, int x0_c
  * utils_eval.py:128-130,193-201; the Burgers rollout, utils_eval_Burgers.py:282-300): encoder (GNN.py:225-239,270), composite
  * coefficients, the L Euler steps (GNN.py:273-291 on GRAND_plus.py:225-343) and the head x[:, :out_cols] (GNN.py:299) by ONE workgroup
  * per mesh - the meshes of a batch are disconnected components, so only workgroup barriers are needed.  mesh_ptr [n_meshes+1]
- * (device): first node of each mesh; every edge must stay inside its mesh; max_mesh_nodes / max_mesh_edges: the largest mesh
- * (<= 1024 nodes, 512 at hidden 32: one node per thread; rows + CSR slice must fit 160 KB: gadapt_small_forward_lds_bytes returns the bytes, or -1).  hidden c in
+ * (device): first node of each mesh (PyG's Batch.ptr); every edge must stay inside its mesh.  mesh_eptr (nullable, device)
+ * [n_meshes+1]: first in-edge of each mesh = rowptr_t[mesh_ptr[m]] - given, a workgroup reads its node and edge bounds side by
+ * side instead of one after the other (a dependent round trip of a ~10 us launch); n_meshes == 1 reads neither.
+ * max_mesh_nodes / max_mesh_edges: the largest mesh
+ * (<= 1024 nodes, 512 at hidden 32: one to four lanes per node; rows + CSR slice must fit 160 KB: gadapt_small_forward_lds_bytes returns the bytes, or -1).  hidden c in
  * {4, 8, 16, 32}.  x_comp [N,dim], f / uu [N] nullable, enc_w [c, n_feat] the frozen bias-free encoder weight; wq / bq / wk advance by
  * w_stride / b_stride floats per layer (0 = shared); layer_params [L,2] = (dt, score scale).  out [N,out_cols]; alpha_all nullable
  * [L,E] (target-CSR order).  No activations are kept: inference only. */
 int64_t gadapt_small_forward_lds_bytes(int max_mesh_nodes, int max_mesh_edges, int c);
-int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_ptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
+int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_ptr, const int32_t* mesh_eptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
                          const float* x_comp, int dim, const float* f, const float* uu, const float* enc_w, int n_feat,
                          const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
                          const float* layer_params, int n_layers, float* out, int out_cols, float* alpha_all, float* x_all, int c, void* stream);
@@ -254,7 +257,7 @@ int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_ptr, int n_m
  * slab: [S][n_meshes][c*c + c] floats - per conv (S = 1 shared, L per-layer) one partial row per mesh (dA then dp0), the layout
  * gadapt_slab_reduce_coeffs_backward(slab + s * n_meshes * (c*c + c), n_meshes, ...) sums and chains to the Linear parameters. */
 int64_t gadapt_small_backward_lds_bytes(int max_mesh_nodes, int max_mesh_edges, int c);
-int gadapt_small_backward(const gadapt_graph* g, const int32_t* mesh_ptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
+int gadapt_small_backward(const gadapt_graph* g, const int32_t* mesh_ptr, const int32_t* mesh_eptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
                           const float* x_all, const float* alpha_all, const float* g_top, int g_cols,
                           const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
                           const float* layer_params, int n_layers, float* slab, int c, void* stream);

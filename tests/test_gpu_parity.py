@@ -142,7 +142,7 @@ def _small_mesh_case(c):
     for d in c[0]:
         per_mesh *= d
     ex = c[5]
-    return c[2] <= 8 and ex.get('residual', True) and not ex.get('learn_step') \
+    return (c[2] <= 8 or (c[2] == 16 and per_mesh <= 256)) and ex.get('residual', True) and not ex.get('learn_step') \
         and ex.get('softmax_temp_type') != 'learnable_a' and not (c[4] == 'GRAND' and ex.get('non_lin', 'identity') != 'identity')
 
 

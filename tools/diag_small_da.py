@@ -31,7 +31,7 @@ for seed in range(3):
     h = lib() if hasattr(lib(), 'gadapt_debug_set_stamp_buffer') else None     # a -DGADAPT_STAMPS build (GADAPT_LIB=build/diag/lib_stamps.so)
     if h is not None:
         h.gadapt_debug_set_stamp_buffer(C_.c_void_p(dbg.data_ptr()))
-    check(lib().gadapt_small_backward(graph.c_ref, ptr(mesh_ptr), n_meshes, mn, me, ptr(x_all), ptr(alpha), ptr(g_top), 1, ptr(wq), ptr(bq), ptr(wk), 0, 0,
+    check(lib().gadapt_small_backward(graph.c_ref, ptr(mesh_ptr[0]), ptr(mesh_ptr[1]), n_meshes, mn, me, ptr(x_all), ptr(alpha), ptr(g_top), 1, ptr(wq), ptr(bq), ptr(wk), 0, 0,
                                       ptr(lp), 1, ptr(slab), c, current_stream(dev)), 'bwd')
     torch.cuda.synchronize()
     row = slab[0].double().sum(0).cpu()
@@ -52,7 +52,7 @@ for seed in range(3):
     print(f"seed {seed}: dA kernel vs fp64-on-same-activations {rel(dA_k, dA_r):.2e}   dp0 {rel(dp0_k, dp0_r):.2e}   |dA| max {dA_r.abs().max():.2e}  sum-of-|terms| / |dA| ~ {((dP.abs().t() @ x.abs()).max() / dA_r.abs().max()).item():.1e}")
     if h is not None:
         lib().gadapt_debug_set_stamp_buffer(None)
-        nm = int(mesh_ptr[1])
+        nm = int(mesh_ptr[0][1])
         dP_k, x_k = dbg[:nm * 8].view(nm, 8).double().cpu(), dbg[nm * 8:2 * nm * 8].view(nm, 8).double().cpu()
         print(f"   mesh 0: dP tile vs fp64 {rel(dP_k, dP[:nm]):.2e}; x tile vs x_all {rel(x_k, x[:nm]):.2e}; dA from the dumped tiles (fp64 product) vs kernel's slab row of mesh 0 {rel((dP_k.t() @ x_k), slab[0, 0, :64].double().cpu().view(8, 8)):.2e}")
         print("   worst dP rows:", (dP_k - dP[:nm]).abs().max(1).values.topk(3))
