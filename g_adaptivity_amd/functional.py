@@ -410,8 +410,8 @@ def small_forward_fits(graph: MeshGraph, part, c: int) -> bool:
 
 def small_training_policy(c: int, max_nodes: int) -> bool:
     """Training sizes at which the one-launch forward + one-launch backward pair is the faster step (tools/gpu_small_train.sh,
-    tools/gpu_small_c16.sh: captured step, meshes/s against the per-layer kernels.  Hidden 8: 11 x 11, batch 8: 164k / 94k; batch 64:
-    1 240k / 715k; 23 x 23, batch 16: 203k / 178k.  Hidden 16: 11 x 11, batch 8: 115k / 91k; 15 x 15, batch 64: 707k / 624k; 20 x 20,
+    tools/gpu_small_c16.sh: captured step, meshes/s against the per-layer kernels.  Hidden 8: 11 x 11, batch 8: 156k / 94k; batch 64:
+    1 196k / 720k; 23 x 23, batch 16: 197k / 178k.  Hidden 16: 11 x 11, batch 8: 115k / 91k; 15 x 15, batch 64: 707k / 624k; 20 x 20,
     batch 16: 135k / 172k.  Hidden 32: 44k / 73k at 11 x 11 - its backward holds a 32 x 32 contraction per mesh in one workgroup)."""
     return SMALL_MESH_FORCE or c <= 8 or (c == 16 and max_nodes <= 256)
 
