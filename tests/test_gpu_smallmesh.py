@@ -16,7 +16,9 @@ CASES = [
     ((15, 15), 3, 16, 3, 'GRAND_plus', {}),
     ((21,), 1, 8, 3, 'GRAND', {'gnn_inc_feat_f': False}),        # Burgers features (params.py:148,155)
     ((21,), 4, 8, 1, 'GRAND', {}),
-    ((23, 23), 2, 8, 4, 'GRAND_plus', {}),                       # the largest shipped mesh (512-thread workgroups)
+    ((23, 23), 2, 8, 4, 'GRAND_plus', {}),                       # the largest shipped mesh (1024 threads, one lane per node)
+    ((20, 20), 2, 8, 3, 'GRAND_plus', {}),                       # 400 nodes: two lanes per node
+    ((8, 8), 3, 8, 3, 'GRAND_plus', {}),                         # 64 nodes: four lanes per node in a 256-thread workgroup
     ((19, 19), 2, 32, 2, 'GRAND_plus', {}),                      # the widest rows the kernel takes (policy forced: see the test)
     ((13, 13), 3, 8, 3, 'GRAND_plus', {'share_conv': False, 'learn_step': True}),
     ((12, 12), 2, 4, 2, 'GRAND_plus', {'softmax_temp_type': 'fixed', 'softmax_temp': 2.0}),
@@ -156,3 +158,43 @@ def test_small_mesh_training_step_graphed_equals_eager_and_tracks_the_oracle(gpu
     for n, p in oracle.named_parameters():
         if p.requires_grad and not n.endswith('lin_skip.weight'):
             assert (res[1][n].cpu() - p.detach()).abs().max().item() <= 2e-5, n
+
+
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh_n,hidden", [(8, 8), (11, 8), (15, 8), (20, 8), (23, 8), (27, 4), (11, 16), (15, 16), (20, 16)],
+                         ids=lambda v: str(v))
+def test_small_mesh_pair_matches_per_layer_kernels_at_every_lane_split(gpu_device, mesh_n, hidden, monkeypatch):
+    """Training forward + backward through the one-launch pair against the per-layer kernels on the same model and batch, at mesh
+    sizes that select every (threads, lanes per node) instantiation of csrc/gadapt_smallmesh.inc: 64 / 121 / 225 / 400 / 529 / 729
+    nodes per mesh = four, four, two, one, one, one lanes in the backward and four, four, four, two, one, one in the forward.  Both
+    are fp32 fma chains of the same formulation: parameter gradients agree to reassociation level."""
+    import g_adaptivity_amd.functional as Fn
+    import torch.nn.functional as F
+    from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt
+    from g_adaptivity_amd._native import lib
+    monkeypatch.setattr(Fn, 'small_forward_policy', lambda c, max_nodes: True)
+    monkeypatch.setattr(Fn, 'small_training_policy', lambda c, max_nodes: True)
+    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=hidden, num_layers=3, device=str(gpu_device))
+    ds = MeshDataset([mesh_n, mesh_n], 3, seed=mesh_n)
+    data = collate(ds.samples).to(gpu_device)
+    torch.manual_seed(3)
+    model = GNN(ds, opt).to(gpu_device).train()
+    res = {}
+    for small in (True, False):
+        monkeypatch.setattr(Fn, 'SMALL_MESH_FORWARD', small)
+        lib().gadapt_profile_reset(); lib().gadapt_profile_enable(1)
+        try:
+            model.zero_grad()
+            out = model(data)
+            F.mse_loss(out, data.x_phys).backward()
+            torch.cuda.synchronize()
+            assert (_launches(10) == 1) == small, "which backward ran is not what the loop variable says"
+        finally:
+            lib().gadapt_profile_enable(0); lib().gadapt_profile_reset()
+        res[small] = (out.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None])
+    assert rel_err(res[True][0], res[False][0])[0] <= 2e-6
+    assert len(res[True][1]) >= 3
+    for a, b in zip(res[True][1], res[False][1]):
+        if b.abs().max() > 0:
+            assert rel_err(a, b)[0] <= 5e-5, rel_err(a, b)
