@@ -62,6 +62,29 @@ extern "C" int gadapt_tile_meta_host(const int32_t* rowptr, const int32_t* col, 
     return GADAPT_OK;
 }
 
+// Strided-walk qualification of the tiles (see include/gadapt_hip.h): sets bit 1 of meta[4t+3] when every neighbour of tile t's rows
+// lies in rows [node0 - 1, node0 + tile_rows + 1) of the tiles `strips` tiles before, at or after t (node0 = t * tile_rows).
+// *n_ok_out = number of tiles that qualify.
+extern "C" int gadapt_tile_meta_strided_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int tile_rows, int strips,
+                                             int32_t* meta_inout, int64_t* n_ok_out) {
+    if (!rowptr || !col || !meta_inout || !n_ok_out || n_nodes <= 0 || tile_rows <= 0 || strips < 2) return GADAPT_E_BADARG;
+    const int64_t n_tiles = (n_nodes + tile_rows - 1) / tile_rows;
+    const int64_t rs = (int64_t)strips * tile_rows;
+    int64_t n_ok = 0;
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        const int64_t lo = t * tile_rows, hi = (lo + tile_rows < n_nodes) ? lo + tile_rows : n_nodes;
+        bool ok = true;
+        for (int32_t e = rowptr[lo]; e < rowptr[hi] && ok; ++e) {
+            const int64_t u = (int64_t)col[e] - lo + 1 + rs;
+            ok = u >= 0 && u < 3 * rs && (u % rs) < tile_rows + 2;
+        }
+        meta_inout[4 * t + 3] = (meta_inout[4 * t + 3] & 1) | (ok ? 2 : 0);
+        n_ok += ok;
+    }
+    *n_ok_out = n_ok;
+    return GADAPT_OK;
+}
+
 // ELL-8 copy of one CSR orientation for the wide kernels (see include/gadapt_hip.h): row i -> ell[8i..8i+7], unused
 // entries -1, rows padded to a multiple of 256 (rows longer than 8 are cut: such a graph never qualifies).  *max_deg_out = the
 // longest row if the orientation qualifies for the 384-row window (every row <= 8 entries and every neighbour of node i

@@ -147,7 +147,7 @@ static int check_launch(const char* what) {
     return GADAPT_OK;
 }
 extern "C" const char* gadapt_last_error(void) { return g_err; }
-extern "C" int gadapt_abi_version(void) { return 6; }   // 6: + wide backward (gadapt_graph.xpos_t/xpos_s, ell_cross_host, block_backward_ws; round 5)
+extern "C" int gadapt_abi_version(void) { return 7; }   // 7: + strided tile walk (gadapt_graph.t_strips, tile_meta_strided_host), small-mesh entry points with mesh_eptr; 6: + wide backward (gadapt_graph.xpos_t/xpos_s, ell_cross_host, block_backward_ws; round 5)
 extern "C" int gadapt_clear_error(void) { g_err[0] = 0; return (int)hipGetLastError(); }
 extern "C" int gadapt_supported_hidden_dim(int c) {
     return c == 4 || c == 8 || c == 16 || c == 32 || c == 64 || c == 128;
@@ -467,6 +467,12 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
     pt.c = C;
     pt.g_stride = g_stride ? g_stride : C;
     pt.sums_partials = sums_partials;
+    // strided tile walk of the hidden-64 dense target pass (128-node mesh rows and the like: gadapt_tile_meta_strided_host)
+    const bool strided = C == 64 && g->t_strips >= 2 && n_tiles % g->t_strips == 0 && g->n_nodes % K::TM == 0;
+    pt.t_strips = strided ? g->t_strips : 1;
+    // (the strip-by-strip order applied inside each XCD group's share of the tiles instead - same nodes per XCD as in the source pass
+    // that follows - was measured no better, and its share boundaries need the L2 path: not kept)
+    pt.t_rows = strided ? n_tiles / g->t_strips : n_tiles;
     if (out4 && (!g_out || x_cols || residual_only || C < 8 || (g_cols && sums_out)))
         return fail(GADAPT_E_BADARG, "4-column backward: a layer with a gradient to pass on, hidden >= 8, not compact-g with d dt / d scale");
 #ifdef GADAPT_STAMPS
@@ -520,6 +526,13 @@ template <int C> static int launch_bwd(const gadapt_graph* g, const float* x_in,
                     }
                 } else if (g_cols) {
                     go(grand_bwd_target_kernel<C, S, true>);
+                } else if (strided && S == 0) {
+                    if constexpr (C == 64 && S == 0) {
+                        constexpr int lds_str = lds_t + K::RING_T * 2 * K::LD * 4;       // one halo row per slab side
+                        auto kern = grand_bwd_target_kernel<C, 0, false, false, true, false, true>;
+                        allow_lds(kern, lds_str);
+                        hipLaunchKernelGGL(kern, dim3(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS))), dim3(K::NT), lds_str, st, pt);
+                    }
                 } else {
                     go(grand_bwd_target_kernel<C, S>);
                 }

@@ -75,6 +75,15 @@ int gadapt_csr_build_host(const int64_t* src, const int64_t* dst, int64_t n_edge
  * window instead of L2), else 0.  The kernels use tile heights 64, 128 and 256 (by hidden size): build all three
  * for both orientations (host pointers). */
 int gadapt_tile_meta_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int tile_rows, int32_t* meta_out);
+/* Strided tile walk (ABI 7; target pass, hidden 64): on row-major meshes whose rows span `strips` >= 2 tiles (128-node rows at
+ * 64-node tiles: config 5) the neighbours of a tile's rows live `strips` tiles away, not next door.  A workgroup then walks the
+ * tiles of ONE strip (t, t + strips, t + 2 strips, ...) and keeps the usual three-slab LDS window, each slab with one halo row per
+ * side for the edges that cross a strip boundary.  This call marks the tiles that qualify: bit 1 of meta[4t+3] is set when every
+ * neighbour of tile t's rows lies in rows [node0 - 1, node0 + tile_rows + 1) of the tiles `strips` before, at or after t
+ * (bit 0 keeps the meaning above); *n_ok_out = their number.  gadapt_graph.t_strips = strips switches the walk on (requires
+ * n_nodes % (strips * 64) == 0); 0 / 1 = off. */
+int gadapt_tile_meta_strided_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int tile_rows, int strips,
+                                  int32_t* meta_inout, int64_t* n_ok_out);
 
 typedef struct gadapt_graph {
     int32_t n_nodes;
@@ -98,6 +107,9 @@ typedef struct gadapt_graph {
     const int32_t* xpos_t;     /* device [round_up(N,256)][8]: ELL-s position (8*src + slot in src's out-row) of the edge in slot k of
                                   node i's in-row; -1 = unused */
     const int32_t* xpos_s;     /* device: ELL-t position (8*dst + slot in dst's in-row) of the edge in slot k of node j's out-row */
+    /* ABI 7 */
+    int32_t t_strips;          /* >= 2: the 64-row tile metadata of the target CSR carries the strided-walk bit for this many tiles per
+                                  mesh row (gadapt_tile_meta_strided_host) and the target pass at hidden 64 walks strip by strip; 0 / 1: off */
 } gadapt_graph;
 
 /* ELL-8 copy of one CSR orientation (host pointers).  The wide kernels (hidden size 64: one wave owns 32 consecutive

@@ -770,3 +770,38 @@ def test_block_backward_inplace_is_bit_identical(gpu_device, hidden, mesh_n, bat
     assert len(res[0]) >= 4
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh_n,batch,strips", [(128, 2, 2), (192, 1, 3), (256, 1, 4)], ids=['128-node-rows', '192-node-rows', '256-node-rows'])
+def test_strided_tile_walk_matches_node_order_walk(gpu_device, mesh_n, batch, strips, monkeypatch):
+    """Hidden-64 target pass on meshes whose rows span several 64-node tiles: the strided walk (one strip per workgroup chunk, LDS
+    window with halo rows; gadapt_tile_meta_strided_host) against the node-order walk (gathers through L2) on the same model and
+    batch.  Per-node arithmetic and edge order are the same; the weight-gradient partials are summed over other tile sets per
+    workgroup: reassociation-level differences only.  64-node rows must not switch the walk on."""
+    import g_adaptivity_amd.graph as graph_mod
+    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=64, num_layers=4, device=str(gpu_device), show_mesh_evol_plots='False')
+    ds = MeshDataset([mesh_n, mesh_n], batch, seed=3)
+    data = collate(ds.samples).to(gpu_device)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(graph_mod, 'STRIDED_WALK', on)
+        torch.manual_seed(8)
+        model = GNN(ds, opt).to(gpu_device).train()
+        out = model(data)
+        F.mse_loss(out, data.x_phys).backward()
+        torch.cuda.synchronize()
+        g = next(iter(model._graphs.values()))
+        assert g.t_strips == (strips if on else 0)
+        res[on] = (out.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None])
+    assert torch.equal(res[True][0], res[False][0])                # the forward does not depend on the walk
+    assert len(res[True][1]) == 4
+    for a, b in zip(res[True][1], res[False][1]):
+        if b.abs().max() > 0:
+            assert rel_err(a, b)[0] <= 2e-5, rel_err(a, b)
+    monkeypatch.setattr(graph_mod, 'STRIDED_WALK', True)
+    ds64 = MeshDataset([64, 64], 2, seed=3)
+    m64 = GNN(ds64, hot_path_opt(mesh_dims=[64, 64], hidden_dim=64, num_layers=2, device=str(gpu_device), show_mesh_evol_plots='False')).to(gpu_device).train()
+    m64(collate(ds64.samples).to(gpu_device)).sum().backward()
+    assert next(iter(m64._graphs.values())).t_strips == 0

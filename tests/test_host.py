@@ -83,7 +83,7 @@ def test_every_declared_symbol_is_exported():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/gadapt_hip.h but not exported"
     assert declared == set(_native.PROTOTYPES), declared ^ set(_native.PROTOTYPES)
-    assert _native.lib().gadapt_abi_version() == 6
+    assert _native.lib().gadapt_abi_version() == 7
     # argument checks need no GPU: the gradient-exchange entry point refuses a null communicator before it looks for RCCL
     assert _native.lib().gadapt_allreduce_flat(None, None, 0, 0, None) == -1
     assert b'allreduce_flat' in _native.lib().gadapt_last_error()
