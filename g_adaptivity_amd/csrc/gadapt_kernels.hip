@@ -1021,6 +1021,8 @@ extern "C" int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_p
     if (dim < 1 || dim > 4 || n_feat != dim + (f ? 1 : 0) + (uu ? 1 : 0) || n_feat > smallmesh::MAXF || n_layers <= 0 || n_layers > smallmesh::MAX_LAYERS
         || out_cols < 1 || out_cols > c)
         return fail(GADAPT_E_BADARG, "small_forward: 1..4 coordinates, encoder columns = coordinates + extras, at most 64 layers, 1 <= out_cols <= hidden");
+    if (n_meshes == 1 && (max_mesh_nodes < g->n_nodes || max_mesh_edges < g->n_edges))
+        return fail(GADAPT_E_BADARG, "small_forward: one mesh = the whole graph: max_mesh_nodes / max_mesh_edges below its node / edge count");
     const int64_t lds = gadapt_small_forward_lds_bytes(max_mesh_nodes, max_mesh_edges, c);
     if (lds < 0) return fail(GADAPT_E_BADARG, "small_forward: hidden in {4,8,16,32}, at most 1024 nodes per mesh (512 at hidden 32), rows + CSR slice within 160 KB of LDS");
     smallmesh::Args p{x_comp, f, uu, enc_w, dim, n_feat, wq, bq, wk, w_stride, b_stride, layer_params, g->rowptr_t, g->col_t, mesh_ptr, mesh_eptr, n_meshes,
@@ -1071,6 +1073,8 @@ extern "C" int gadapt_small_backward(const gadapt_graph* g, const int32_t* mesh_
         || !wq || !bq || !wk || !layer_params || !slab)
         return fail(GADAPT_E_BADARG, "small_backward: null pointer");
     if (g_cols < 1 || g_cols > c || n_layers <= 0 || n_layers > smallmesh::MAX_LAYERS) return fail(GADAPT_E_BADARG, "small_backward: 1 <= g_cols <= hidden, at most 64 layers");
+    if (n_meshes == 1 && (max_mesh_nodes < g->n_nodes || max_mesh_edges < g->n_edges))
+        return fail(GADAPT_E_BADARG, "small_backward: one mesh = the whole graph: max_mesh_nodes / max_mesh_edges below its node / edge count");
     const int64_t lds = gadapt_small_backward_lds_bytes(max_mesh_nodes, max_mesh_edges, c);
     if (lds < 0) return fail(GADAPT_E_BADARG, "small_backward: hidden in {4,8,16,32}, at most 1024 nodes per mesh (512 at hidden 32), three row tiles + both CSR slices within 160 KB of LDS");
     // slab: [S][n_meshes][C*C + C] - one row set per conv, what gadapt_slab_reduce_coeffs_backward takes per conv
