@@ -198,3 +198,54 @@ def test_small_mesh_pair_matches_per_layer_kernels_at_every_lane_split(gpu_devic
     for a, b in zip(res[True][1], res[False][1]):
         if b.abs().max() > 0:
             assert rel_err(a, b)[0] <= 5e-5, rel_err(a, b)
+
+
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh_n,hidden", [(9, 8), (14, 8), (21, 8), (9, 16)], ids=lambda v: str(v))
+def test_small_mesh_pair_takes_long_rows(gpu_device, mesh_n, hidden, monkeypatch):
+    """Rows of more than eight in-neighbours (and nodes with more than eight out-edges) take the loop paths of the one-launch
+    kernels, which the lanes of a node walk with a stride: every mesh of the batch gets a hub node with 14 extra in-edges and one
+    with 12 extra out-edges (inside the mesh: the partition check must still pass).  Forward, attention weights and parameter
+    gradients against the per-layer kernels on the same model and batch, at one / two / four lanes per node."""
+    import g_adaptivity_amd.functional as Fn
+    import torch.nn.functional as F
+    from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt
+    from g_adaptivity_amd._native import lib
+    monkeypatch.setattr(Fn, 'small_forward_policy', lambda c, max_nodes: True)
+    monkeypatch.setattr(Fn, 'small_training_policy', lambda c, max_nodes: True)
+    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=hidden, num_layers=3, device=str(gpu_device), fix_boundary=False)
+    ds = MeshDataset([mesh_n, mesh_n], 3, seed=1)
+    data = collate(ds.samples)
+    per = mesh_n * mesh_n
+    gen = torch.Generator().manual_seed(11)
+    extra = []
+    for m in range(3):
+        base = m * per
+        hub_in, hub_out = base + per // 2, base + per // 3
+        src = base + torch.randperm(per, generator=gen)[:14]
+        dst = base + torch.randperm(per, generator=gen)[:12]
+        extra += [torch.stack([src, torch.full_like(src, hub_in)]), torch.stack([torch.full_like(dst, hub_out), dst])]
+    data.edge_index = torch.cat([data.edge_index] + extra, dim=1)
+    data = data.to(gpu_device)
+    torch.manual_seed(2)
+    model = GNN(ds, opt).to(gpu_device).train()
+    res = {}
+    for small in (True, False):
+        monkeypatch.setattr(Fn, 'SMALL_MESH_FORWARD', small)
+        lib().gadapt_profile_reset(); lib().gadapt_profile_enable(1)
+        try:
+            model.zero_grad()
+            out = model(data)
+            F.mse_loss(out, data.x_phys).backward()
+            torch.cuda.synchronize()
+            assert (_launches(10) == 1) == small
+        finally:
+            lib().gadapt_profile_enable(0); lib().gadapt_profile_reset()
+        res[small] = (out.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None])
+    g = next(iter(model._graphs.values()))
+    assert g.max_in_degree > 8
+    assert rel_err(res[True][0], res[False][0])[0] <= 2e-6
+    for a, b in zip(res[True][1], res[False][1]):
+        if b.abs().max() > 0:
+            assert rel_err(a, b)[0] <= 5e-5, rel_err(a, b)
