@@ -86,11 +86,6 @@ def algorithmic_bytes(kernel, n_nodes, n_edges, c, variant=0, dim=2):
         return (4 * n_nodes * dim if variant & 1 else (16 * n_nodes if variant & 2 else dense)) + x_in + csr
     if kernel == 'backward_source':    # write dx               (+ CSR by source)
         return (16 * n_nodes if variant & 8 else dense) + csr       # out4: only columns 0..3 of dx are produced (layer above a compact layer 0)
-    # wide backward (csrc/gadapt_wide_bwd.inc): the same 12 N C + 8 (E + N + 1) of a layer's backward, split by what each launch must touch
-    if kernel == 'backward_edge':      # read g                 (+ CSR by source; the x rows it reads are the main kernel's)
-        return (4 * n_nodes * dim if variant & 1 else dense) + csr
-    if kernel == 'backward_main':      # read saved x, write dx (+ CSR by target)
-        return dense + (16 * n_nodes if variant & 8 else dense) + csr
     raise KeyError(kernel)
 
 
@@ -415,7 +410,7 @@ def main():
         if w['conv'] == 'GAT_plus':
             graph_obj = graph_obj.with_self_loops()                   # the graph the GAT_plus kernels walk (GATConv's self-loops)
         n_nodes, n_edges = graph_obj.num_nodes, graph_obj.num_edges
-        for kid, name in ((0, 'forward'), (1, 'backward_target'), (2, 'backward_source'), (7, 'backward_edge'), (8, 'backward_main')):
+        for kid, name in ((0, 'forward'), (1, 'backward_target'), (2, 'backward_source')):
             cap = 4 * args.steps * w['layers'] + 16
             buf, vbuf = (C.c_double * cap)(), (C.c_int * cap)()
             cnt = lib.gadapt_profile_samples(kid, buf, cap)

@@ -19,7 +19,7 @@ class GadaptGraph(C.Structure):
                 ('rowptr_s', C.c_void_p), ('col_s', C.c_void_p), ('perm_s', C.c_void_p), ('tpos_s', C.c_void_p),
                 ('meta_t', C.c_void_p * 3), ('meta_s', C.c_void_p * 3),
                 ('ell_t', C.c_void_p), ('ell_s', C.c_void_p), ('wide_deg_t', C.c_int32), ('wide_deg_s', C.c_int32),
-                ('wide_big_deg_t', C.c_int32), ('xpos_t', C.c_void_p), ('xpos_s', C.c_void_p), ('t_strips', C.c_int32)]
+                ('wide_big_deg_t', C.c_int32)]
 
 
 TILE_HEIGHTS = (64, 128, 256)
@@ -36,10 +36,8 @@ PROTOTYPES = {
     'gadapt_clear_error': (_I, []),
     'gadapt_csr_build_host': (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P]),
     'gadapt_tile_meta_host': (_I, [_P, _P, _L, _I, _P]),
-    'gadapt_tile_meta_strided_host': (_I, [_P, _P, _L, _I, _I, _P, _P]),
     'gadapt_ell_build_host': (_I, [_P, _P, _L, _P, _P]),
     'gadapt_wide_window_host': (_I, [_P, _P, _L, _I, _I, _P]),
-    'gadapt_ell_cross_host': (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P]),
     'gadapt_coeffs_forward': (_I, [_P, _P, _P, _P, _P, _I, _P]),
     'gadapt_coeffs_backward': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'gadapt_encode_linear': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
@@ -62,8 +60,6 @@ PROTOTYPES = {
     'gadapt_slab_reduce': (_I, [_P, _I, _P, _P, _P, _I, _P]),
     'gadapt_block_forward': (_I, [_G, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _I, _P]),
     'gadapt_block_backward': (_I, [_G, _P, _I, _P, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
-    'gadapt_block_backward_ws': (_I, [_G, _P, _I, _P, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
-    'gadapt_wide_backward_ws_floats': (_L, [_L]),
     'gadapt_small_forward_lds_bytes': (_L, [_I, _I, _I]),
     'gadapt_small_forward': (_I, [_G, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _L, _L, _P, _I, _P, _I, _P, _P, _I, _P]),
     'gadapt_small_backward_lds_bytes': (_L, [_I, _I, _I]),
@@ -84,7 +80,6 @@ PROTOTYPES = {
     'gadapt_profile_variants': (_I, [_I, C.POINTER(C.c_int), _I]),
     'gadapt_profile_reset': (_I, []),
     'gadapt_profile_calibrate': (_I, [_I, _P]),
-    'gadapt_debug_set_wide_backward': (_I, [_I]),
     'gadapt_debug_set_backward_inplace': (_I, [_I]),
     'gadapt_debug_occupancy': (_I, [_I, C.POINTER(C.c_int)]),
 }

@@ -62,29 +62,6 @@ extern "C" int gadapt_tile_meta_host(const int32_t* rowptr, const int32_t* col, 
     return GADAPT_OK;
 }
 
-// Strided-walk qualification of the tiles (see include/gadapt_hip.h): sets bit 1 of meta[4t+3] when every neighbour of tile t's rows
-// lies in rows [node0 - 1, node0 + tile_rows + 1) of the tiles `strips` tiles before, at or after t (node0 = t * tile_rows).
-// *n_ok_out = number of tiles that qualify.
-extern "C" int gadapt_tile_meta_strided_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int tile_rows, int strips,
-                                             int32_t* meta_inout, int64_t* n_ok_out) {
-    if (!rowptr || !col || !meta_inout || !n_ok_out || n_nodes <= 0 || tile_rows <= 0 || strips < 2) return GADAPT_E_BADARG;
-    const int64_t n_tiles = (n_nodes + tile_rows - 1) / tile_rows;
-    const int64_t rs = (int64_t)strips * tile_rows;
-    int64_t n_ok = 0;
-    for (int64_t t = 0; t < n_tiles; ++t) {
-        const int64_t lo = t * tile_rows, hi = (lo + tile_rows < n_nodes) ? lo + tile_rows : n_nodes;
-        bool ok = true;
-        for (int32_t e = rowptr[lo]; e < rowptr[hi] && ok; ++e) {
-            const int64_t u = (int64_t)col[e] - lo + 1 + rs;
-            ok = u >= 0 && u < 3 * rs && (u % rs) < tile_rows + 2;
-        }
-        meta_inout[4 * t + 3] = (meta_inout[4 * t + 3] & 1) | (ok ? 2 : 0);
-        n_ok += ok;
-    }
-    *n_ok_out = n_ok;
-    return GADAPT_OK;
-}
-
 // ELL-8 copy of one CSR orientation for the wide kernels (see include/gadapt_hip.h): row i -> ell[8i..8i+7], unused
 // entries -1, rows padded to a multiple of 256 (rows longer than 8 are cut: such a graph never qualifies).  *max_deg_out = the
 // longest row if the orientation qualifies for the 384-row window (every row <= 8 entries and every neighbour of node i
@@ -117,32 +94,5 @@ extern "C" int gadapt_wide_window_host(const int32_t* rowptr, const int32_t* col
         }
     }
     *max_deg_out = ok ? longest : 0;
-    return GADAPT_OK;
-}
-
-// Cross positions between the two ELL-8 copies (see include/gadapt_hip.h): for the edge in slot k of node i's in-row
-// (ELL-t position 8 i + k) the position of the same edge in its source's out-row (ELL-s position 8 src + k'), and the inverse.
-// The wide backward kernels exchange per-edge values between the two orientations through these (one kernel writes a value
-// where the other one reads it with a coalesced row load).  Rows longer than 8 are cut like the ELL copies themselves: such a
-// graph never qualifies for the wide kernels.
-extern "C" int gadapt_ell_cross_host(const int32_t* rowptr_t, const int32_t* col_t, const int32_t* tpos_s,
-                                     const int32_t* rowptr_s, const int32_t* col_s, const int32_t* perm_s,
-                                     int64_t n_nodes, int32_t* xpos_t_out, int32_t* xpos_s_out) {
-    if (!rowptr_t || !col_t || !tpos_s || !rowptr_s || !col_s || !perm_s || !xpos_t_out || !xpos_s_out || n_nodes <= 0)
-        return GADAPT_E_BADARG;
-    const int64_t n_pad = (n_nodes + 255) / 256 * 256;
-    for (int64_t k = 0; k < n_pad * 8; ++k) xpos_t_out[k] = xpos_s_out[k] = -1;
-    for (int64_t i = 0; i < n_nodes; ++i) {
-        const int32_t e0 = rowptr_t[i], d = rowptr_t[i + 1] - e0;
-        for (int32_t k = 0; k < d && k < 8; ++k) {
-            const int32_t src = col_t[e0 + k], ks = tpos_s[e0 + k] - rowptr_s[src];
-            xpos_t_out[8 * i + k] = (ks >= 0 && ks < 8) ? 8 * src + ks : -1;
-        }
-        const int32_t s0 = rowptr_s[i], ds = rowptr_s[i + 1] - s0;
-        for (int32_t k = 0; k < ds && k < 8; ++k) {
-            const int32_t dst = col_s[s0 + k], kt = perm_s[s0 + k] - rowptr_t[dst];
-            xpos_s_out[8 * i + k] = (kt >= 0 && kt < 8) ? 8 * dst + kt : -1;
-        }
-    }
     return GADAPT_OK;
 }

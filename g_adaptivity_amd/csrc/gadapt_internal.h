@@ -1,0 +1,221 @@
+// gadapt_internal.h - what the translation units of libgadapt_hip.so share on the host side: build-time geometry parameters, error
+// reporting, the optional per-launch event pairs, launch helpers, and the entry points one unit offers the others.
+//
+// The library is built from several .hip files so that `make -j` compiles the kernel families in parallel and an edit to one
+// family rebuilds one unit (the hot kernels are large templates instantiated for six hidden sizes; as ONE unit the build took
+// 2 min 20 s on one core):
+//   gadapt_kernels.hip         C-ABI of layers / blocks / small per-step kernels, error + profiling state
+//   gadapt_tu_fwd.hip          grand_fwd_kernel<C> (gadapt_fwd.inc), wide::fwd_kernel (gadapt_wide.inc)
+//   gadapt_tu_bwd_target.hip   grand_bwd_target_kernel<C,...>, grand_bwd_target_compact_kernel (gadapt_bwd_target.inc)
+//   gadapt_tu_bwd_source.hip   grand_bwd_source_kernel<C,...>, grand_bwd_source4_kernel (gadapt_bwd_source.inc)
+//   gadapt_tu_smallmesh.hip    one-launch small-mesh pair (gadapt_smallmesh.inc)
+//   gadapt_tu_sparse.hip       generic CSR primitives (gadapt_sparse.inc)
+//   gadapt_tu_gat.hip          fused GAT_plus block (gadapt_gat.inc)
+// Device code is never shared across units (no relocatable device code): every unit includes gadapt_common.inc itself.
+#ifndef GADAPT_INTERNAL_H
+#define GADAPT_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <mutex>
+#include <type_traits>
+#include <utility>
+#include <vector>
+#include "gadapt_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GADAPT_MAXD 8           // in/out degree handled from registers; larger rows take the loop path
+// minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
+#ifndef GADAPT_WAVES_FWD
+#define GADAPT_WAVES_FWD 2
+#endif
+#ifndef GADAPT_WAVES_BWD_T
+#define GADAPT_WAVES_BWD_T 2
+#endif
+#ifndef GADAPT_WAVES_BWD_S
+#define GADAPT_WAVES_BWD_S 2
+#endif
+// Hidden sizes from here on give the backward kernels one wave per SIMD (512 registers): at C = 128 the dA accumulators
+// (64) + projection blocks (32) + row buffers do not fit 256 registers and the spill traffic costs more than the second
+// resident workgroup brings.
+#ifndef GADAPT_ONE_WAVE_C
+#define GADAPT_ONE_WAVE_C 128
+#endif
+// Hidden sizes from here on would use 512-thread workgroups (Cfg::NT).  Measured at hidden 128 (-DGADAPT_WIDE_WG_C=128
+// -DGADAPT_ONE_WAVE_C=256: the per-wave shares of the dA / projection blocks halve, two waves per SIMD): the backward kernels
+// still spill (52 / 47 registers) and BASELINE config 4 ran 16.1k meshes/s against 17.8k with 256 threads at one wave per
+// SIMD (forward 79 vs 59 us, target 142 vs 147, source 106 vs 93) - not adopted, the geometry stays parametrised.
+#ifndef GADAPT_WIDE_WG_C
+#define GADAPT_WIDE_WG_C 1024
+#endif
+#ifndef GADAPT_SLAB_CHUNKS
+#define GADAPT_SLAB_CHUNKS 8    // second-level partials of the slab reduction (<= 32: the scratch the callers allocate).
+                                // 32 / 16 / 8 chunks: first level 5.1 / 5.5 / 5.0 us, second level + chain rule 12.1 / 8.8 / 6.6 us
+#endif
+#ifndef GADAPT_T_RING_MAX_C
+#define GADAPT_T_RING_MAX_C 128   // target pass: largest hidden size that keeps the rolling LDS window of x rows
+#endif
+#ifndef GADAPT_BWD_JIT_B_C
+#define GADAPT_BWD_JIT_B_C 1024  // backward kernels rebuild the projection fragments per tile from this hidden size on
+#endif
+#ifndef GADAPT_BWD_ONE_PER_CU
+#define GADAPT_BWD_ONE_PER_CU 1
+#endif
+#ifndef GADAPT_T_PREFETCH_MAX_C
+#define GADAPT_T_PREFETCH_MAX_C 128  // target pass: largest hidden size that requests the next tile one tile ahead
+#endif
+// Softmax arithmetic: expf / IEEE division (<= 1 ulp each).  The approximate forms (v_exp_f32 of a rounded product, v_rcp_f32)
+// leave alpha with ~4x the rounding error of the reference's exp / true division; harmless for the coordinates (2e-7 either way)
+// but visible in parameter gradients that are the small remainder of large cancelling sums (64x64, 6 layers, hidden 128: 3.4e-4
+// against the fp64 oracle with them, 1.4e-4 without, fp32 reference path 1.0e-4).  Cost of the exact forms: +0.6 us per forward
+// launch (17.1 -> 17.7 us), nothing measurable elsewhere.
+__device__ __forceinline__ float sm_exp(float x) { return expf(x); }
+__device__ __forceinline__ float sm_rcp(float x) { return 1.0f / x; }
+
+// ------------------------------------------------------------------------------------------------
+// error reporting (state in gadapt_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+int gadapt_fail_(int code, const char* msg);
+int gadapt_check_launch_(const char* what);
+static inline int fail(int code, const char* msg) { return gadapt_fail_(code, msg); }
+static inline int check_launch(const char* what) { return gadapt_check_launch_(what); }
+
+// ------------------------------------------------------------------------------------------------
+// optional per-kernel timing (bench/roofline only): HIP events on the launch stream around every hot-kernel launch.  Off by
+// default; when off a launch reads one relaxed atomic and touches nothing else.  variant: bit 0 = compact upstream gradient,
+// bit 1 = compact layer input, bit 2 = head-only output, bit 3 = 4-column backward output.
+// ------------------------------------------------------------------------------------------------
+struct ProfScope {
+    hipStream_t st; int idx = -1; hipEvent_t eb = nullptr;
+    ProfScope(int id, hipStream_t s, int variant = 0);
+    ~ProfScope();
+};
+
+#ifdef GADAPT_STAMPS
+extern unsigned long long* g_stamp_buf;                         // diagnostic builds: in-kernel cycle stamps (tools/stamp_*.py)
+#endif
+
+#include "gadapt_common.inc"
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+// Workgroups of a launch: a multiple of 8 (XCD groups), at most max_blocks (the resident set) unless that would give a workgroup
+// more than 64 tiles (Cfg::MAXM: its tile metadata must fit the LDS table).
+static inline int grid_for(int n_tiles, int max_blocks) {
+    int g = (n_tiles + 7) & ~7;
+    if (g > max_blocks) g = max_blocks;
+    const int need = (((n_tiles + 63) / 64) + 7) & ~7;
+    if (g < need) g = need;
+    if (g < 8) g = 8;
+    return g;
+}
+#ifndef GADAPT_FWD_MAX_BLOCKS
+#define GADAPT_FWD_MAX_BLOCKS 512        /* 2 resident workgroups per CU (LDS ring: 4 tiles each) x 256 CUs */
+#endif
+#ifndef GADAPT_BWD_S_MAX_BLOCKS
+#define GADAPT_BWD_S_MAX_BLOCKS 512      /* the resident set (2 workgroups per CU): measured 27.8 vs 28.7 us with 1024 */
+#endif
+#ifndef GADAPT_BWD_T_MAX_BLOCKS
+#define GADAPT_BWD_T_MAX_BLOCKS 512      /* target pass grid = slab row count */
+#endif
+
+// per-tile metadata pointer for this kernel's tile height (the graph carries one array per supported height)
+template <int TM> static const int32_t* meta_for(const int32_t* const (&m)[3]) {
+    static_assert(TM == 64 || TM == 128 || TM == 256, "tile heights with metadata");
+    return m[TM == 64 ? 0 : (TM == 128 ? 1 : 2)];
+}
+// More than 48 KB of dynamic LDS needs the attribute set once per (device, kernel); the call costs several microseconds
+// of host time, which is most of an eager small-graph forward, so it is remembered (per translation unit).
+template <typename KernelT> static void allow_lds(KernelT k, int bytes) {
+    if (bytes <= 48 * 1024) return;
+    // forward launches come from the Python thread, backward launches from autograd's worker thread: the table is guarded
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void*>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void* f = reinterpret_cast<const void*>(k);
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& d : done) if (d.first == dev && d.second == f) return;
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) done.emplace_back(dev, f);
+}
+
+// resident set of a launch: two 256-thread workgroups per CU, or one 512-thread workgroup (Cfg::NT)
+template <int C> static constexpr int resident_blocks(int two_per_cu_default) { return Cfg<C>::NT == 512 ? 256 : two_per_cu_default; }
+// ... and the backward kernels of hidden sizes that run one wave per SIMD (GADAPT_ONE_WAVE_C: 392 / 504 registers) fit ONE
+// 256-thread workgroup per CU: 256 workgroups are the resident set, a 512-workgroup launch would run as two rounds (and
+// flush twice as many slab rows).
+template <int C> static constexpr int resident_blocks_bwd(int two_per_cu_default) {
+    return (C >= GADAPT_ONE_WAVE_C && GADAPT_BWD_ONE_PER_CU) ? 256 : resident_blocks<C>(two_per_cu_default);
+}
+// ... and the target pass at hidden 32 (128-row tiles: ring + dP tile + slices = 87 KB of LDS) fits one workgroup per CU too
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor: forward / target / source = 2 / 1 / 2 at hidden 32, 2 / 2 / 2 at 64,
+// 2 / 1 / 1 at 128, 3 / 3 / 3 at 8).
+template <int C> static constexpr int resident_blocks_bwd_t(int two_per_cu_default) {
+    return (C == 32 && GADAPT_BWD_ONE_PER_CU) ? 256 : resident_blocks_bwd<C>(two_per_cu_default);
+}
+template <int C> static int tiles_for(int64_t n_nodes) { return (int)((n_nodes + Cfg<C>::TM - 1) / Cfg<C>::TM); }
+
+// GADAPT_DEV_C=<hidden>: development builds that instantiate the tiled kernels for ONE hidden size only (never shipped: build()
+// and the Makefile's default target compile every size)
+#ifdef GADAPT_DEV_C
+#define GADAPT_DISPATCH_C(c, CALL)                                                   \
+    switch (c) {                                                                     \
+        case GADAPT_DEV_C: { constexpr int CC = GADAPT_DEV_C; return CALL; }         \
+        default: return fail(GADAPT_E_BADARG, "development build: one hidden size only (GADAPT_DEV_C)");  \
+    }
+#else
+#define GADAPT_DISPATCH_C(c, CALL)                                                   \
+    switch (c) {                                                                     \
+        case 4:   { constexpr int CC = 4;   return CALL; }                           \
+        case 8:   { constexpr int CC = 8;   return CALL; }                           \
+        case 16:  { constexpr int CC = 16;  return CALL; }                           \
+        case 32:  { constexpr int CC = 32;  return CALL; }                           \
+        case 64:  { constexpr int CC = 64;  return CALL; }                           \
+        case 128: { constexpr int CC = 128; return CALL; }                           \
+        default: return fail(GADAPT_E_BADARG, "hidden_dim must be one of 4, 8, 16, 32, 64, 128");  \
+    }
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// what the kernel units offer the C-ABI unit (validated arguments; one launch each)
+// ------------------------------------------------------------------------------------------------
+// Loss fused into the head-only forward launch of the last layer (gadapt_block_forward_loss): the launch that writes x_top4 also
+// writes seed = d loss / d x_top4[:, :d] and one partial of sum |pred - target|^p per workgroup.
+struct FwdLossArgs {
+    const float* target;   // [N,d]
+    float* seed;           // [N,d]
+    float* partials;       // [GADAPT_LOSS_PARTIALS_MAX]: slot b written by workgroup b, slots past the grid zeroed by workgroup 0
+    int d, l1;
+    float inv_count;       // 1 / (N d)
+};
+#define GADAPT_LOSS_PARTIALS_MAX 512
+// Compact layer input assembled from the caller's node fields instead of read from x_all's slot 0 (gadapt_block_forward_fields):
+// row i = [x_comp[i, 0..dim) | f[i] | uu[i] | 0...] (GNN.py:225-239 through the identity encoder, GNN.py:75-82); the launch also
+// writes the rows of its own nodes to x0c [N,4] for the layer-0 backward.
+struct FwdFieldArgs {
+    const float* x_comp; const float* f; const float* uu;   // f / uu nullable
+    int dim;
+    float* x0c;
+};
+int gadapt_launch_fwd_c(int c, const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0, const float* lp,
+                        float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st,
+                        const FwdLossArgs* loss = nullptr, const FwdFieldArgs* fields = nullptr);
+// target pass (always) ...
+int gadapt_launch_bwd_target_c(int c, const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha, const float* a,
+                               const float* lp, float* edge_ws, float* dxd, float* slab, int accumulate, float* sums_out, float* sums_sc_out,
+                               int want_source, int residual_only, int g_cols, int x_cols, int out4, int g_stride, int sums_partials,
+                               hipStream_t st);
+// ... and the source pass of the same layer (g_out != NULL)
+int gadapt_launch_bwd_source_c(int c, const gadapt_graph* g, const float* x_in, const float* g_in, const float* edge_ws, const float* dxd,
+                               const float* a, const float* p0, float* g_out, int g_cols, int out4, hipStream_t st);
+int gadapt_slab_rows_c(int64_t n_nodes, int c);
+int gadapt_occupancy_fwd_c(int c);
+int gadapt_occupancy_bwd_target_c(int c);
+int gadapt_occupancy_bwd_source_c(int c);
+
+#endif  // GADAPT_INTERNAL_H

@@ -20,18 +20,6 @@ from ._native import check, current_stream, lib, ptr
 from .graph import MeshGraph
 
 
-# The wide backward kernels (csrc/gadapt_wide_bwd.inc) are an alternative to the tiled target / source pair in the layers they
-# cover; off by default (the two measure level on the metric workload, docs/measurements.md F).  GADAPT_WIDE_BWD=1 or
-# set_wide_backward(True) select them.
-_WIDE_BACKWARD = {'on': os.environ.get('GADAPT_WIDE_BWD', '0') == '1'}
-
-
-def set_wide_backward(on: bool) -> None:
-    """Select the wide backward kernels (hidden 64, graphs that qualify) or the tiled pair for later backward calls."""
-    _WIDE_BACKWARD['on'] = bool(on)
-    check(lib().gadapt_debug_set_wide_backward(int(bool(on))), 'gadapt_debug_set_wide_backward')
-
-
 def _require_gpu(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise _native.NativeError(f"{what}: the message-passing path runs on the MI355X only (got a {t.device} tensor); "
@@ -154,15 +142,11 @@ class _GrandEulerBlock(torch.autograd.Function):
             d_lp = flat[n_w:]                   # [2,L], written whole by gadapt_layer_params_reduce below
             d_ws = torch.empty(2 * L * slab_rows, device=dev, dtype=torch.float32)   # one slot per (kind, layer, workgroup)
         d_x0 = torch.empty(n, c, device=dev, dtype=torch.float32) if need_x0 else None
-        # workspace of the wide backward kernels (hidden 64 on graphs that qualify): the layers they cover run as an edge kernel + one
-        # main kernel instead of the target / source pair
-        wsf = graph.wide_backward_ws_floats if (c == 64 and _WIDE_BACKWARD['on']) else 0
-        wide_ws = torch.empty(wsf, device=dev, dtype=torch.float32) if wsf else None
-        check(lib().gadapt_block_backward_ws(graph.c_ref, ptr(x_all), ctx.x0_cols, ptr(alpha), ptr(g_top), g_cols, L,
-                                             ptr(a), c * c if S > 1 else 0, ptr(p0), c if S > 1 else 0, ptr(layer_params),
-                                             ptr(g_ws), ptr(dxd_ws), ptr(edge_ws), ptr(slab), ptr(d_ws), int(bool(ctx.needs_input_grad[5])),
-                                             ptr(d_x0), c, st, ptr(wide_ws)),
-              'gadapt_block_backward_ws')
+        check(lib().gadapt_block_backward(graph.c_ref, ptr(x_all), ctx.x0_cols, ptr(alpha), ptr(g_top), g_cols, L,
+                                          ptr(a), c * c if S > 1 else 0, ptr(p0), c if S > 1 else 0, ptr(layer_params),
+                                          ptr(g_ws), ptr(dxd_ws), ptr(edge_ws), ptr(slab), ptr(d_ws), int(bool(ctx.needs_input_grad[5])),
+                                          ptr(d_x0), c, st),
+              'gadapt_block_backward')
         scratch = torch.empty(32 * (c * c + c), device=dev, dtype=torch.float32)
         cuts = [0, S * c * c, S * (c * c + c), S * (2 * c * c + c), S * (2 * c * c + 2 * c)]
         d_wq, d_wk = flat[cuts[0]:cuts[1]].view(S, c, c), flat[cuts[2]:cuts[3]].view(S, c, c)

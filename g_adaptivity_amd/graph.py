@@ -141,11 +141,6 @@ WIDE_KERNELS = True
 # batch too small to fill the 256 CUs does not earn back (forward of 64x64 meshes, hidden 64, 4 layers as one hipGraph:
 # batch 1 / 4 / 8 / 16 = 78.6 / 80.7 / 85.7 / 93.2 us wide against 74.5 / 74.1 / 87.1 / 110.1 us tiled).
 WIDE_MIN_NODES = 24576
-# The strided tile walk of the hidden-64 target pass on meshes whose rows span several tiles (gadapt_tile_meta_strided_host).  OFF by
-# default: measured on config 5 (docs/measurements.md G) the target pass gains 0-3 % from gathering out of LDS instead of L2 and the
-# source pass that follows LOSES 9 % (it finds less of dxd / the edge scratch where the node-order target pass leaves it).  Tests
-# compare the two walks.  Read when a MeshGraph is built; part of the cache key.
-STRIDED_WALK = os.environ.get('GADAPT_STRIDED_WALK', '0') == '1'
 
 
 class MeshGraph:
@@ -172,21 +167,6 @@ class MeshGraph:
                 if _native.lib().gadapt_tile_meta_host(rp.data_ptr(), cl.data_ptr(), n, tm, m.data_ptr()) != 0:
                     raise _native.NativeError("gadapt_tile_meta_host failed")
                 metas[(tag, tm)] = m
-        # strided tile walk of the hidden-64 target pass (csrc/gadapt_bwd_target.inc, STR): row-major meshes whose rows span 2..4
-        # 64-node tiles - hardly any tile finds its neighbours next door, nearly all find them `strips` tiles away
-        self.t_strips = 0
-        m64 = metas[('t', 64)]
-        n_t = m64.numel() // 4
-        if STRIDED_WALK and n_t >= 8 and int((m64[3::4] & 1).sum()) * 2 < n_t:
-            for strips in (2, 3, 4):
-                if n % (64 * strips):
-                    continue
-                trial, n_ok = m64.clone(), C.c_int64(0)
-                if _native.lib().gadapt_tile_meta_strided_host(rowptr_t.data_ptr(), col_t.data_ptr(), n, 64, strips, trial.data_ptr(), C.addressof(n_ok)) != 0:
-                    raise _native.NativeError("gadapt_tile_meta_strided_host failed")
-                if n_ok.value * 10 >= 9 * n_t:
-                    metas[('t', 64)], self.t_strips = trial, strips
-                    break
         metas = {k: v.to(self.device) for k, v in metas.items()}
         self._metas = metas
         # ELL-8 copies + eligibility for the wide (hidden 64) kernels
@@ -199,14 +179,6 @@ class MeshGraph:
                 raise _native.NativeError("gadapt_ell_build_host failed")
             ells[tag], wide_deg[tag] = ell.to(self.device), (int(md.value) if (WIDE_KERNELS and n >= WIDE_MIN_NODES) else 0)
         self._ells, self.wide_deg = ells, wide_deg
-        # cross positions between the two ELL copies: the wide backward hands per-edge values from one end of an edge to the other
-        self._xpos = None
-        if wide_deg['t'] > 0 and wide_deg['s'] > 0:
-            xt, xs = torch.empty(n_pad * 8, dtype=torch.int32), torch.empty(n_pad * 8, dtype=torch.int32)
-            if _native.lib().gadapt_ell_cross_host(rowptr_t.data_ptr(), col_t.data_ptr(), tpos_s.data_ptr(), rowptr_s.data_ptr(), col_s.data_ptr(),
-                                                   perm_s.data_ptr(), n, xt.data_ptr(), xs.data_ptr()) != 0:
-                raise _native.NativeError("gadapt_ell_cross_host failed")
-            self._xpos = (xt.to(self.device), xs.to(self.device))
         # 512-row window of the wide forward: row-major meshes with up to 128 nodes per mesh row that miss the 384-row one
         self.wide_big_deg = 0
         if WIDE_KERNELS and n >= WIDE_MIN_NODES and wide_deg['t'] == 0:
@@ -225,9 +197,7 @@ class MeshGraph:
                                     self.tpos_s.data_ptr(),
                                     (C.c_void_p * 3)(*[metas[('t', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]),
                                     (C.c_void_p * 3)(*[metas[('s', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]),
-                                    ells['t'].data_ptr(), ells['s'].data_ptr(), wide_deg['t'], wide_deg['s'], self.wide_big_deg,
-                                    self._xpos[0].data_ptr() if self._xpos else None, self._xpos[1].data_ptr() if self._xpos else None,
-                                    self.t_strips)
+                                    ells['t'].data_ptr(), ells['s'].data_ptr(), wide_deg['t'], wide_deg['s'], self.wide_big_deg)
         self.c_ref = C.byref(self.c_struct)
 
     def mesh_partition(self, batch: Optional[torch.Tensor]):
@@ -266,11 +236,6 @@ class MeshGraph:
         return part
 
     @property
-    def wide_backward_ws_floats(self) -> int:
-        """Floats of the workspace `gadapt_block_backward_ws` takes for the wide backward kernels; 0 = this graph does not qualify."""
-        return int(_native.lib().gadapt_wide_backward_ws_floats(self.num_nodes)) if self._xpos else 0
-
-    @property
     def has_in(self) -> torch.Tensor:
         """[N,1] float mask: 1 where a node has at least one in-edge (kept on the graph it belongs to)."""
         m = getattr(self, '_has_in', None)
@@ -306,7 +271,7 @@ class GraphCache:
 
     @staticmethod
     def _key(edge_index: torch.Tensor, num_nodes: int, device) -> Tuple:
-        return (int(num_nodes), str(device), content_fingerprint([edge_index]), WIDE_KERNELS, WIDE_MIN_NODES, STRIDED_WALK)
+        return (int(num_nodes), str(device), content_fingerprint([edge_index]), WIDE_KERNELS, WIDE_MIN_NODES)
 
     def get(self, edge_index: torch.Tensor, num_nodes: int, device) -> MeshGraph:
         key = self._key(edge_index, num_nodes, device)

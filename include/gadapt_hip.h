@@ -75,15 +75,6 @@ int gadapt_csr_build_host(const int64_t* src, const int64_t* dst, int64_t n_edge
  * window instead of L2), else 0.  The kernels use tile heights 64, 128 and 256 (by hidden size): build all three
  * for both orientations (host pointers). */
 int gadapt_tile_meta_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int tile_rows, int32_t* meta_out);
-/* Strided tile walk (ABI 7; target pass, hidden 64): on row-major meshes whose rows span `strips` >= 2 tiles (128-node rows at
- * 64-node tiles: config 5) the neighbours of a tile's rows live `strips` tiles away, not next door.  A workgroup then walks the
- * tiles of ONE strip (t, t + strips, t + 2 strips, ...) and keeps the usual three-slab LDS window, each slab with one halo row per
- * side for the edges that cross a strip boundary.  This call marks the tiles that qualify: bit 1 of meta[4t+3] is set when every
- * neighbour of tile t's rows lies in rows [node0 - 1, node0 + tile_rows + 1) of the tiles `strips` before, at or after t
- * (bit 0 keeps the meaning above); *n_ok_out = their number.  gadapt_graph.t_strips = strips switches the walk on (requires
- * n_nodes % (strips * 64) == 0); 0 / 1 = off. */
-int gadapt_tile_meta_strided_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int tile_rows, int strips,
-                                  int32_t* meta_inout, int64_t* n_ok_out);
 
 typedef struct gadapt_graph {
     int32_t n_nodes;
@@ -103,13 +94,6 @@ typedef struct gadapt_graph {
     int32_t wide_deg_s;        /* same for the source orientation */
     int32_t wide_big_deg_t;    /* longest in-row if the target orientation qualifies for the 512-row window of the wide forward
                                   (gadapt_wide_window_host(halo 128, rows <= 7): meshes with up to 128 nodes per row), else 0 */
-    /* ABI 6, optional (NULL = absent): cross positions between the two ELL copies (gadapt_ell_cross_host), for the wide backward */
-    const int32_t* xpos_t;     /* device [round_up(N,256)][8]: ELL-s position (8*src + slot in src's out-row) of the edge in slot k of
-                                  node i's in-row; -1 = unused */
-    const int32_t* xpos_s;     /* device: ELL-t position (8*dst + slot in dst's in-row) of the edge in slot k of node j's out-row */
-    /* ABI 7 */
-    int32_t t_strips;          /* >= 2: the 64-row tile metadata of the target CSR carries the strided-walk bit for this many tiles per
-                                  mesh row (gadapt_tile_meta_strided_host) and the target pass at hidden 64 walks strip by strip; 0 / 1: off */
 } gadapt_graph;
 
 /* ELL-8 copy of one CSR orientation (host pointers).  The wide kernels (hidden size 64: one wave owns 32 consecutive
@@ -122,14 +106,6 @@ int gadapt_ell_build_host(const int32_t* rowptr, const int32_t* col, int64_t n_n
  * every neighbour of node i lies in rows [256*(i/256) - halo, 256*(i/256) + 256 + halo), else 0.  halo 128 / max_row 7 is what
  * the wide forward's 512-row window takes (row-major meshes with up to 128 nodes per mesh row: BASELINE config 5). */
 int gadapt_wide_window_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int halo, int max_row, int32_t* max_deg_out);
-/* Cross positions between the two ELL-8 copies (host pointers; outputs round_up(N,256)*8 int32 each, -1 = unused): xpos_t[8i+k]
- * = where the edge in slot k of node i's in-row sits in its source's out-row (8*src + k'), xpos_s[8j+k] = where the edge in
- * slot k of node j's out-row sits in its target's in-row.  The wide backward kernels hand per-edge values from one side of an
- * edge to the other through them (autograd of MessagePassing.propagate, GRAND_plus.py:233-234: every edge quantity is needed
- * grouped by target AND by source). */
-int gadapt_ell_cross_host(const int32_t* rowptr_t, const int32_t* col_t, const int32_t* tpos_s,
-                          const int32_t* rowptr_s, const int32_t* col_s, const int32_t* perm_s,
-                          int64_t n_nodes, int32_t* xpos_t_out, int32_t* xpos_s_out);
 
 /* ------------------------------------------------------------------ weights
  * A[o][c] = sum_r Wk[r][o] Wq[r][c],  p0[o] = sum_r Wk[r][o] bq[r].
@@ -232,18 +208,6 @@ int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols
                           const float* layer_params,
                           float* g_ws, float* dxd_ws, float* edge_ws, float* slab,
                           float* d_layer_params, int want_d_scale, float* d_x0, int c, void* stream);
-/* The same with a workspace for the WIDE backward kernels (hidden 64, graphs that qualify in both orientations and carry
- * xpos_t / xpos_s): wide_ws (nullable) = gadapt_wide_backward_ws_floats(N) floats.  With it - and gadapt_debug_set_wide_backward(1) -
- * the layers the wide kernels cover (today: the top layer of a block with a compact upstream gradient) run as an edge kernel + one
- * main kernel (csrc/gadapt_wide_bwd.inc) instead of the tiled target / source pair; every other layer, and every call without the
- * workspace, runs the pair.  Same results up to fp32 summation order. */
-int64_t gadapt_wide_backward_ws_floats(int64_t n_nodes);
-int gadapt_block_backward_ws(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all,
-                             const float* g_top, int g_top_cols, int n_layers,
-                             const float* a, int64_t a_stride, const float* p0, int64_t p0_stride,
-                             const float* layer_params,
-                             float* g_ws, float* dxd_ws, float* edge_ws, float* slab,
-                             float* d_layer_params, int want_d_scale, float* d_x0, int c, void* stream, float* wide_ws);
 /* ------------------------------------------------------------------ small meshes: the whole evaluation forward in ONE launch
  * The reference's own sizes (params.py:37,56,107,130-134: 11x11 ... 23x23 meshes, hidden 8, 4 layers; evaluation one sample per call,
  * utils_eval.py:128-130,193-201; the Burgers rollout, utils_eval_Burgers.py:282-300): encoder (GNN.py:225-239,270), composite
@@ -398,11 +362,7 @@ int gadapt_profile_reset(void);
 /* Dispatch share D of an event pair: n x one empty launch (kernel id 3, p1) and n x two empty launches (id 4, p2),
  * bracketed like the hot kernels; D = 2 p1 - p2. */
 int gadapt_profile_calibrate(int n, void* stream);
-/* Switch: 1 lets gadapt_block_backward_ws run the wide backward kernels in the layers they cover (when it is given a workspace);
- * 0 (the default: the two measure level on the metric workload, docs/measurements.md F) keeps the tiled target / source pair
- * everywhere.  GADAPT_WIDE_BWD=1 in the environment sets the initial value.  tests compare the two on the same inputs. */
-int gadapt_debug_set_wide_backward(int on);
-/* Switch: 1 (the default; GADAPT_BWD_INPLACE=0 in the environment starts with 0) lets gadapt_block_backward_ws keep a dense
+/* Switch: 1 (the default; GADAPT_BWD_INPLACE=0 in the environment starts with 0) lets gadapt_block_backward keep a dense
  * layer's dxd rows in the buffer its source pass then writes g_out to - every lane group reads its dxd row before it stores the
  * same row of g_out - so a layer pair touches two [N,C] work buffers instead of three (dxd_ws then only serves layer 0 and the
  * 4-column pair).  Results are bit-identical either way (tests/test_gpu_ops.py::test_block_backward_inplace_is_bit_identical). */

@@ -685,67 +685,11 @@ def test_wide_kernels_rebase_large_scores(gpu_device):
     assert rel_err(res, ref)[0] <= 2e-5, rel_err(res, ref)
 
 
-@pytest.mark.one_dispatch
-@pytest.mark.gpu
-@pytest.mark.parametrize("mesh_n,batch,layers", [(16, 3, 4), (64, 2, 2), (64, 9, 4), (33, 5, 3)], ids=['16x16-b3', '64x64-b2-L2', '64x64-b9', '33x33-b5-L3'])
-def test_wide_backward_matches_two_pass(gpu_device, mesh_n, batch, layers, monkeypatch):
-    """The wide backward (edge kernel + main kernel, csrc/gadapt_wide_bwd.inc) against the tiled target / source pair on the same
-    inputs: parameter gradients at model level (compact slots: the top layer's compact upstream gradient) and d x0 + parameter
-    gradients at block-op level, up to fp32 reassociation.  Batches of several steps per workgroup, a ragged last step, meshes whose
-    rows do not align with the 256-node steps."""
-    import g_adaptivity_amd.graph as graph_mod
-    from g_adaptivity_amd._native import lib
-    monkeypatch.setattr(graph_mod, 'WIDE_MIN_NODES', 0)
-    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=64, num_layers=layers, device=str(gpu_device), show_mesh_evol_plots='False')
-    ds = MeshDataset([mesh_n, mesh_n], batch, seed=9)
-    data = collate(ds.samples).to(gpu_device)
-    torch.manual_seed(5)
-    model = GNN(ds, opt).to(gpu_device).train()
-    res = {}
-    for wide in (0, 1):
-        Fn.set_wide_backward(wide)
-        try:
-            model.zero_grad()
-            F.mse_loss(model(data), data.x_phys).backward()
-            torch.cuda.synchronize()
-            res[wide] = [p.grad.clone() for p in model.parameters() if p.grad is not None]
-        finally:
-            Fn.set_wide_backward(False)
-    g = next(iter(model._graphs.values()))
-    assert g.wide_backward_ws_floats > 0, "the mesh batch must qualify for the wide backward, or this test compares the pair with itself"
-    assert len(res[0]) == 4
-    for a, b in zip(res[0], res[1]):
-        if a.abs().max() > 0:
-            assert rel_err(b, a)[0] <= 2e-5, rel_err(b, a)
-    # operator level: d x0 wanted, compact upstream gradient through out_cols
-    C = 64
-    graph = g
-    n = graph.num_nodes
-    wq, bq, wk, bk = [w.unsqueeze(0) for w in _random_layer(C, 22, gpu_device)]
-    lp = torch.tensor([[0.1, 1.0 / math.sqrt(C)]] * layers, device=gpu_device)
-    x0 = torch.randn(n, C, generator=torch.Generator().manual_seed(23)).to(gpu_device)
-    up = torch.randn(n, 2, generator=torch.Generator().manual_seed(24)).to(gpu_device)
-    outs = {}
-    for wide in (0, 1):
-        Fn.set_wide_backward(wide)
-        try:
-            xr = x0.clone().requires_grad_(True)
-            ps = [t.clone().requires_grad_(True) for t in (wq, bq, wk, bk)]
-            y, _ = Fn.grand_euler_block(xr, *ps, lp, graph, layers, out_cols=2)
-            (y * up).sum().backward()
-            torch.cuda.synchronize()
-            outs[wide] = [xr.grad.clone()] + [t.grad.clone() for t in ps[:3]]
-        finally:
-            Fn.set_wide_backward(False)
-    for a, b in zip(outs[0], outs[1]):
-        assert rel_err(b, a)[0] <= 2e-5, rel_err(b, a)
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("hidden,mesh_n,batch,layers,learn", [(64, 64, 3, 4, False), (64, 33, 5, 3, True), (32, 20, 4, 3, False), (128, 16, 2, 3, False), (8, 15, 3, 4, False)],
                          ids=['C64-64x64', 'C64-33x33-learn-step', 'C32', 'C128', 'C8'])
 def test_block_backward_inplace_is_bit_identical(gpu_device, hidden, mesh_n, batch, layers, learn, monkeypatch):
-    """gadapt_block_backward_ws with the source pass writing g_out over the dxd rows it has read (the default) against separate
+    """gadapt_block_backward with the source pass writing g_out over the dxd rows it has read (the default) against separate
     buffers: the same launches on the same values, so every gradient is bit-identical."""
     import g_adaptivity_amd.functional as Fn_mod
     from g_adaptivity_amd._native import lib
@@ -770,38 +714,3 @@ def test_block_backward_inplace_is_bit_identical(gpu_device, hidden, mesh_n, bat
     assert len(res[0]) >= 4
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
-
-
-@pytest.mark.one_dispatch
-@pytest.mark.gpu
-@pytest.mark.parametrize("mesh_n,batch,strips", [(128, 2, 2), (192, 1, 3), (256, 1, 4)], ids=['128-node-rows', '192-node-rows', '256-node-rows'])
-def test_strided_tile_walk_matches_node_order_walk(gpu_device, mesh_n, batch, strips, monkeypatch):
-    """Hidden-64 target pass on meshes whose rows span several 64-node tiles: the strided walk (one strip per workgroup chunk, LDS
-    window with halo rows; gadapt_tile_meta_strided_host) against the node-order walk (gathers through L2) on the same model and
-    batch.  Per-node arithmetic and edge order are the same; the weight-gradient partials are summed over other tile sets per
-    workgroup: reassociation-level differences only.  64-node rows must not switch the walk on."""
-    import g_adaptivity_amd.graph as graph_mod
-    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=64, num_layers=4, device=str(gpu_device), show_mesh_evol_plots='False')
-    ds = MeshDataset([mesh_n, mesh_n], batch, seed=3)
-    data = collate(ds.samples).to(gpu_device)
-    res = {}
-    for on in (True, False):
-        monkeypatch.setattr(graph_mod, 'STRIDED_WALK', on)
-        torch.manual_seed(8)
-        model = GNN(ds, opt).to(gpu_device).train()
-        out = model(data)
-        F.mse_loss(out, data.x_phys).backward()
-        torch.cuda.synchronize()
-        g = next(iter(model._graphs.values()))
-        assert g.t_strips == (strips if on else 0)
-        res[on] = (out.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None])
-    assert torch.equal(res[True][0], res[False][0])                # the forward does not depend on the walk
-    assert len(res[True][1]) == 4
-    for a, b in zip(res[True][1], res[False][1]):
-        if b.abs().max() > 0:
-            assert rel_err(a, b)[0] <= 2e-5, rel_err(a, b)
-    monkeypatch.setattr(graph_mod, 'STRIDED_WALK', True)
-    ds64 = MeshDataset([64, 64], 2, seed=3)
-    m64 = GNN(ds64, hot_path_opt(mesh_dims=[64, 64], hidden_dim=64, num_layers=2, device=str(gpu_device), show_mesh_evol_plots='False')).to(gpu_device).train()
-    m64(collate(ds64.samples).to(gpu_device)).sum().backward()
-    assert next(iter(m64._graphs.values())).t_strips == 0

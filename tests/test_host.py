@@ -83,7 +83,7 @@ def test_every_declared_symbol_is_exported():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/gadapt_hip.h but not exported"
     assert declared == set(_native.PROTOTYPES), declared ^ set(_native.PROTOTYPES)
-    assert _native.lib().gadapt_abi_version() == 7
+    assert _native.lib().gadapt_abi_version() == 8
     # argument checks need no GPU: the gradient-exchange entry point refuses a null communicator before it looks for RCCL
     assert _native.lib().gadapt_allreduce_flat(None, None, 0, 0, None) == -1
     assert b'allreduce_flat' in _native.lib().gadapt_last_error()
@@ -392,71 +392,3 @@ def test_device_mesh_loader_fields_and_static_sink_on_cpu():
             seen_static += int(any(b is s for s in sinks.values()))
     assert set(sinks) == {4 * 49, 2 * 49}                           # one static batch per batch size (10 = 4 + 4 + 2)
     assert seen_static == 6 - 2                                     # every batch but the first of each size IS the static object
-
-
-def test_ell_cross_positions_pair_the_two_orientations():
-    """gadapt_ell_cross_host: the edge in slot k of node i's in-row and the same edge in its source's out-row point at each other."""
-    from g_adaptivity_amd import MeshDataset, collate, hot_path_opt, GNN
-    import g_adaptivity_amd.graph as graph_mod
-    ds = MeshDataset([9, 9], 3, seed=1)
-    data = collate(ds.samples)
-    ei = graph_mod.prepare_edge_index(data, 2, 9, True, False, 243)
-    g = MeshGraph(ei, 243, 'cpu')
-    assert g._xpos is not None and g.wide_backward_ws_floats == 256 * 8 * 4
-    xt, xs = g._xpos
-    et, es = g._ells['t'], g._ells['s']
-    rt, rs = g.rowptr_t.long(), g.rowptr_s.long()
-    seen = 0
-    for i in range(243):
-        for k in range(int(rt[i + 1] - rt[i])):
-            q = int(xt[8 * i + k])
-            src = int(et[8 * i + k])
-            assert q // 8 == src and int(es[q]) == i and int(xs[q]) == 8 * i + k
-            seen += 1
-        assert (xt[8 * i + int(rt[i + 1] - rt[i]):8 * i + 8] == -1).all()
-    assert seen == g.num_edges and (xt[8 * 243:] == -1).all() and (xs[8 * 243:] == -1).all()
-
-
-def test_strided_walk_qualification_and_order(monkeypatch):
-    """gadapt_tile_meta_strided_host + graph.STRIDED_WALK: on row-major meshes whose rows span 2 / 3 tiles of 64 nodes every tile
-    qualifies for the strided walk (bit 1 of its metadata word) and only boundary rows for the node-order window (bit 0); 64-node rows and rows
-    that are not a multiple of 64 leave the walk off.  The walk's place -> tile map (csrc strided_tile) is a permutation that keeps
-    a strip's rows consecutive, and every neighbour of a qualifying tile's rows lies in the slabs the kernel holds for it: one
-    place behind, the tile itself, one place ahead, each with one halo row per side."""
-    import g_adaptivity_amd.graph as graph_mod
-    from g_adaptivity_amd import MeshDataset, collate
-    monkeypatch.setattr(graph_mod, 'STRIDED_WALK', True)
-    for n, batch, strips in ((128, 2, 2), (192, 1, 3), (64, 3, 0), (100, 2, 0)):
-        ds = MeshDataset([n, n], batch, seed=0)
-        data = collate(ds.samples)
-        ei = graph_mod.prepare_edge_index(data, 2, n, True, False, batch * n * n)
-        g = MeshGraph(ei, batch * n * n, 'cpu')
-        assert g.t_strips == strips, (n, g.t_strips)
-        m = g._metas[('t', 64)].view(-1, 4)
-        if not strips:
-            assert int(((m[:, 3] >> 1) & 1).sum()) == 0
-            continue
-        n_tiles = m.shape[0]
-        # (bit 0 survives on the first and last mesh rows only: fix_boundary leaves boundary nodes without in-edges from other rows)
-        assert int(((m[:, 3] >> 1) & 1).sum()) == n_tiles and int((m[:, 3] & 1).sum()) <= 2 * strips * batch
-        t_rows = n_tiles // strips
-        place_to_tile = [(t % t_rows) * strips + t // t_rows for t in range(n_tiles)]        # strided_tile() of the kernels
-        assert sorted(place_to_tile) == list(range(n_tiles))
-        tile_to_place = {tile: t for t, tile in enumerate(place_to_tile)}
-        rp, col = g.rowptr_t.long(), g.col_t.long()
-        for tile in range(0, n_tiles, 7):                                                     # a sample of the tiles
-            t = tile_to_place[tile]
-            held = []
-            for dt_ in (-1, 0, 1):
-                if 0 <= t + dt_ < n_tiles:
-                    n0 = place_to_tile[t + dt_] * 64
-                    held.append((n0 - 1, n0 + 65))
-            nbrs = col[rp[tile * 64]:rp[tile * 64 + 64]]
-            ok = torch.zeros_like(nbrs, dtype=torch.bool)
-            for lo, hi in held:
-                ok |= (nbrs >= lo) & (nbrs < hi)
-            assert bool(ok.all()), (n, tile)
-    monkeypatch.setattr(graph_mod, 'STRIDED_WALK', False)
-    ds = MeshDataset([128, 128], 1, seed=0)
-    g = MeshGraph(graph_mod.prepare_edge_index(collate(ds.samples), 2, 128, True, False, 128 * 128), 128 * 128, 'cpu')
-    assert g.t_strips == 0

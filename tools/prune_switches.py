@@ -12,6 +12,13 @@ FIXED = {  # macro: value (None = never defined)
     'GADAPT_ABL_NO_EDGEWS': None, 'GADAPT_ABL_NO_DA': None, 'GADAPT_ABL_NO_ACCUM': None, 'GADAPT_ABL_EDGEWS_LINEAR': None,
     'GADAPT_DA_BPREFETCH': 1, 'GADAPT_SPLIT_PK': 0, 'GADAPT_MFMA_INTERLEAVE': 1, 'GADAPT_T_MFMA_PRIO': 0,
     'GADAPT_STAGGER_T': 0, 'GADAPT_STAGGER_FWD': 0, 'GADAPT_T_TWO_BUFFERS': 0,
+    # round 6: switches whose losing side has been measured at least twice (docs/measurements.md B-J)
+    'GADAPT_DIAG_G_TILE0': None, 'GADAPT_DIAG_EWS_TARGET_ORDER': None,
+    'GADAPT_T_DIFF': 1, 'GADAPT_T_STREAM': 0, 'GADAPT_S_STREAM_DXD': 0, 'GADAPT_S_ALTERNATE': 0, 'GADAPT_T_ALTERNATE': 1,
+    'GADAPT_DA_IN_SOURCE': 0, 'GADAPT_DA_F16': 0, 'GADAPT_BWD_OUT4': 1, 'GADAPT_XC_COMPACT_KERNEL': 1, 'GADAPT_XC_ONE_KSTEP': 1,
+    'GADAPT_PK_DOT': 1, 'GADAPT_GEMM_SPLIT': 1, 'GADAPT_PRESPLIT_F': 1, 'GADAPT_PRESPLIT_S': 1, 'GADAPT_PRESPLIT_T': 1,
+    'GADAPT_SPLIT_F16_S': 1, 'GADAPT_SPLIT_F16_T': 0, 'GADAPT_SPLIT_F16_WIDE': 0, 'GADAPT_FPL': 8, 'GADAPT_FWD_ONE_WAVE': 0,
+    'GADAPT_PRECISE_SOFTMAX': 1, 'GADAPT_S_STREAM': 2, 'GADAPT_DA_UNROLL': 2, 'GADAPT_S_RESIDENT_B': 1,
 }
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel register / scratch report of the hot kernels (hipcc -Rpass-analysis=kernel-resource-usage); `make resources`.
 
-    python tools/resources.py [extra hipcc flags]
+    python tools/resources.py [extra hipcc flags] [translation units, e.g. gadapt_tu_bwd_target]
 """
 import os
 import re
@@ -9,9 +9,20 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Iinclude", *sys.argv[1:], "-c", "-o", "/dev/null",
-       "g_adaptivity_amd/csrc/gadapt_kernels.hip", "-Rpass-analysis=kernel-resource-usage"]
-out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True).stderr
+UNITS = ["gadapt_tu_fwd", "gadapt_tu_bwd_target", "gadapt_tu_bwd_source", "gadapt_tu_smallmesh"]   # the hot kernels' translation units
+flags = [a for a in sys.argv[1:] if a.startswith("-")]
+units = [a for a in sys.argv[1:] if not a.startswith("-")] or UNITS
+from concurrent.futures import ThreadPoolExecutor
+
+
+def remarks(unit):
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Iinclude", "-Ig_adaptivity_amd/csrc", *flags, "-c", "-o", "/dev/null",
+           f"g_adaptivity_amd/csrc/{unit}.hip", "-Rpass-analysis=kernel-resource-usage"]
+    return subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True).stderr
+
+
+with ThreadPoolExecutor(max_workers=4) as ex:
+    out = "\n".join(ex.map(remarks, units))
 cur, rec = None, {}
 for line in out.splitlines():
     m = re.search(r"remark: (.*?) \[-Rpass", line)
