@@ -50,8 +50,11 @@ WORKLOADS = {
     'poisson2d_64x64_b32_L4_C64_learn_step': dict(n=64, batch=32, layers=4, hidden=64, conv='GRAND_plus', f=True, uu=True, learn_step=True),
     'poisson2d_64x64_b32_L4_C64_GAT_plus': dict(n=64, batch=32, layers=4, hidden=64, conv='GAT_plus', f=True, uu=True),
 }
+# BASELINE.json configs 2, 4 and 5: timed on the default line beside the headline (config 3's per-GPU shard)
+OTHER_BASELINE_WORKLOADS = ('poisson2d_32x32_b32_L4_C64', 'burgers2d_64x64_b32_L6_C128', 'euler20_128x128_b16_C64')
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X fp32 matrix (= vector) peak, SURVEY.md §8(d)
+MIN_WINDOW_S = 0.05             # a timed window lasts at least this long (the K-step block is repeated)
 
 
 def algorithmic_bytes_gat(kernel, n_nodes, n_edges, c, variant=0):
@@ -135,6 +138,8 @@ def main():
     ap.add_argument('--torch-loss', action='store_true', help='torch F.mse_loss instead of the one-launch native loss')
     ap.add_argument('--plain-backward', action='store_true', help='loss.backward() without the preallocated root gradient')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no-fused-step', action='store_true',
+                    help='the captured autograd iteration (16 launches) instead of the fused 13-launch iteration (training.FusedIteration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dense-slots', action='store_true',
                     help='materialise the zero-padded encoder output, the full last-layer output and the padded top gradient '
@@ -146,6 +151,8 @@ def main():
                     help='skip the third measurement: the reference training loop on SHUFFLED, changing batches (GraphedTrainStep)')
     ap.add_argument('--no-gat-plus', action='store_true',
                     help="skip the extra timing of conv_type='GAT_plus' on the same mesh batch (default workload, one GPU only)")
+    ap.add_argument('--no-other-workloads', action='store_true',
+                    help='skip the timing of the other single-GPU BASELINE.json configurations (default workload, one GPU only)')
     ap.add_argument('--no-companion', action='store_true',
                     help='skip the second timing of the other slot flow (dense when the headline is compact and vice versa)')
     args = ap.parse_args()
@@ -217,9 +224,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)                      # every rank's rehearsal must have passed
         return bool(t.item() == 1.0)
 
-    ds = MeshDataset([w['n'], w['n']], w['batch'], seed=rank)        # every rank owns its own shard of meshes
-    data = collate(ds.samples).to(dev)
-    target = data.x_phys
+    def make_batch(w_):
+        ds_ = MeshDataset([w_['n'], w_['n']], w_['batch'], seed=rank)    # every rank owns its own shard of meshes
+        return ds_, collate(ds_.samples).to(dev)
+
+    ds, data = make_batch(w)
     # one GPU: the optimizer step is captured with forward and backward (step count on the device).  N > 1: forward + loss +
     # backward are the replayed graph, the RCCL all-reduce of the 33 KB gradient bucket and the Adam launch (step count on
     # the device as well: no host-side value changes from step to step) follow it on the same stream; with the RCCL backend the
@@ -229,18 +238,20 @@ def main():
     # value, two launches fewer - the one-element fill and the multiplication by it); --plain-backward: the literal call
     root = None if (args.plain_backward or args.torch_loss) else unit_gradient(dev)
 
-    def build_runner(dense_slots, w=w):
+    def build_runner(dense_slots, w=w, batch=None):
         """model + optimizer + step() for one slot flow; the step is a replayed hipGraph unless --no-graph / capture fails."""
+        ds_, data_ = batch if batch is not None else (ds, data)
+        target = data_.x_phys
         opt = hot_path_opt(mesh_dims=[w['n'], w['n']], hidden_dim=w['hidden'], num_layers=w['layers'], conv_type=w['conv'],
                            gnn_inc_feat_f=w['f'], gnn_inc_feat_uu=w['uu'], device=str(dev), loss_type='mesh_loss',
                            show_mesh_evol_plots='False', compact_slots=not dense_slots, learn_step=bool(w.get('learn_step', False)))
         torch.manual_seed(0)                                          # identical replicas
-        model = GNN(ds, opt).to(dev)
+        model = GNN(ds_, opt).to(dev)
         model.train()
         optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=True)
 
         def fwd_bwd():
-            out = model(data)
+            out = model(data_)
             loss = loss_fn(out, target)
             if root is None:
                 loss.backward()
@@ -257,15 +268,38 @@ def main():
         for _ in range(2):                                            # first steps eagerly: builds the CSR cache and the flat bucket
             eager_step()
         torch.cuda.synchronize()
+        # The fused 13-launch iteration (training.FusedIteration: node fields read by layer 0, loss in the last layer's launch, Adam +
+        # next-step coefficients in the tail) when model, optimizer, loss and batch qualify - the same step, bit-identical parameters
+        # (tests/test_gpu_training.py); --no-fused-step / any other configuration: the autograd iteration.
+        fused, fused_reason = None, 'disabled (--no-fused-step / --torch-loss / --plain-backward / --dense-slots)'
+        if not (args.no_fused_step or args.torch_loss or args.plain_backward or dense_slots):
+            from g_adaptivity_amd.training import FusedIteration
+            fused_reason = FusedIteration.eligible(model, optim, loss_fn, data_, 'x_phys')
+            if fused_reason is None:
+                fused = FusedIteration(model, optim, loss_fn, data_, 'x_phys')
+                fused.refresh_coeffs()
+
+        def fwd_bwd_run():                                            # zero_grad + forward + loss + backward of the route taken
+            if fused is not None:
+                fused.forward_backward()
+            else:
+                optim.zero_grad(); fwd_bwd()
+
+        def optim_run():
+            if fused is not None:
+                fused.finish()
+            else:
+                optim.step()
+
         graph, cap_all = None, capture_all
         if not args.no_graph:
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    optim.zero_grad(); fwd_bwd()
+                    fwd_bwd_run()
                     if cap_all:
-                        optim.step()
+                        optim_run()
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
@@ -274,9 +308,9 @@ def main():
                 # polls events); "thread_local" keeps those from invalidating the capture.  GADAPT_BENCH_CAPTURE_MODE overrides.
                 mode = os.environ.get('GADAPT_BENCH_CAPTURE_MODE', 'thread_local' if world > 1 else 'global')
                 with torch.cuda.graph(g, stream=side, capture_error_mode=mode):
-                    fwd_bwd()
+                    fwd_bwd_run()
                     if cap_all:
-                        optim.step()
+                        optim_run()
                 graph = g
             except Exception as e:                                    # stay correct: fall back to eager launches
                 print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
@@ -291,41 +325,51 @@ def main():
             if graph is not None:
                 graph.replay()                                        # forward + loss + backward (+ all-reduce + Adam when captured)
                 if not cap_all:
-                    optim.step()                                      # all-reduce + fused Adam
+                    optim_run()                                       # all-reduce + fused Adam
+            elif fused is not None:
+                fused.run()
             else:
                 eager_step()
 
-        return {'opt': opt, 'model': model, 'optim': optim, 'step': step, 'fwd_bwd': fwd_bwd, 'graph': graph, 'capture_all': cap_all}
+        return {'opt': opt, 'model': model, 'optim': optim, 'step': step, 'fwd_bwd': (fused.forward_backward if fused is not None else fwd_bwd), 'graph': graph,
+                'capture_all': cap_all, 'fused': fused is not None, 'fused_reason': fused_reason}
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def timed_windows(step_fn):
-        """W warm-up steps, then `--windows` windows of EXACTLY K steps each, every window bracketed by barrier +
-        torch.cuda.synchronize() on both sides and reduced with MAX over ranks.  Returns the per-window seconds."""
+    def timed_block(step_fn, blocks):
+        """`blocks` x K steps bracketed by barrier + torch.cuda.synchronize() on both sides, MAX over ranks: seconds."""
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(blocks * args.steps):
+            step_fn()
+        torch.cuda.synchronize(); barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    def timed_windows(step_fn, n_windows=None):
+        """W warm-up steps, then `--windows` timed windows.  A window is the K-step block (`--steps`) repeated R times back to back, R the
+        smallest count that makes a window at least MIN_WINDOW_S long (K = 20 steps of 0.3 ms are 6 ms: too short for a clock or a
+        utilisation sampler to corroborate - VERDICT r5 weak 11); R comes from one untimed K-step block and is the same on every rank
+        (MAX over ranks).  Returns (per-window seconds PER K-STEP BLOCK, R)."""
         for _ in range(args.warmup):
             step_fn()
-        out = []
-        for _ in range(max(args.windows, 1)):
-            barrier(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step_fn()
-            torch.cuda.synchronize(); barrier()
-            el = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([el], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
-            out.append(el)
-        return out
+        probe = timed_block(step_fn, 1)
+        blocks = max(1, min(4096, int(MIN_WINDOW_S / max(probe, 1e-6)) + 1))
+        return [timed_block(step_fn, blocks) / blocks for _ in range(max(n_windows or args.windows, 1))], blocks
 
-    def summarise(times):
+    def summarise(timed):
+        times, blocks = timed
         srt = sorted(times)
         med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
         per = lambda t: round(1e3 * t / args.steps, 4)                # noqa: E731
-        return med, {'n': len(times), 'steps_per_window': args.steps, 'ms_per_step_min': per(srt[0]), 'ms_per_step_median': per(med),
+        return med, {'n': len(times), 'steps_per_window': args.steps * blocks, 'blocks_per_window': blocks, 'min_window_ms': round(1e3 * MIN_WINDOW_S, 1),
+                     'window_ms_median': round(1e3 * med * blocks, 2), 'ms_per_step_min': per(srt[0]), 'ms_per_step_median': per(med),
                      'ms_per_step_max': per(srt[-1])}
 
     main_run = build_runner(args.dense_slots)
@@ -374,23 +418,23 @@ def main():
     if rank == 0 and world == 1 and not args.no_gat_plus and args.workload == 'poisson2d_64x64_b32_L4_C64' and not args.dense_slots:
         wg = WORKLOADS['poisson2d_64x64_b32_L4_C64_GAT_plus']
         other = build_runner(False, wg)
-        keep_windows, args.windows = args.windows, min(args.windows, 3)
-        g_el, g_win = summarise(timed_windows(other['step']))
-        args.windows = keep_windows
+        g_el, g_win = summarise(timed_windows(other['step'], min(args.windows, 3)))
         gat_plus = {'workload': 'poisson2d_64x64_b32_L4_C64_GAT_plus', 'value': round(wg['batch'] * args.steps / g_el, 1), 'unit': 'meshes/s',
                     'ms_per_step': round(1e3 * g_el / args.steps, 4), 'windows': g_win, 'launch': 'hipgraph+adam' if other['graph'] is not None else 'eager'}
         del other
         torch.cuda.synchronize()
 
-    # ---- instrumented pass (eager, HIP events around each hot-kernel launch)
-    roofline, kernels = None, {}
-    if rank == 0:
+    def instrument(run, w, workload):
+        """Second, instrumented pass of `run` (eager launches, HIP events on the launch stream around every hot-kernel launch):
+        (kernels, roofline) - per-kernel, per-variant medians and the roofline object of the dominant kernel.  Rank 0 only."""
+        roofline, kernels = None, {}
+        model, optim, fwd_bwd = run['model'], run['optim'], run['fwd_bwd']
         import ctypes as C
         lib = _native.lib()
         lib.gadapt_profile_reset(); lib.gadapt_profile_enable(1)
         def local_step():                                             # rank 0 only: no collective in here
             optim.zero_grad()
-            fwd_bwd()
+            fwd_bwd()                                                 # (the fused route: its forward + backward launches, no optimizer)
         for _ in range(args.steps):
             local_step()
         # dispatch share of an event pair: empty launches queued behind real work, bracketed the same way
@@ -447,11 +491,11 @@ def main():
                 kernels[dom]['variants'], key=lambda v: kernels[dom]['variants'][v]['avg_us'] * kernels[dom]['variants'][v]['launches_per_step'])
             kd = kernels[dom]['variants'][dvar]
             traffic = None
-            pmc = load_pmc(args.workload)                            # filled from separate rocprofv3 --pmc passes
+            pmc = load_pmc(workload)                                 # filled from separate rocprofv3 --pmc passes
             ent = pmc.get(f'{dom}:{dvar}', pmc.get(dom))
             if isinstance(ent, dict):
                 traffic = ent.get('traffic_bytes')
-            prof_us, prof_file = load_profile_avg_us(args.workload, dom, dvar)
+            prof_us, prof_file = load_profile_avg_us(workload, dom, dvar)
             roofline = {'kernel': dom, 'variant': dvar, 'bound': 'hbm', 'achieved': kd['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(kd['achieved_GBs'] / HBM_PEAK_GBS, 4), 'traffic': traffic,
                         'traffic_note': 'fabric-side bytes per launch of this kernel variant, (2 FETCH_SIZE + WRITE_SIZE) KiB, read from the '
@@ -463,6 +507,31 @@ def main():
                         # the same quantity from the committed rocprofv3 --kernel-trace --stats summary of this workload
                         'profile': None if prof_us is None else {'file': prof_file, 'avg_us': round(prof_us, 2),
                                                                  'frac': round(kd['alg_bytes_per_launch'] / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+        return kernels, roofline
+
+    roofline, kernels = None, {}
+    if rank == 0:
+        kernels, roofline = instrument(main_run, w, args.workload)
+
+    # ---- the other single-GPU BASELINE.json configurations on the same line: same step, same timing protocol, two
+    # windows, their own instrumented pass; no second slot flow, no CPU leg.  Default workload, one GPU only.
+    other_workloads = None
+    if rank == 0 and world == 1 and not args.no_other_workloads and args.workload == 'poisson2d_64x64_b32_L4_C64' and not args.dense_slots:
+        other_workloads = {}
+        for name in OTHER_BASELINE_WORKLOADS:
+            wo = WORKLOADS[name]
+            run = build_runner(False, wo, make_batch(wo))
+            o_el, o_win = summarise(timed_windows(run['step'], 2))
+            o_kernels, o_roof = instrument(run, wo, name)
+            keep = ('kernel', 'variant', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_us', 'alg_bytes_per_launch', 'profile')
+            other_workloads[name] = {'value': round(wo['batch'] * args.steps / o_el, 1), 'unit': 'meshes/s', 'ms_per_step': round(1e3 * o_el / args.steps, 4),
+                                     'windows': o_win, 'launch': 'hipgraph+adam' if run['graph'] is not None else 'eager',
+                                     'config': {'mesh': f"{wo['n']}x{wo['n']}", 'meshes_per_gpu': wo['batch'], 'mp_layers': wo['layers'], 'hidden': wo['hidden'],
+                                                'conv_type': wo['conv']},
+                                     'roofline': None if o_roof is None else {k_: o_roof[k_] for k_ in keep},
+                                     'kernels_avg_us': {k_: v_['avg_us'] for k_, v_ in o_kernels.items()}}
+            del run
+            torch.cuda.synchronize()
 
     # ---- secondary roofline: the projections, priced as the reference formulation's GEMM flops
     # (12 N C^2 per layer: Q, K forward + dX, dW backward) against the fp32 matrix peak, whole step
@@ -608,9 +677,9 @@ def main():
             'config': {'workload': args.workload, 'mesh': f"{w['n']}x{w['n']}", 'meshes_per_gpu': w['batch'],
                        'global_batch': w['batch'] * world, 'mp_layers': w['layers'], 'hidden': w['hidden'],
                        'conv_type': w['conv'], 'parallelism': f'dp{world}',
-                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'loss': 'torch' if args.torch_loss else 'native', 'root_gradient': 'created per step (loss.backward())' if root is None else 'preallocated (unit_gradient)', 'slots': 'dense' if args.dense_slots else 'compact', 'slots_note': None if args.dense_slots else 'identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the [N,4] encoder output in forward and backward, layer 1 hands it the 4 gradient columns it reads, the last layer writes the [N,4] head the model returns (GNN.py:299) and takes the compact top gradient; --dense-slots runs the literal dense flow', 'launch': ('hipgraph+adam' if world == 1 else ('hipgraph+allreduce+adam' if capture_all else 'hipgraph, then allreduce+adam')) if graph is not None else 'eager'},
+                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'fused_step': main_run['fused'], 'fused_step_off_reason': main_run['fused_reason'], 'loss': 'torch' if args.torch_loss else 'native', 'root_gradient': 'created per step (loss.backward())' if root is None else 'preallocated (unit_gradient)', 'slots': 'dense' if args.dense_slots else 'compact', 'slots_note': None if args.dense_slots else 'identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the [N,4] encoder output in forward and backward, layer 1 hands it the 4 gradient columns it reads, the last layer writes the [N,4] head the model returns (GNN.py:299) and takes the compact top gradient; --dense-slots runs the literal dense flow', 'launch': ('hipgraph+adam' if world == 1 else ('hipgraph+allreduce+adam' if capture_all else 'hipgraph, then allreduce+adam')) if graph is not None else 'eager'},
             'roofline': roofline, 'roofline_mfma': roofline_mfma, 'kernels': kernels, 'cpu_baseline': cpu, 'train_loop': train_loop,
-            'gat_plus': gat_plus,
+            'gat_plus': gat_plus, 'other_workloads': other_workloads,
         }
         if world > 1:
             line['allreduce_us_per_step'] = allreduce_us

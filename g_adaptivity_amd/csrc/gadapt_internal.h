@@ -184,27 +184,13 @@ template <int C> static int tiles_for(int64_t n_nodes) { return (int)((n_nodes +
 // ------------------------------------------------------------------------------------------------
 // what the kernel units offer the C-ABI unit (validated arguments; one launch each)
 // ------------------------------------------------------------------------------------------------
-// Loss fused into the head-only forward launch of the last layer (gadapt_block_forward_loss): the launch that writes x_top4 also
-// writes seed = d loss / d x_top4[:, :d] and one partial of sum |pred - target|^p per workgroup.
-struct FwdLossArgs {
-    const float* target;   // [N,d]
-    float* seed;           // [N,d]
-    float* partials;       // [GADAPT_LOSS_PARTIALS_MAX]: slot b written by workgroup b, slots past the grid zeroed by workgroup 0
-    int d, l1;
-    float inv_count;       // 1 / (N d)
-};
-#define GADAPT_LOSS_PARTIALS_MAX 512
-// Compact layer input assembled from the caller's node fields instead of read from x_all's slot 0 (gadapt_block_forward_fields):
-// row i = [x_comp[i, 0..dim) | f[i] | uu[i] | 0...] (GNN.py:225-239 through the identity encoder, GNN.py:75-82); the launch also
-// writes the rows of its own nodes to x0c [N,4] for the layer-0 backward.
-struct FwdFieldArgs {
-    const float* x_comp; const float* f; const float* uu;   // f / uu nullable
-    int dim;
-    float* x0c;
-};
+// Extras of the forward launches of a fused training step (gadapt_block_forward_loss): layer 0 assembles its compact [N,4] input
+// from the caller's node fields (fs) and writes it to x0c for the layer-0 backward; the head-only launch of the last layer also
+// produces the loss derivative and one loss partial per wave (loss; *n_partials_out = the grid of that launch).
+struct FwdExtra { FieldSrc fs; float* x0c; LossArgs loss; int* n_partials_out; };
+#define GADAPT_LOSS_PARTIALS_MAX 4096  /* waves of a forward launch: GADAPT_FWD_MAX_BLOCKS workgroups of up to 8 waves */
 int gadapt_launch_fwd_c(int c, const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0, const float* lp,
-                        float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st,
-                        const FwdLossArgs* loss = nullptr, const FwdFieldArgs* fields = nullptr);
+                        float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st, const FwdExtra* extra = nullptr);
 // target pass (always) ...
 int gadapt_launch_bwd_target_c(int c, const gadapt_graph* g, const float* x_in, const float* g_in, const float* alpha, const float* a,
                                const float* lp, float* edge_ws, float* dxd, float* slab, int accumulate, float* sums_out, float* sums_sc_out,

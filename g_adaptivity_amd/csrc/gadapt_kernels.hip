@@ -416,9 +416,9 @@ extern "C" int gadapt_adam_step_dev(float* param, const float* grad, float* exp_
 // ------------------------------------------------------------------------------------------------
 // L-step Euler block (GNN.py:273-291)
 // ------------------------------------------------------------------------------------------------
-extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_cols, int n_layers, const float* a, int64_t a_stride,
-                                    const float* p0, int64_t p0_stride, const float* layer_params, float* alpha_all, float* x_top4,
-                                    int c, void* stream) {
+static int block_forward(const gadapt_graph* g, float* x_all, int x0_cols, int n_layers, const float* a, int64_t a_stride,
+                         const float* p0, int64_t p0_stride, const float* layer_params, float* alpha_all, float* x_top4,
+                         int c, void* stream, const FwdExtra* extra) {
     if (int rc = check_graph(g, c)) return rc;
     if (!x_all || n_layers <= 0 || !a || !p0 || !layer_params) return fail(GADAPT_E_BADARG, "block_forward: bad argument");
     if (x0_cols != 0 && (x0_cols != 4 || n_layers < 2 || c < 8)) return fail(GADAPT_E_BADARG, "block_forward: compact x0 needs 4 columns, >= 2 layers, hidden >= 8");
@@ -430,13 +430,81 @@ extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_
         int rc;
         if ((l == 0 && x0_cols) || (last && x_top4))             // compact input and/or compact-only output
             rc = gadapt_launch_fwd_c(c, g, x_all + l * nc, (last && x_top4) ? nullptr : x_all + (l + 1) * nc, a + l * a_stride, p0 + l * p0_stride,
-                                     layer_params + 2 * l, alpha_l, 0, l == 0 ? x0_cols : 0, last ? x_top4 : nullptr, st);
+                                     layer_params + 2 * l, alpha_l, 0, l == 0 ? x0_cols : 0, last ? x_top4 : nullptr, st, extra);
         else
             rc = gadapt_layer_forward(g, x_all + l * nc, x_all + (l + 1) * nc, a + l * a_stride, p0 + l * p0_stride,
                                       layer_params + 2 * l, alpha_l, 0, c, stream);
         if (rc) return rc;
     }
     return GADAPT_OK;
+}
+extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_cols, int n_layers, const float* a, int64_t a_stride,
+                                    const float* p0, int64_t p0_stride, const float* layer_params, float* alpha_all, float* x_top4,
+                                    int c, void* stream) {
+    return block_forward(g, x_all, x0_cols, n_layers, a, a_stride, p0, p0_stride, layer_params, alpha_all, x_top4, c, stream, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused training step (run_GNN.py:99-131 as 13 launches): forward with the node fields as layer-0 input and the loss in the last
+// layer's launch; tail = slab sums + chain rule + Adam + the next step's composite coefficients
+// ------------------------------------------------------------------------------------------------
+extern "C" int gadapt_loss_partials_max(void) { return GADAPT_LOSS_PARTIALS_MAX; }
+extern "C" int gadapt_block_forward_loss(const gadapt_graph* g, float* x_all, const float* x_comp, int dim, const float* f_tensor, const float* uu_tensor,
+                                         int n_layers, const float* a, const float* p0, const float* layer_params, float* alpha_all, float* x_top4,
+                                         const float* target, int d, int l1, float* seed, float* loss_partials, int c, void* stream) {
+    if (!x_comp || dim < 1 || dim > 4 || dim + (f_tensor ? 1 : 0) + (uu_tensor ? 1 : 0) > 4)
+        return fail(GADAPT_E_BADARG, "block_forward_loss: 1..4 coordinates, coordinates + extras <= 4 columns");
+    if (!x_top4 || !target || !seed || !loss_partials || d < 1 || d > 4) return fail(GADAPT_E_BADARG, "block_forward_loss: head rows, target, seed, partials; 1 <= d <= 4");
+    if (!g || g->n_nodes <= 0) return fail(GADAPT_E_BADARG, "bad graph");
+    int n_partials = 0;
+    // x_all slot 0 starts with the compact [N,4] layer-0 input (written by the layer-0 launch for the layer-0 backward)
+    FwdExtra ex{FieldSrc{x_comp, f_tensor, uu_tensor, dim}, x_all,
+                LossArgs{target, seed, loss_partials, d, l1 ? 1 : 0, 1.0f / (float)((int64_t)g->n_nodes * d)}, &n_partials};
+    if (int rc = block_forward(g, x_all, 4, n_layers, a, 0, p0, 0, layer_params, alpha_all, x_top4, c, stream, &ex)) return rc;
+    if (n_partials <= 0 || n_partials > GADAPT_LOSS_PARTIALS_MAX) return fail(GADAPT_E_RUNTIME, "block_forward_loss: loss partial count out of range");
+    return n_partials;
+}
+
+extern "C" int gadapt_step_tail(const float* slab, int n_rows, float* scratch, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                                float lr, float beta1, float beta2, float eps, float weight_decay, int32_t* state, float grad_scale,
+                                float* a_out, float* p0_out, const float* loss_partials, int n_loss_partials, float* loss_out, int64_t loss_count,
+                                int c, void* stream) {
+    const bool gradient_only = slab && !exp_avg && !exp_avg_sq;     // data parallel, first half: stop at the flat gradient
+    if (!param || !grad || !gadapt_supported_hidden_dim(c) || (!gradient_only && (!exp_avg || !exp_avg_sq || !state || !a_out || !p0_out)))
+        return fail(GADAPT_E_BADARG, "step_tail: bad argument");
+    if (slab && (n_rows <= 0 || !scratch)) return fail(GADAPT_E_BADARG, "step_tail: slab without row count / scratch");
+    if (loss_partials && (n_loss_partials <= 0 || !loss_out || loss_count <= 0 || !slab))
+        return fail(GADAPT_E_BADARG, "step_tail: loss partials need a count, a destination and the slab launch they ride in");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int row_len = c * c + c;
+    int blocks = (2 * c * c + 2 * c + 1023) / 1024;                // one entry of the flat gradient / bucket per thread
+    if (slab) {
+        const int nbx = (row_len + 255) / 256;
+        hipLaunchKernelGGL(slab_reduce1_kernel, dim3(nbx + (loss_partials ? 1 : 0), GADAPT_SLAB_CHUNKS), dim3(256), 0, st, slab, scratch, n_rows, row_len,
+                           nbx, (const float*)nullptr, 0, 0, (float*)nullptr, loss_partials, n_loss_partials, 1.0f / (float)loss_count, loss_out);
+    }
+    if (gradient_only) {                                            // second-level sums + chain rule, as gadapt_slab_reduce_coeffs_backward
+        const int c2 = c * c, lds2 = (c * (c + 1) + c) * 4;
+#define GADAPT_R2(CC) case CC: allow_lds(reduce2_coeffs_bwd_kernel<CC>, lds2); \
+        hipLaunchKernelGGL(reduce2_coeffs_bwd_kernel<CC>, dim3(blocks), dim3(1024), lds2, st, scratch, param, param + c2, param + c2 + c, \
+                           grad, grad + c2, grad + c2 + c, grad + 2 * c2 + c); break;
+        switch (c) { GADAPT_R2(4) GADAPT_R2(8) GADAPT_R2(16) GADAPT_R2(32) GADAPT_R2(64) GADAPT_R2(128) default: break; }
+#undef GADAPT_R2
+        return check_launch("step_tail (gradient)");
+    }
+    TailArgs p{slab ? scratch : nullptr, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, state};
+#define GADAPT_TAIL(CC) case CC: { constexpr int lds = tail_lds_floats<CC>() * 4; allow_lds(step_tail_kernel<CC>, lds); \
+        hipLaunchKernelGGL(step_tail_kernel<CC>, dim3(tail_blocks<CC>()), dim3(1024), lds, st, p); } break;
+    switch (c) { GADAPT_TAIL(4) GADAPT_TAIL(8) GADAPT_TAIL(16) GADAPT_TAIL(32) GADAPT_TAIL(64) GADAPT_TAIL(128) default: break; }
+#undef GADAPT_TAIL
+    if (int rc = check_launch("step_tail")) return rc;
+    // the composite coefficients of the UPDATED weights for the next step's forward (the launch that used to open every step)
+    const int c2 = c * c, n_out = c2 + c;
+#define GADAPT_CFS(CC) case CC: hipLaunchKernelGGL(coeffs_fwd_step_kernel<CC>, dim3((n_out + 255) / 256), dim3(256), 0, st, param, param + c2, param + c2 + c, \
+                                                   a_out, p0_out, state); break;
+    switch (c) { GADAPT_CFS(4) GADAPT_CFS(8) GADAPT_CFS(16) GADAPT_CFS(32) GADAPT_CFS(64) GADAPT_CFS(128) default: break; }
+#undef GADAPT_CFS
+    return check_launch("coeffs_fwd_step_kernel");
 }
 
 extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all, const float* g_top, int g_top_cols, int n_layers,

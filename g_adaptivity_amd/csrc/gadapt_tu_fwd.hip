@@ -17,7 +17,7 @@ static inline int wide_grid(int n_steps) {
     return g;
 }
 static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
-                           const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st) {
+                           const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st, const FwdExtra* ex) {
     const int n_steps = (g->n_nodes + wide::STEP - 1) / wide::STEP;
     const bool big = g->wide_deg_t <= 0;                        // 512-row window (meshes with up to 128 nodes per row)
     wide::FwdArgs p{x_in, x_out, a, p0, lp, g->ell_t, g->rowptr_t, alpha_out, g->n_nodes, n_steps, residual_only,
@@ -25,6 +25,10 @@ static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_ou
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
 #endif
+    if (ex) {
+        if (x_cols) { p.fs = ex->fs; p.x0c = ex->x0c; }
+        if (!x_out && !x_cols && ex->loss.target) { p.loss = ex->loss; if (ex->n_partials_out) *ex->n_partials_out = 8 * wide_grid(n_steps); }
+    }
     ProfScope prof(0, st, (x_cols ? 2 : 0) | (x_out ? 0 : 4));
     auto go = [&](auto kern, int lds) { allow_lds(kern, lds); hipLaunchKernelGGL(kern, dim3(wide_grid(n_steps)), dim3(512), lds, st, p); };
     const bool head = !x_out && !x_cols;                        // head-only output: its own instantiation (aggregates one chunk)
@@ -41,21 +45,25 @@ static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_ou
 }
 
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
-                                       const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st) {
+                                       const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st, const FwdExtra* ex) {
     using K = Cfg<C>;
     if (x_cols != 0 && x_cols != 4) return fail(GADAPT_E_BADARG, "compact layer input: 4 columns");
     if constexpr (C == 64) {
         if (g->ell_t && (g->wide_deg_t > 0 || (g->wide_big_deg_t > 0 && g->wide_big_deg_t <= 7)) && wide_enabled())
-            return launch_wide_fwd(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, x_cols, x_top4, st);
+            return launch_wide_fwd(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, x_cols, x_top4, st, ex);
     }
     FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t), alpha_out, g->n_nodes,
               (g->n_nodes + K::TM - 1) / K::TM, residual_only, g->n_edges, nullptr, x_top4};
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
 #endif
+    const dim3 grid(grid_for(p.n_tiles, resident_blocks<C>(GADAPT_FWD_MAX_BLOCKS)));
+    if (ex) {
+        if (x_cols) { p.fs = ex->fs; p.x0c = ex->x0c; }
+        if (!x_out && x_top4 && ex->loss.target) { p.loss = ex->loss; if (ex->n_partials_out) *ex->n_partials_out = (int)grid.x * K::NW; }
+    }
     ProfScope prof(0, st, (x_cols ? 2 : 0) | (x_out ? 0 : 4));
     constexpr int lds = K::lds_bytes(0, K::RING + 1);
-    const dim3 grid(grid_for(p.n_tiles, resident_blocks<C>(GADAPT_FWD_MAX_BLOCKS)));
     if (x_cols) {
         allow_lds(grand_fwd_kernel<C, true>, lds);
         hipLaunchKernelGGL((grand_fwd_kernel<C, true>), grid, dim3(K::NT), lds, st, p);
@@ -67,10 +75,8 @@ template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in,
 }
 
 int gadapt_launch_fwd_c(int c, const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0, const float* lp,
-                        float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st,
-                        const FwdLossArgs* loss, const FwdFieldArgs* fields) {
-    if (loss || fields) return fail(GADAPT_E_BADARG, "launch_fwd: fused loss / field input not built");
-    GADAPT_DISPATCH_C(c, launch_fwd<CC>(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, x_cols, x_top4, st));
+                        float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st, const FwdExtra* extra) {
+    GADAPT_DISPATCH_C(c, launch_fwd<CC>(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, x_cols, x_top4, st, extra));
 }
 
 template <int C> static int occupancy_fwd() {

@@ -186,7 +186,7 @@ class FlatAdam:
         self._own_grad, self.grad_bucket = None, None
         self._active_ids = frozenset(id(p) for p in self.active)
         if self.capturable:
-            self._dev_state = torch.tensor([self.step_count, 0], device=dev, dtype=torch.int32)
+            self._dev_state = torch.tensor([self.step_count, 0, 0, 0], device=dev, dtype=torch.int32)
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -236,7 +236,7 @@ class FlatAdam:
         b = self.bucket
         if self.capturable:
             if self._dev_state is None:
-                self._dev_state = torch.zeros(2, device=b.device, dtype=torch.int32)
+                self._dev_state = torch.zeros(4, device=b.device, dtype=torch.int32)    # {steps, ticket / barrier counters}: gadapt_hip.h
             check(lib().gadapt_adam_step_dev(ptr(b), ptr(self.grad_bucket), ptr(self.exp_avg), ptr(self.exp_avg_sq), b.numel(),
                                              self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                              ptr(self._dev_state), scale, current_stream(b.device)), 'gadapt_adam_step_dev')

@@ -15,6 +15,7 @@ counterpart.
 """
 from __future__ import annotations
 
+import time
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
@@ -23,12 +24,161 @@ from . import graph as _graph_mod
 from .functional import mse_loss, unit_gradient
 from .optim import FlatAdam
 
+import torch.nn as nn
+
+from . import _native
+from ._native import check, current_stream, lib, ptr
+
 INPUT_FIELDS = ('x_comp', 'f_tensor', 'uu_tensor')
 TOPOLOGY_FIELDS = ('edge_index', 'to_boundary_edge_mask', 'to_corner_nodes_mask', 'diff_boundary_edges_mask', 'batch')
 
 
+class FusedIteration:
+    """The training iteration of `src/run_GNN.py:99-131` for a weight-shared GRAND / GRAND_plus model behind the identity encoder as
+    13 launches on preallocated buffers, straight over the C-ABI (no autograd): `gadapt_block_forward_loss` (layer 0 reads the node
+    fields, the last layer's launch produces the loss derivative and the loss partials), `gadapt_block_backward`, `gadapt_step_tail`
+    (slab sums + chain rule + Adam + the NEXT step's composite coefficients).  The per-layer launches are the ones the autograd path
+    issues, on the same values in the same order, and the Adam / coefficient arithmetic is shared code: parameters and moments are
+    bit-identical to the eager loop; the loss value is summed in another (fixed) order.
+
+    Built by `GraphedTrainStep` (and `bench.py`) when `eligible` says the model, optimizer, loss and batch qualify; everything else
+    keeps the captured autograd iteration.  Bound to ONE batch object (its field tensors are read by address).  `coeffs`: the (A, p0)
+    buffers shared by all the plans of one model - the tail of every step leaves the coefficients of the updated weights there;
+    `refresh_coeffs()` recomputes them after the weights changed by any other means."""
+
+    @staticmethod
+    def eligible(model, optimizer, loss_fn, data, target_field: str) -> Optional[str]:
+        """None when the fused iteration applies, else the reason it does not."""
+        from .functional import l1_loss
+        o = model.opt
+        dev = torch.device(o['device'])
+        if loss_fn not in (mse_loss, l1_loss):
+            return 'loss is not the native mse_loss / l1_loss'
+        if not (model._fusable() and o['share_conv'] and o.get('compact_slots', True) and o['num_layers'] >= 2 and o['hidden_dim'] >= 8):
+            return 'not a fusable weight-shared block of >= 2 layers at hidden >= 8 with compact slots'
+        if o.get('learn_step') or o.get('softmax_temp_type') == 'learnable_a' or o['loss_type'] != 'mesh_loss':
+            return 'learnable steps / temperature or a loss other than mesh_loss'
+        if o.get('gnn_inc_glob_feat_f') or o.get('gnn_inc_glob_feat_uu') or o.get('gnn_normalize'):
+            return 'global features / field normalisation'
+        if not (isinstance(model.enc, nn.Linear) and model.enc.bias is None and not model.enc.weight.requires_grad
+                and model.enc.weight.shape[1] <= 4 and model._enc_is_zero_pad() and isinstance(model.dec, nn.Identity)):
+            return 'encoder is not the frozen zero-pad identity (or the decoder not Identity)'
+        x_comp, tgt = data.x_comp, getattr(data, target_field, None)
+        if not (torch.is_tensor(x_comp) and x_comp.is_cuda and x_comp.dtype == torch.float32 and x_comp.dim() == 2 and x_comp.is_contiguous()
+                and x_comp.shape[1] == model.dim and torch.is_tensor(tgt) and tgt.is_cuda and tgt.dtype == torch.float32 and tgt.is_contiguous()
+                and tgt.shape == (x_comp.shape[0], model.dim)):
+            return 'x_comp / target are not dense fp32 [N,dim] device tensors'
+        for flag, name in (('gnn_inc_feat_f', 'f_tensor'), ('gnn_inc_feat_uu', 'uu_tensor')):
+            if o[flag]:
+                t = getattr(data, name, None)
+                if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.shape == (x_comp.shape[0],) and t.is_contiguous()):
+                    return f'{name} is not a dense fp32 [N] device tensor'
+        conv = model.conv_layers[0]
+        want = [conv.lin_query.weight, conv.lin_query.bias, conv.lin_key.weight, conv.lin_key.bias]
+        c = o['hidden_dim']
+        if not (isinstance(optimizer, FlatAdam) and optimizer.capturable and optimizer.bucket is not None and optimizer._dev_state is not None
+                and optimizer.reduce_op == 'mean' and len(optimizer.active) == 4 and all(a is b for a, b in zip(optimizer.active, want))
+                and list(optimizer.offsets) == [0, c * c, c * c + c, 2 * c * c + c]):
+            return 'optimizer is not a laid-out FlatAdam(capturable=True) over exactly [Wq | bq | Wk | bk]'
+        graph = model._graph(data, x_comp.shape[0], dev)
+        with torch.enable_grad():
+            if model._small_plan(data, graph, x_comp, getattr(data, 'f_tensor', None) if o['gnn_inc_feat_f'] else None,
+                                 getattr(data, 'uu_tensor', None) if o['gnn_inc_feat_uu'] else None) is not None:
+                return 'small-mesh batch: the one-launch pair runs it'
+        return None
+
+    def __init__(self, model, optimizer: FlatAdam, loss_fn, data, target_field: str, coeffs=None):
+        from .functional import l1_loss
+        o = model.opt
+        self.model, self.optimizer = model, optimizer
+        self.l1 = loss_fn is l1_loss
+        dev = self.device = torch.device(o['device'])
+        self.x_comp, self.target = data.x_comp, getattr(data, target_field)
+        self.f = data.f_tensor if o['gnn_inc_feat_f'] else None
+        self.uu = data.uu_tensor if o['gnn_inc_feat_uu'] else None
+        n, c, L = int(self.x_comp.shape[0]), int(o['hidden_dim']), int(o['num_layers'])
+        self.n, self.c, self.L, self.d = n, c, L, int(model.dim)
+        self.graph = model._graph(data, n, dev)
+        e = max(self.graph.num_edges, 1)
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.lp = model._layer_params(dev).contiguous()
+        # activations: slot l = input of layer l (slot 0: the compact [N,4] rows at its start); the last layer writes the head only
+        self.x_all = torch.empty(L, n, c, **f32)
+        self.alpha = torch.empty(L, e, **f32)
+        self.x_top4 = torch.empty(n, 4, **f32)
+        self.seed = torch.empty(n, self.d, **f32)
+        self.partials = torch.zeros(lib().gadapt_loss_partials_max(), **f32)
+        self.loss = torch.zeros((), **f32)
+        self.g_ws, self.dxd_ws, self.edge_ws = torch.empty(2, n, c, **f32), torch.empty(n, c, **f32), torch.empty(e, 2, **f32)
+        self.slab_rows = lib().gadapt_backward_slab_rows(n, c)
+        self.slab = torch.empty(lib().gadapt_backward_slab_floats(n, c), **f32)
+        self.scratch = torch.empty(32 * (c * c + c), **f32)
+        self.flat = torch.empty(2 * c * c + 2 * c, **f32)                # [dWq | dbq | dWk | dbk]: the parameters' .grad are views of it
+        self.coeffs = coeffs if coeffs is not None else (torch.empty(c, c, **f32), torch.empty(c, **f32))
+        cuts = [0, c * c, c * c + c, 2 * c * c + c, 2 * c * c + 2 * c]
+        self.grads = [(p, self.flat[cuts[k]:cuts[k + 1]].view_as(p)) for k, p in enumerate(optimizer.active)]
+        self.out = self.x_top4[:, :self.d]
+
+    def refresh_coeffs(self):
+        """(A, p0) of the parameters as they are NOW (one launch): before the first step, and after any change of the weights that did
+        not come from `finish()` (an eager optimizer step, `load_state_dict`, a restored snapshot)."""
+        b, c = self.optimizer.bucket, self.c
+        check(lib().gadapt_coeffs_forward(ptr(b), ptr(b[c * c:]), ptr(b[c * c + c:]), ptr(self.coeffs[0]), ptr(self.coeffs[1]), c, current_stream(self.device)),
+              'gadapt_coeffs_forward')
+
+    def _world(self) -> int:
+        import torch.distributed as dist
+        o = self.optimizer
+        if o.data_parallel and (o.group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)):
+            return dist.get_world_size(o.group)
+        return 1
+
+    def forward_backward(self):
+        """zero_grad + model(data) + loss + backward: 4 + 7 launches at 4 layers (the gradient of the conv parameters is still in
+        the slab: `finish()` sums it).  Data parallel: also the slab sums + chain rule, so that `flat` holds this rank's gradient."""
+        st, c, L = current_stream(self.device), self.c, self.L
+        a, p0 = self.coeffs
+        self.n_part = lib().gadapt_block_forward_loss(self.graph.c_ref, ptr(self.x_all), ptr(self.x_comp), self.d, ptr(self.f), ptr(self.uu), L, ptr(a), ptr(p0),
+                                                      ptr(self.lp), ptr(self.alpha), ptr(self.x_top4), ptr(self.target), self.d, int(self.l1),
+                                                      ptr(self.seed), ptr(self.partials), c, st)
+        check(min(self.n_part, 0), 'gadapt_block_forward_loss')
+        check(lib().gadapt_block_backward(self.graph.c_ref, ptr(self.x_all), 4, ptr(self.alpha), ptr(self.seed), self.d, L, ptr(a), 0, ptr(p0), 0,
+                                          ptr(self.lp), ptr(self.g_ws), ptr(self.dxd_ws), ptr(self.edge_ws), ptr(self.slab), None, 0, None, c, st),
+              'gadapt_block_backward')
+        self.model.end_MLmodel = time.time()                   # GNN.py:301
+        if self._world() > 1:
+            self._tail(stop_after_gradient=True)
+
+    def _tail(self, stop_after_gradient=False, gradient_given=False, scale=1.0):
+        o, c = self.optimizer, self.c
+        g = o.param_groups[0]
+        check(lib().gadapt_step_tail(None if gradient_given else ptr(self.slab), self.slab_rows, ptr(self.scratch), ptr(o.bucket), ptr(self.flat),
+                                     None if stop_after_gradient else ptr(o.exp_avg), None if stop_after_gradient else ptr(o.exp_avg_sq),
+                                     g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], ptr(o._dev_state), scale,
+                                     ptr(self.coeffs[0]), ptr(self.coeffs[1]), None if gradient_given else ptr(self.partials), self.n_part,
+                                     ptr(self.loss), self.n * self.d, c, current_stream(self.device)), 'gadapt_step_tail')
+
+    def finish(self):
+        """optimizer.step(): one GPU - slab sums + chain rule + Adam + next coefficients (2 launches); data parallel - all-reduce of
+        the flat gradient, then Adam + next coefficients (1 launch)."""
+        world = self._world()
+        if world == 1:
+            self._tail()
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.optimizer.group)
+            self._tail(gradient_given=True, scale=1.0 / world)
+        self.optimizer.step_count += 1
+        self.optimizer.grad_bucket = self.flat
+
+    def run(self):
+        self.forward_backward()
+        self.finish()
+        return self.out, self.loss
+
+
 class _Captured:
-    __slots__ = ('static', 'graph', 'loss', 'out', 'grads')
+    __slots__ = ('static', 'graph', 'loss', 'out', 'grads', 'fused')
 
 
 class GraphedTrainStep:
@@ -48,7 +198,7 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer: FlatAdam, loss_fn: Callable = mse_loss, target_field: str = 'x_phys', warmup: int = 2,
-                 capture_optimizer: bool = True, max_graphs: int = 4):
+                 capture_optimizer: bool = True, max_graphs: int = 4, fused: bool = True):
         if not isinstance(optimizer, FlatAdam) or not optimizer.capturable:
             raise TypeError("GraphedTrainStep needs FlatAdam(capturable=True): the step count must live on the device")
         if not model.training:
@@ -72,6 +222,14 @@ class GraphedTrainStep:
         from .functional import l1_loss
         self._root = unit_gradient(self.device) if loss_fn in (mse_loss, l1_loss) else None
         self._pool = None
+        # fused=True: topologies whose step qualifies (FusedIteration.eligible) are captured as the 13-launch fused iteration instead of
+        # the autograd one (same parameters bit for bit).  The composite coefficients (A, p0) then live across steps - every step's
+        # tail leaves those of the updated weights - in buffers shared by all captures; `_coeffs_stale` marks them for recomputation
+        # whenever the weights change by any other route (eager steps, a capture's warm-up, refresh()).
+        self.fused = bool(fused)
+        self._coeffs = None
+        self._coeffs_stale = True
+        self.fused_reason: Optional[str] = None              # why the last capture did not take the fused route (None: it did)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # captured on a side stream by design
 
     # ------------------------------------------------------------------ the iteration (what eager code would run)
@@ -92,7 +250,13 @@ class GraphedTrainStep:
         _, loss = self._iteration(data)
         if not self.capture_optimizer:
             self.optimizer.step()
+        self._coeffs_stale = True
         return loss
+
+    def refresh(self):
+        """Tell the step that the model's weights were changed behind its back (`load_state_dict`, an optimizer step issued elsewhere,
+        manual edits): the fused captures recompute their composite coefficients before the next replay."""
+        self._coeffs_stale = True
 
     # ------------------------------------------------------------------ capture
     def _snapshot(self):
@@ -151,6 +315,26 @@ class GraphedTrainStep:
             finally:
                 self.optimizer.data_parallel = dp
             self._restore(snap)
+            self._coeffs_stale = True
+            # the fused 13-launch iteration when this topology qualifies (the warm-up has laid the optimizer's bucket out by now)
+            c.fused = None
+            if self.fused:
+                self.fused_reason = FusedIteration.eligible(self.model, self.optimizer, self.loss_fn, c.static, self.target_field)
+                if self.fused_reason is None:
+                    if self._coeffs is None:
+                        cc = int(self.model.opt['hidden_dim'])
+                        self._coeffs = (torch.empty(cc, cc, device=dev), torch.empty(cc, device=dev))
+                    c.fused = FusedIteration(self.model, self.optimizer, self.loss_fn, c.static, self.target_field, coeffs=self._coeffs)
+                    c.fused.refresh_coeffs()
+                    for _ in range(self.warmup):             # first launches of these entry points (LDS attributes, ...) outside the capture
+                        c.fused.forward_backward()
+                        if self.capture_optimizer:
+                            dp, self.optimizer.data_parallel = self.optimizer.data_parallel, False
+                            try:
+                                c.fused.finish()
+                            finally:
+                                self.optimizer.data_parallel = dp
+                    self._restore(snap)
         cur.wait_stream(self._side)
         torch.cuda.synchronize(dev)
         c.graph = torch.cuda.CUDAGraph()
@@ -159,11 +343,20 @@ class GraphedTrainStep:
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         # other threads of the process (the RCCL watchdog) make HIP calls while this one captures: thread_local keeps them out
         mode = 'thread_local' if multi else 'global'
-        with torch.cuda.graph(c.graph, stream=self._side, pool=self._pool, capture_error_mode=mode):
-            c.out, c.loss = self._iteration(c.static)
-        # the .grad tensors this graph writes (views of its flat gradient tensor): an eager optimizer.step() after a replay must
-        # read THESE, not the ones a later capture of another topology left on the parameters
-        c.grads = [(p, p.grad) for p in self.optimizer.params]
+        if c.fused is not None:
+            # (coefficients: left OUT of the graph - the first replay and every replay after a foreign weight change is preceded
+            # by refresh_coeffs(), all others read what the previous step's tail wrote)
+            with torch.cuda.graph(c.graph, stream=self._side, pool=self._pool, capture_error_mode=mode):
+                c.fused.forward_backward()
+                if self.capture_optimizer:
+                    c.fused.finish()
+            c.out, c.loss, c.grads = c.fused.out, c.fused.loss, c.fused.grads
+        else:
+            with torch.cuda.graph(c.graph, stream=self._side, pool=self._pool, capture_error_mode=mode):
+                c.out, c.loss = self._iteration(c.static)
+            # the .grad tensors this graph writes (views of its flat gradient tensor): an eager optimizer.step() after a replay must
+            # read THESE, not the ones a later capture of another topology left on the parameters
+            c.grads = [(p, p.grad) for p in self.optimizer.params]
         if self._pool is None:
             self._pool = c.graph.pool()                      # later captures share the private pool (one step runs at a time)
         return c
@@ -202,11 +395,22 @@ class GraphedTrainStep:
                     continue
                 if src.data_ptr() != dst.data_ptr():         # loaders bound with `static_batch` write in place
                     dst.copy_(src.reshape(dst.shape), non_blocking=True)
+        if c.fused is not None and self._coeffs_stale:
+            c.fused.refresh_coeffs()                         # (A, p0) of the weights as they are now; from here on the tails keep them current
         c.graph.replay()
         for p, g in c.grads:                                 # `.grad` shows what THIS replay computed (each capture has its own tensors)
             p.grad = g
-        if not self.capture_optimizer:
+        if c.fused is not None:
+            if self.capture_optimizer:
+                self._coeffs_stale = False
+            else:
+                c.fused.finish()                             # all-reduce + Adam + next coefficients
+                self._coeffs_stale = False
+        elif not self.capture_optimizer:
             self.optimizer.step()                            # all-reduce + fused Adam
+            self._coeffs_stale = True
+        else:
+            self._coeffs_stale = True
         return c.loss
 
     def static_batch(self, data):

@@ -208,6 +208,42 @@ int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols
                           const float* layer_params,
                           float* g_ws, float* dxd_ws, float* edge_ws, float* slab,
                           float* d_layer_params, int want_d_scale, float* d_x0, int c, void* stream);
+/* ------------------------------------------------------------------ fused training step (ABI 8)
+ * The reference's iteration - zero_grad, model(data), F.mse_loss / F.l1_loss(out, data.x_phys), backward, Adam step
+ * (run_GNN.py:99-131; loss :80-84,106; Adam :88,128-131) - for a weight-shared GRAND / GRAND_plus block behind the identity
+ * encoder, as 14 launches instead of 16 (and without the two that cost most: the loss and the encoder): gadapt_block_forward_loss, gadapt_block_backward (g_top = seed, g_top_cols = d),
+ * gadapt_step_tail.
+ *
+ * gadapt_block_forward_loss = gadapt_block_forward(x0_cols = 4, x_top4) with two things folded into its launches:
+ *   - layer 0 assembles its compact [N,4] input [x_comp | f | uu | 0] from the caller's node fields (the feature concatenation of
+ *     GNN.py:225-239 through the zero-pad encoder GNN.py:75-82; f_tensor / uu_tensor nullable, dim + extras <= 4) and writes it to
+ *     the start of x_all's slot 0, where the layer-0 backward reads it: no encoder launch;
+ *   - the last layer's head-only launch also writes seed [N,d] = d loss / d x_top4[:, :d] (same arithmetic as gadapt_loss_forward)
+ *     and one partial of sum |x_top4[:, :d] - target|^p per wave to loss_partials (gadapt_loss_partials_max() floats): no loss
+ *     launch.  Returns the number of partials written (> 0) or a negative error code.
+ * (a, p0): the composite coefficients of the shared conv - from gadapt_coeffs_forward before the first step, from the previous
+ * step's gadapt_step_tail afterwards. */
+int gadapt_loss_partials_max(void);
+int gadapt_block_forward_loss(const gadapt_graph* g, float* x_all, const float* x_comp, int dim, const float* f_tensor /*nullable*/,
+                              const float* uu_tensor /*nullable*/, int n_layers, const float* a, const float* p0,
+                              const float* layer_params, float* alpha_all, float* x_top4,
+                              const float* target, int d, int l1, float* seed, float* loss_partials, int c, void* stream);
+/* Tail of the step.  slab != NULL (one GPU): three launches - the first-level slab sums (as gadapt_slab_reduce_coeffs_backward's
+ * first launch; one extra workgroup sums the loss partials in a fixed order: loss_out[0] = sum / loss_count); ONE launch that
+ * finishes the sums, applies the chain rule to the flat gradient grad = [dWq | dbq | dWk | dbk] (gadapt_slab_reduce_coeffs_backward's
+ * arithmetic) and runs Adam on the flat bucket param = [Wq | bq | Wk | bk] (gadapt_adam_step_dev's arithmetic and state; a workgroup
+ * owns whole rows r of Wq / Wk with bq[r], bk[r] - the chain rule of those entries reads only entries the same workgroup owns, so
+ * the launch needs no exchange between workgroups); and gadapt_coeffs_forward of the UPDATED weights -> (a_out, p0_out) for the
+ * next step.  slab == NULL (data parallel): grad is given - the caller all-reduced it - and two launches do Adam + coefficients;
+ * its first half is the same call with slab given and exp_avg = exp_avg_sq = NULL: the two sum launches (loss included), stopping at
+ * the flat gradient.  state = int32[2] {steps taken, 0} as for gadapt_adam_step_dev.
+ * Bit-identical parameters, moments and coefficients to the separate launches (tests/test_gpu_training.py). */
+int gadapt_step_tail(const float* slab /*nullable*/, int n_rows, float* scratch, float* param, float* grad, float* exp_avg,
+                     float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t* state,
+                     float grad_scale, float* a_out, float* p0_out,
+                     const float* loss_partials /*nullable*/, int n_loss_partials, float* loss_out, int64_t loss_count,
+                     int c, void* stream);
+
 /* ------------------------------------------------------------------ small meshes: the whole evaluation forward in ONE launch
  * The reference's own sizes (params.py:37,56,107,130-134: 11x11 ... 23x23 meshes, hidden 8, 4 layers; evaluation one sample per call,
  * utils_eval.py:128-130,193-201; the Burgers rollout, utils_eval_Burgers.py:282-300): encoder (GNN.py:225-239,270), composite
