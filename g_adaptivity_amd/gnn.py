@@ -241,7 +241,9 @@ class GNN(nn.Module):
         contiguous node ranges and fit a workgroup (graph.mesh_partition, functional.small_forward_fits).  With autograd on
         (training) also: fixed steps and temperature (the one-launch backward returns the conv gradients only)."""
         o = self.opt
-        train = torch.is_grad_enabled()
+        # training = autograd is on AND some conv parameter wants a gradient: an eval-mode model called outside no_grad with frozen
+        # weights is an evaluation (nothing to keep for a backward, the evaluation policy's sizes apply)
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.conv_layers.parameters())
         if not x_comp.is_cuda:                                             # (the per-layer path raises the no-CPU-fallback error)
             return None
         if not (Fn.SMALL_MESH_FORWARD and self._fusable() and o['hidden_dim'] <= 32
@@ -336,7 +338,8 @@ class GNN(nn.Module):
         x_all, sliced, x0_cols = None, False, 0
         feats, coeffs = None, None
         first = self.conv_layers[0]
-        # ---- small meshes, evaluation: encoder + all layers + head as ONE launch, one workgroup per mesh (the reference's own
+        # ---- small meshes (evaluation, and training at the sizes functional.small_training_policy takes): encoder + all layers + head as
+        # ONE launch, one workgroup per mesh (the reference's own
         # sizes: params.py:37,56,107,130-134; utils_eval.py:193-201, utils_eval_Burgers.py:282-300)
         if fusable and not glob:
             plan = self._small_plan(data, graph, x_comp, f, uu)

@@ -38,6 +38,13 @@ class GraphedForward:
                 f = self.static.f_tensor if o['gnn_inc_feat_f'] else None
                 uu = self.static.uu_tensor if o['gnn_inc_feat_uu'] else None
                 self._plan = model._small_plan(self.static, graph, xc, f, uu)
+        # The direct launch passes raw parameter addresses, taken once: only when every one of them IS live parameter storage - one
+        # shared conv (the plan's weights are views of the parameters) and constant steps / temperature.  Per-layer convs and learnable
+        # steps / temperature are STACKED COPIES in the plan (gnn._small_plan): launched directly they would go stale with the next
+        # optimizer step or load_state_dict, so those models take the captured graph below, which re-stacks from the live parameters on
+        # every replay.
+        if self._plan is not None and not (o['share_conv'] and not o.get('learn_step') and o.get('softmax_temp_type') != 'learnable_a'):
+            self._plan = None
         if self._plan is not None:                         # one kernel per call: launched directly, nothing to capture
             self.direct = True
             self._use_f, self._use_uu = bool(o['gnn_inc_feat_f']), bool(o['gnn_inc_feat_uu'])
@@ -75,6 +82,10 @@ class GraphedForward:
                       pl['wq'].data_ptr(), pl['bq'].data_ptr(), pl['wk'].data_ptr(), c * c if S > 1 else 0, c if S > 1 else 0, pl['lp'].data_ptr(), L,
                       self.out.data_ptr(), pl['out_cols'], None if self._alpha is None else self._alpha.data_ptr(), None, c, None]
         self._n = n
+        # the parameters whose storage the argument list points into: a re-bound `.data` (FlatAdam lays its bucket out on its first
+        # step, load_state_dict(assign=True), ...) moves them - checked per call (refresh())
+        first = m.conv_layers[0]
+        self._live = [(t, t.data_ptr()) for t in (first.lin_query.weight, first.lin_query.bias, first.lin_key.weight, m.enc.weight)]
         if pl['store']:                                    # GRAND_plus.py:253-256, :381: the layers show the static attention tensor
             for l, layer in enumerate(m.conv_layers):
                 layer.stored_ei, layer._stored = graph.edge_index, (graph, self._alpha[l])
@@ -94,7 +105,22 @@ class GraphedForward:
             raise ValueError(f"{name}: {tuple(src.shape)} does not fit the {self._n} nodes this forward was prepared for")
         return src
 
+    def refresh(self):
+        """Rebuild the direct launch's argument list from the model as it is now (parameter storage that moved)."""
+        if self.direct:
+            with torch.no_grad():
+                xc = self.static.x_comp if self.static.x_comp.dim() == 2 else self.static.x_comp.unsqueeze(-1)
+                o = self.model.opt
+                plan = self.model._small_plan(self.static, self._plan['graph'], xc, self.static.f_tensor if o['gnn_inc_feat_f'] else None,
+                                              self.static.uu_tensor if o['gnn_inc_feat_uu'] else None)
+            if plan is None:
+                raise RuntimeError("GraphedForward.refresh(): the model no longer qualifies for the one-launch forward; build a new GraphedForward")
+            self._plan = plan
+            self._prepare_direct()
+
     def _direct_call(self, data, fields, sync):
+        if any(t.data_ptr() != ptr_ for t, ptr_ in self._live):
+            self.refresh()
         a = self._args
         xc = self._field('x_comp', data, fields, True)
         f = self._field('f_tensor', data, fields, self._use_f)

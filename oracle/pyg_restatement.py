@@ -440,6 +440,7 @@ class OracleGNN(nn.Module):
                 per_mesh = getattr(self, name)(grid.unsqueeze(1).to(self.enc.weight.dtype))
                 feats = torch.cat([feats.to(per_mesh.dtype), per_mesh.repeat_interleave(torch.bincount(data.batch), dim=0)], dim=-1)
         x = self.enc(feats.to(self.enc.weight.dtype))                                      # :270
+        x = F.dropout(x, opt.get('dropout', 0.0), training=self.training)                  # :271 (identity at the shipped p = 0)
         alphas = []
         for i, layer in enumerate(self.conv_layers):                                       # :273
             if opt['conv_type'] == 'TRANS':                                                # GNN.py:284, stock TransformerConv

@@ -84,6 +84,31 @@ def test_rollout_reuses_the_graph_and_hipgraph_replay_equals_eager(gpu_device, h
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("share", [True, False], ids=['shared-conv-direct-launch', 'per-layer-convs-captured-graph'])
+def test_graphed_forward_follows_weight_changes(gpu_device, share):
+    """`GraphedForward` on a small-mesh batch must never serve stale weights.  A shared conv is launched directly
+    on the parameters' own storage - in-place optimizer updates are seen, and parameter storage that MOVES (FlatAdam lays its bucket
+    out on its first step; `p.data = ...`) is noticed per call.  Per-layer convs are stacked copies in the one-launch plan, so they
+    take the captured graph, which re-stacks from the live parameters on every replay."""
+    from g_adaptivity_amd.inference import GraphedForward
+    opt = hot_path_opt(mesh_dims=[11, 11], hidden_dim=8, num_layers=3, share_conv=share, device=str(gpu_device))
+    ds = MeshDataset([11, 11], 2, seed=2)
+    data = collate(ds.samples).to(gpu_device)
+    torch.manual_seed(3)
+    model = GNN(ds, opt).to(gpu_device).eval()
+    runner = GraphedForward(model, data)
+    assert runner.direct == share
+    with torch.no_grad():
+        assert torch.equal(runner(data).clone(), model(data))
+        for p in model.conv_layers.parameters():                        # in place, raw (no version bump: what the Adam kernels do)
+            p.data.mul_(1.25)
+        assert torch.equal(runner(data).clone(), model(data))
+        for p in model.conv_layers.parameters():                        # storage re-bound (what FlatAdam._build does)
+            p.data = (p.data * 0.5).clone()
+        assert torch.equal(runner(data).clone(), model(data))
+
+
+@pytest.mark.gpu
 def test_compact_encoder_output_equals_dense(gpu_device):
     """Identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the compact [N,4] features and the top layer's backward
     the compact [N,dim] gradient.  The forward gives exactly what the dense [N,C] matrices give (same kernels, same order).

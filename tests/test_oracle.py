@@ -273,3 +273,23 @@ def test_edge_features_against_a_dense_loop():
             for w_, t in zip(torch.softmax(s, 0), es):
                 out2[i, h] += w_ * (v[ei[0, t], h] + bare[t].view(H, c)[h])
     assert (out2.view(n, -1) - x - res2).abs().max().item() <= 1e-12
+
+
+def test_oracle_applies_the_input_dropout_of_the_reference():
+    """`src/GNN.py:271`: `x = F.dropout(enc(features), opt['dropout'], training=self.training)` - the identity at the shipped p = 0 and
+    in evaluation, active in training at p > 0 (the restatement was missing the op)."""
+    from g_adaptivity_amd import MeshDataset, collate, hot_path_opt
+    from oracle.pyg_restatement import OracleGNN
+    ds = MeshDataset([6, 6], 2, seed=0)
+    data = collate(ds.samples)
+    outs = {}
+    for p_drop, train in ((0.0, True), (0.5, False), (0.5, True)):
+        opt = hot_path_opt(mesh_dims=[6, 6], hidden_dim=8, num_layers=2, dropout=p_drop, device='cpu')
+        torch.manual_seed(0)
+        m = OracleGNN(ds, opt)
+        m.train(train)
+        torch.manual_seed(1)
+        outs[(p_drop, train)] = m(data).detach()
+    assert torch.equal(outs[(0.0, True)], outs[(0.5, False)])            # p = 0 and evaluation: the identity
+    assert not torch.equal(outs[(0.0, True)], outs[(0.5, True)])         # training at p = 0.5: the encoder output is dropped out
+
