@@ -8,7 +8,7 @@ within 1e-4 relative, measured against the oracle's fp64 twin.  ONE rule for eve
 where `noise` is the fp32 ORACLE's own error against its fp64 twin (round 5: the band below is consulted only in a NOISY case - one where
 that single-run noise reaches half the floor, 5e-5, on some parameter; a case whose oracle is quiet must meet the 1e-4 floor - and
 every comparison is RECORDED:
-`gpurun_out/r05_parity.json` -> committed as `profiles/r05_parity.json`: per case, kernel dispatch and parameter the error against
+`gpurun_out/r06_parity.json` -> committed as `profiles/r06_parity.json` (one per round, `PARITY_ROUND`): per case, kernel dispatch and parameter the error against
 fp64, the single-run noise, the band if it was computed, and which rule admitted it).  Some shapes cannot reach 1e-4 in fp32 at all: the 1-D case
 (|grad| ~ 1e-6) and above all BASELINE config 4 (64x64, 6 layers, hidden 128: |grad| ~ 1e-10, the remainder of sums that cancel to
 1 part in 1e3..1e4).  There the fp32 result is a draw from a band, for the reference too: its edge order is the iteration order of
@@ -33,11 +33,12 @@ GRAD_TOL = 1e-4
 import json   # noqa: E402
 import os     # noqa: E402
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PARITY_LOG = os.path.join(_ROOT, 'gpurun_out', 'r05_parity.json')
+PARITY_ROUND = 'r06'
+PARITY_LOG = os.path.join(_ROOT, 'gpurun_out', f'{PARITY_ROUND}_parity.json')
 
 
 def _record(case_id, rows, coord):
-    """Append one case's margins to gpurun_out/r05_parity.json (rewritten whole each time: the file stays valid JSON)."""
+    """Append one case's margins to gpurun_out/<round>_parity.json (rewritten whole each time: the file stays valid JSON)."""
     os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
     try:
         log = json.load(open(PARITY_LOG))

@@ -72,13 +72,18 @@ def test_bench_line_roofline_is_reproducible_from_profiles():
     assert rm['frac'] == rm['measured']['hot_kernels_time_weighted'] and 'reference_flops_vs_fp32_peak' in rm
 
 
+def _newest_parity_record():
+    paths = sorted(glob.glob(os.path.join(PROF, 'r*_parity.json')))
+    return paths[-1] if paths else None
+
+
 def test_parity_margins_are_committed_for_every_case():
-    """the parity run's margins are on record - `profiles/r05_parity.json` (written by tests/test_gpu_parity.py on
+    """the parity run's margins are on record - `profiles/rNN_parity.json` (written by tests/test_gpu_parity.py on
     the GPU box, copied here) has an entry for every case of the parity matrix in every kernel dispatch it runs in, each parameter
     with its error against fp64, the oracle's single-run noise, the band where one was computed, and the rule that admitted it."""
-    path = os.path.join(PROF, 'r05_parity.json')
-    if not os.path.exists(path):
-        pytest.skip("profiles/r05_parity.json not committed yet (GPU run pending)")
+    path = _newest_parity_record()
+    if path is None:
+        pytest.skip("no profiles/rNN_parity.json committed yet (GPU run pending)")
     log = json.load(open(path))
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import test_gpu_parity as tp
@@ -91,3 +96,22 @@ def test_parity_margins_are_committed_for_every_case():
             assert row['e64'] <= row['bound'], (cid, row)
             if row['rule'] == 'band':                        # only in a case whose oracle is itself noisy on some parameter
                 assert row['noisy_case'] and max(r['noise_single_run'] for r in rec['gradients']) >= 0.5 * log['grad_tol'], (cid, row)
+
+
+def test_parity_record_is_not_older_than_the_kernels():
+    """the committed parity record must come from a run of the kernels as they are - the newest commit that touched
+    `g_adaptivity_amd/csrc/` may not be younger than the newest commit that touched the newest `profiles/rNN_parity.json`.  (In a tree
+    without git history - the GPU box's snapshot - there is nothing to compare.)"""
+    import subprocess
+    path = _newest_parity_record()
+    if path is None or not os.path.isdir(os.path.join(ROOT, '.git')):
+        pytest.skip("no parity record or no git history here")
+
+    def last_commit_time(rel):
+        out = subprocess.run(['git', 'log', '-1', '--format=%ct', '--', rel], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        return int(out) if out else None
+    t_rec, t_src = last_commit_time(os.path.relpath(path, ROOT)), last_commit_time('g_adaptivity_amd/csrc')
+    if t_rec is None:
+        pytest.skip("the parity record is not committed yet")
+    assert t_src is None or t_rec >= t_src, (f"{os.path.basename(path)} was committed before the last change of g_adaptivity_amd/csrc: re-run "
+                                            "tests/test_gpu_parity.py on the GPU and commit gpurun_out/<round>_parity.json to profiles/")

@@ -6,7 +6,7 @@
 set -o pipefail
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out
 DEF=poisson2d_64x64_b32_L4_C64
 for WL in $DEF poisson2d_32x32_b32_L4_C64 burgers2d_64x64_b32_L6_C128 euler20_128x128_b16_C64; do

@@ -41,7 +41,11 @@ def variant(n):
         return None
     if 'bwd_target_compact' in n:
         return 'compact_x'
-    if 'bwd_target' in n:                                   # <C, SUMS, GC, XC, DA, D4>
+    if 'bwd_target' in n and len(a) <= 4:                   # round 6 on: <C, SUMS, GC, D4>
+        a += ['false'] * (4 - len(a))
+        if a[3] == 'true': return 'compact_g+out4' if a[2] == 'true' else 'out4'
+        return 'compact_g' if a[2] == 'true' else 'dense'
+    if 'bwd_target' in n:                                   # rounds 1-5: <C, SUMS, GC, XC, DA, D4[, STR]>
         a += ['false'] * (6 - len(a))
         if a[3] == 'true': return 'compact_x'
         if a[5] == 'true': return 'compact_g+out4' if a[2] == 'true' else 'out4'

@@ -2,7 +2,7 @@
 # GPU box, repo root: rocprofv3 stats + PMC passes for every BASELINE bench workload -> gpurun_out/prof_<tag>_<workload>/, then
 # pmc.json + traffic.json (tools/make_pmc_json.py: ONE pass set feeds both) into gpurun_out/ AND into profiles/ of this checkout,
 # so a bench run later in the same call reads the fresh counters.   bash tools/profile_all.sh <tag> [workload ...]
-TAG=${1:-r05}; shift
+TAG=${1:-r06}; shift
 WLS=${@:-poisson2d_64x64_b32_L4_C64 poisson2d_32x32_b32_L4_C64 burgers2d_64x64_b32_L6_C128 euler20_128x128_b16_C64}
 rm -f gpurun_out/pmc_${TAG}.json
 for WL in $WLS; do

@@ -24,10 +24,26 @@ ds = MeshDataset([w['n'], w['n']], w['batch'], seed=0)
 data = collate(ds.samples).to(dev)
 torch.manual_seed(0)
 model = GNN(ds, opt).to(dev).train()
-optim = FlatAdam(model.parameters(), lr=1e-3)
-for _ in range(a.steps):
+optim = FlatAdam(model.parameters(), lr=1e-3, capturable=True)
+from g_adaptivity_amd import mse_loss, unit_gradient               # noqa: E402
+from g_adaptivity_amd.training import FusedIteration               # noqa: E402
+
+
+def autograd_step():
     optim.zero_grad()
-    F.mse_loss(model(data), data.x_phys).backward()
+    mse_loss(model(data), data.x_phys).backward(gradient=unit_gradient(dev))
     optim.step()
+
+
+autograd_step()                                                    # lays the optimizer's bucket out
+fused = None
+if FusedIteration.eligible(model, optim, mse_loss, data, 'x_phys') is None:      # the route bench.py's step takes
+    fused = FusedIteration(model, optim, mse_loss, data, 'x_phys')
+    fused.refresh_coeffs()
+for _ in range(a.steps):
+    if fused is not None:
+        fused.run()
+    else:
+        autograd_step()
 torch.cuda.synchronize()
-print("profiled", a.steps, "steps of", a.workload)
+print("profiled", a.steps, "steps of", a.workload, "(fused iteration)" if fused is not None else "(autograd iteration)")
