@@ -51,17 +51,25 @@ class GraphedForward:
             self._last = {}
             self._prepare_direct()
             return
+        self._warmup = warmup
+        self._capture()
+        self._last = {}                                    # field -> (source tensor, its version) of the last copy
+
+    def _capture(self):
+        """Capture `model(self.static)`.  The graph reads the parameters by ADDRESS: in-place updates are followed, parameter storage
+        that moves (`p.data = ...`: FlatAdam's bucket, load_state_dict(assign=True)) is noticed per call and captured again."""
+        model, dev = self.model, self.device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.no_grad(), torch.cuda.stream(side):
-            for _ in range(warmup):                        # builds the CSR cache and warms the allocator outside the capture
+            for _ in range(self._warmup):                  # builds the CSR cache and warms the allocator outside the capture
                 model(self.static)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph, stream=side):
             self.out = model(self.static)
-        self._last = {}                                    # field -> (source tensor, its version) of the last copy
+        self._live = [(t, t.data_ptr()) for t in model.parameters()]
 
     # ------------------------------------------------------------------ small meshes: one kernel, launched directly
     def _prepare_direct(self):
@@ -106,7 +114,11 @@ class GraphedForward:
         return src
 
     def refresh(self):
-        """Rebuild the direct launch's argument list from the model as it is now (parameter storage that moved)."""
+        """Rebuild the direct launch's argument list / capture the graph again from the model as it is now (parameter storage that
+        moved)."""
+        if not self.direct:
+            self._capture()
+            return
         if self.direct:
             with torch.no_grad():
                 xc = self.static.x_comp if self.static.x_comp.dim() == 2 else self.static.x_comp.unsqueeze(-1)
@@ -146,6 +158,8 @@ class GraphedForward:
         Returns the static output tensor (overwritten by the next call; clone it to keep it)."""
         if self.direct:
             return self._direct_call(data, fields, sync)
+        if any(t.data_ptr() != ptr_ for t, ptr_ in self._live):
+            self.refresh()
         for name in FIELDS:
             src = fields.get(name, getattr(data, name, None) if data is not None else None)
             if src is None:

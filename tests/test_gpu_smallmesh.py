@@ -162,9 +162,9 @@ def test_small_mesh_training_step_graphed_equals_eager_and_tracks_the_oracle(gpu
 
 @pytest.mark.one_dispatch
 @pytest.mark.gpu
-@pytest.mark.parametrize("share", [True, False], ids=['shared-conv', 'per-layer-convs'])
-@pytest.mark.parametrize("mesh_n,hidden", [(8, 8), (11, 8), (15, 8), (20, 8), (23, 8), (27, 4), (11, 16), (15, 16), (20, 16), (13, 8), (13, 16)],
-                         ids=lambda v: str(v))
+@pytest.mark.parametrize("mesh_n,hidden,share", [(8, 8, True), (11, 8, True), (15, 8, True), (20, 8, True), (23, 8, True), (27, 4, True), (11, 16, True),
+                                                   (15, 16, True), (20, 16, True), (13, 8, True), (13, 16, True), (13, 8, False), (13, 16, False)],
+                         ids=lambda v: {True: 'shared-conv', False: 'per-layer-convs'}.get(v, str(v)) if isinstance(v, bool) else str(v))
 def test_small_mesh_pair_matches_per_layer_kernels_at_every_lane_split(gpu_device, mesh_n, hidden, share, monkeypatch):
     """Training forward + backward through the one-launch pair against the per-layer kernels on the same model and batch, at mesh
     sizes that select every (threads, lanes per node) instantiation of csrc/gadapt_smallmesh.inc: 64 / 121 / 225 / 400 / 529 / 729
@@ -172,8 +172,6 @@ def test_small_mesh_pair_matches_per_layer_kernels_at_every_lane_split(gpu_devic
     are fp32 fma chains of the same formulation: parameter gradients agree to reassociation level.  per-layer-convs: the
     backward's `share_conv=False` branch in TRAINING - weights reloaded per layer, one slab set per conv, a slab reduction per conv -
     at two sizes (odd node counts: the LDS regions behind the index arrays must still be 16-byte aligned)."""
-    if not share and mesh_n != 13:
-        pytest.skip("per-layer convs: the 13 x 13 cases")
     import g_adaptivity_amd.functional as Fn
     import torch.nn.functional as F
     from g_adaptivity_amd import GNN, MeshDataset, collate, hot_path_opt
