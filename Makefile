@@ -28,9 +28,10 @@ $(OBJDIR)/gadapt_tu_smallmesh.o: $(CSRC)/gadapt_smallmesh.inc
 $(OBJDIR)/gadapt_tu_sparse.o: $(CSRC)/gadapt_sparse.inc
 $(OBJDIR)/gadapt_tu_gat.o: $(CSRC)/gadapt_gat.inc
 
+# FLAGS_<unit>="-D..." adds flags to ONE translation unit (A/B builds of a kernel family: tools/ab_units.sh)
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(SHARED)
 	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+	$(HIPCC) $(HIPFLAGS) $(FLAGS_$*) -c -o $@ $<
 
 $(OBJDIR)/csr_build.o: $(CSRC)/csr_build.cpp include/gadapt_hip.h
 	@mkdir -p $(OBJDIR)
