@@ -61,7 +61,8 @@ PROTOTYPES = {
     'gadapt_block_forward': (_I, [_G, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _I, _P]),
     'gadapt_block_backward': (_I, [_G, _P, _I, _P, _P, _I, _I, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     'gadapt_loss_partials_max': (_I, []),
-    'gadapt_block_forward_loss': (_I, [_G, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P]),
+    'gadapt_forward_computes_coeffs': (_I, [_G, _I]),
+    'gadapt_block_forward_loss': (_I, [_G, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P]),
     'gadapt_step_tail': (_I, [_P, _I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P, _F, _P, _P, _P, _I, _P, _L, _I, _P]),
     'gadapt_small_forward_lds_bytes': (_L, [_I, _I, _I]),
     'gadapt_small_forward': (_I, [_G, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _L, _L, _P, _I, _P, _I, _P, _P, _I, _P]),

@@ -45,28 +45,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GADAPT_ONE_WAVE_C
 #define GADAPT_ONE_WAVE_C 128
 #endif
-// Hidden sizes from here on would use 512-thread workgroups (Cfg::NT).  Measured at hidden 128 (-DGADAPT_WIDE_WG_C=128
-// -DGADAPT_ONE_WAVE_C=256: the per-wave shares of the dA / projection blocks halve, two waves per SIMD): the backward kernels
-// still spill (52 / 47 registers) and BASELINE config 4 ran 16.1k meshes/s against 17.8k with 256 threads at one wave per
-// SIMD (forward 79 vs 59 us, target 142 vs 147, source 106 vs 93) - not adopted, the geometry stays parametrised.
-#ifndef GADAPT_WIDE_WG_C
-#define GADAPT_WIDE_WG_C 1024
-#endif
+// (512-thread workgroups at hidden 128 - two waves per SIMD - were measured in rounds 2 and 6, per kernel family: the source pass then
+// fits 206 registers without spills and runs 80 us against 68, the target pass is level, the forward 78 against 61: docs/measurements.md
+// K.  Every tiled kernel is a 256-thread workgroup.)
 #ifndef GADAPT_SLAB_CHUNKS
 #define GADAPT_SLAB_CHUNKS 8    // second-level partials of the slab reduction (<= 32: the scratch the callers allocate).
                                 // 32 / 16 / 8 chunks: first level 5.1 / 5.5 / 5.0 us, second level + chain rule 12.1 / 8.8 / 6.6 us
-#endif
-#ifndef GADAPT_T_RING_MAX_C
-#define GADAPT_T_RING_MAX_C 128   // target pass: largest hidden size that keeps the rolling LDS window of x rows
-#endif
-#ifndef GADAPT_BWD_JIT_B_C
-#define GADAPT_BWD_JIT_B_C 1024  // backward kernels rebuild the projection fragments per tile from this hidden size on
-#endif
-#ifndef GADAPT_BWD_ONE_PER_CU
-#define GADAPT_BWD_ONE_PER_CU 1
-#endif
-#ifndef GADAPT_T_PREFETCH_MAX_C
-#define GADAPT_T_PREFETCH_MAX_C 128  // target pass: largest hidden size that requests the next tile one tile ahead
 #endif
 // Softmax arithmetic: expf / IEEE division (<= 1 ulp each).  The approximate forms (v_exp_f32 of a rounded product, v_rcp_f32)
 // leave alpha with ~4x the rounding error of the reference's exp / true division; harmless for the coordinates (2e-7 either way)
@@ -150,13 +134,13 @@ template <int C> static constexpr int resident_blocks(int two_per_cu_default) { 
 // 256-thread workgroup per CU: 256 workgroups are the resident set, a 512-workgroup launch would run as two rounds (and
 // flush twice as many slab rows).
 template <int C> static constexpr int resident_blocks_bwd(int two_per_cu_default) {
-    return (C >= GADAPT_ONE_WAVE_C && GADAPT_BWD_ONE_PER_CU) ? 256 : resident_blocks<C>(two_per_cu_default);
+    return C >= GADAPT_ONE_WAVE_C ? 256 : resident_blocks<C>(two_per_cu_default);
 }
 // ... and the target pass at hidden 32 (128-row tiles: ring + dP tile + slices = 87 KB of LDS) fits one workgroup per CU too
 // (hipOccupancyMaxActiveBlocksPerMultiprocessor: forward / target / source = 2 / 1 / 2 at hidden 32, 2 / 2 / 2 at 64,
 // 2 / 1 / 1 at 128, 3 / 3 / 3 at 8).
 template <int C> static constexpr int resident_blocks_bwd_t(int two_per_cu_default) {
-    return (C == 32 && GADAPT_BWD_ONE_PER_CU) ? 256 : resident_blocks_bwd<C>(two_per_cu_default);
+    return C == 32 ? 256 : resident_blocks_bwd<C>(two_per_cu_default);
 }
 template <int C> static int tiles_for(int64_t n_nodes) { return (int)((n_nodes + Cfg<C>::TM - 1) / Cfg<C>::TM); }
 
@@ -187,7 +171,10 @@ template <int C> static int tiles_for(int64_t n_nodes) { return (int)((n_nodes +
 // Extras of the forward launches of a fused training step (gadapt_block_forward_loss): layer 0 assembles its compact [N,4] input
 // from the caller's node fields (fs) and writes it to x0c for the layer-0 backward; the head-only launch of the last layer also
 // produces the loss derivative and one loss partial per wave (loss; *n_partials_out = the grid of that launch).
-struct FwdExtra { FieldSrc fs; float* x0c; LossArgs loss; int* n_partials_out; };
+// cw / a_out / p0_out (nullable): the flat parameter bucket - the layer-0 launch computes the composite coefficients itself when it is
+// the wide kernel (gadapt_forward_computes_coeffs_c) and writes them to a_out / p0_out for the launches that follow.
+struct FwdExtra { FieldSrc fs; float* x0c; LossArgs loss; int* n_partials_out; const float* cw; float* a_out; float* p0_out; };
+int gadapt_forward_computes_coeffs_c(const gadapt_graph* g, int c);
 #define GADAPT_LOSS_PARTIALS_MAX 4096  /* waves of a forward launch: GADAPT_FWD_MAX_BLOCKS workgroups of up to 8 waves */
 int gadapt_launch_fwd_c(int c, const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0, const float* lp,
                         float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st, const FwdExtra* extra = nullptr);

@@ -428,9 +428,19 @@ static int block_forward(const gadapt_graph* g, float* x_all, int x0_cols, int n
         const bool last = (l == n_layers - 1);
         float* alpha_l = alpha_all ? alpha_all + (size_t)l * g->n_edges : nullptr;
         int rc;
+        // extras of a fused training step, per layer: the node fields and the weights (in-kernel coefficients) for layer 0, the loss for
+        // the last layer
+        FwdExtra ex_l{};
+        const FwdExtra* ex = nullptr;
+        if (extra) {
+            if (l == 0) { ex_l.fs = extra->fs; ex_l.x0c = extra->x0c; }
+            if (l == 0) { ex_l.cw = extra->cw; ex_l.a_out = extra->a_out; ex_l.p0_out = extra->p0_out; }
+            if (last) { ex_l.loss = extra->loss; ex_l.n_partials_out = extra->n_partials_out; }
+            ex = &ex_l;
+        }
         if ((l == 0 && x0_cols) || (last && x_top4))             // compact input and/or compact-only output
             rc = gadapt_launch_fwd_c(c, g, x_all + l * nc, (last && x_top4) ? nullptr : x_all + (l + 1) * nc, a + l * a_stride, p0 + l * p0_stride,
-                                     layer_params + 2 * l, alpha_l, 0, l == 0 ? x0_cols : 0, last ? x_top4 : nullptr, st, extra);
+                                     layer_params + 2 * l, alpha_l, 0, l == 0 ? x0_cols : 0, last ? x_top4 : nullptr, st, ex);
         else
             rc = gadapt_layer_forward(g, x_all + l * nc, x_all + (l + 1) * nc, a + l * a_stride, p0 + l * p0_stride,
                                       layer_params + 2 * l, alpha_l, 0, c, stream);
@@ -449,8 +459,9 @@ extern "C" int gadapt_block_forward(const gadapt_graph* g, float* x_all, int x0_
 // layer's launch; tail = slab sums + chain rule + Adam + the next step's composite coefficients
 // ------------------------------------------------------------------------------------------------
 extern "C" int gadapt_loss_partials_max(void) { return GADAPT_LOSS_PARTIALS_MAX; }
+extern "C" int gadapt_forward_computes_coeffs(const gadapt_graph* g, int c) { return g ? gadapt_forward_computes_coeffs_c(g, c) : 0; }
 extern "C" int gadapt_block_forward_loss(const gadapt_graph* g, float* x_all, const float* x_comp, int dim, const float* f_tensor, const float* uu_tensor,
-                                         int n_layers, const float* a, const float* p0, const float* layer_params, float* alpha_all, float* x_top4,
+                                         int n_layers, float* a, float* p0, const float* param, const float* layer_params, float* alpha_all, float* x_top4,
                                          const float* target, int d, int l1, float* seed, float* loss_partials, int c, void* stream) {
     if (!x_comp || dim < 1 || dim > 4 || dim + (f_tensor ? 1 : 0) + (uu_tensor ? 1 : 0) > 4)
         return fail(GADAPT_E_BADARG, "block_forward_loss: 1..4 coordinates, coordinates + extras <= 4 columns");
@@ -458,8 +469,10 @@ extern "C" int gadapt_block_forward_loss(const gadapt_graph* g, float* x_all, co
     if (!g || g->n_nodes <= 0) return fail(GADAPT_E_BADARG, "bad graph");
     int n_partials = 0;
     // x_all slot 0 starts with the compact [N,4] layer-0 input (written by the layer-0 launch for the layer-0 backward)
+    if (param && !gadapt_forward_computes_coeffs_c(g, c))
+        return fail(GADAPT_E_BADARG, "block_forward_loss: param given, but this graph / hidden size does not compute the coefficients in its layer-0 launch (gadapt_forward_computes_coeffs)");
     FwdExtra ex{FieldSrc{x_comp, f_tensor, uu_tensor, dim}, x_all,
-                LossArgs{target, seed, loss_partials, d, l1 ? 1 : 0, 1.0f / (float)((int64_t)g->n_nodes * d)}, &n_partials};
+                LossArgs{target, seed, loss_partials, d, l1 ? 1 : 0, 1.0f / (float)((int64_t)g->n_nodes * d)}, &n_partials, param, a, p0};
     if (int rc = block_forward(g, x_all, 4, n_layers, a, 0, p0, 0, layer_params, alpha_all, x_top4, c, stream, &ex)) return rc;
     if (n_partials <= 0 || n_partials > GADAPT_LOSS_PARTIALS_MAX) return fail(GADAPT_E_RUNTIME, "block_forward_loss: loss partial count out of range");
     return n_partials;
@@ -470,7 +483,7 @@ extern "C" int gadapt_step_tail(const float* slab, int n_rows, float* scratch, f
                                 float* a_out, float* p0_out, const float* loss_partials, int n_loss_partials, float* loss_out, int64_t loss_count,
                                 int c, void* stream) {
     const bool gradient_only = slab && !exp_avg && !exp_avg_sq;     // data parallel, first half: stop at the flat gradient
-    if (!param || !grad || !gadapt_supported_hidden_dim(c) || (!gradient_only && (!exp_avg || !exp_avg_sq || !state || !a_out || !p0_out)))
+    if (!param || !grad || !gadapt_supported_hidden_dim(c) || (!gradient_only && (!state || !exp_avg || !exp_avg_sq || (!a_out != !p0_out))))
         return fail(GADAPT_E_BADARG, "step_tail: bad argument");
     if (slab && (n_rows <= 0 || !scratch)) return fail(GADAPT_E_BADARG, "step_tail: slab without row count / scratch");
     if (loss_partials && (n_loss_partials <= 0 || !loss_out || loss_count <= 0 || !slab))
@@ -480,8 +493,12 @@ extern "C" int gadapt_step_tail(const float* slab, int n_rows, float* scratch, f
     int blocks = (2 * c * c + 2 * c + 1023) / 1024;                // one entry of the flat gradient / bucket per thread
     if (slab) {
         const int nbx = (row_len + 255) / 256;
-        hipLaunchKernelGGL(slab_reduce1_kernel, dim3(nbx + (loss_partials ? 1 : 0), GADAPT_SLAB_CHUNKS), dim3(256), 0, st, slab, scratch, n_rows, row_len,
-                           nbx, (const float*)nullptr, 0, 0, (float*)nullptr, loss_partials, n_loss_partials, 1.0f / (float)loss_count, loss_out);
+        // (+ one workgroup: the step count for the Adam launch of this step, and the loss value)
+        hipLaunchKernelGGL(slab_reduce1_kernel, dim3(nbx + 1, GADAPT_SLAB_CHUNKS), dim3(256), 0, st, slab, scratch, n_rows, row_len,
+                           nbx, (const float*)nullptr, 0, 0, (float*)nullptr, loss_partials, n_loss_partials, loss_partials ? 1.0f / (float)loss_count : 0.f, loss_out,
+                           gradient_only ? nullptr : state);     // (data parallel: the count advances with the Adam half)
+    } else {
+        hipLaunchKernelGGL(step_count_kernel, dim3(1), dim3(64), 0, st, state);
     }
     if (gradient_only) {                                            // second-level sums + chain rule, as gadapt_slab_reduce_coeffs_backward
         const int c2 = c * c, lds2 = (c * (c + 1) + c) * 4;
@@ -498,13 +515,11 @@ extern "C" int gadapt_step_tail(const float* slab, int n_rows, float* scratch, f
     switch (c) { GADAPT_TAIL(4) GADAPT_TAIL(8) GADAPT_TAIL(16) GADAPT_TAIL(32) GADAPT_TAIL(64) GADAPT_TAIL(128) default: break; }
 #undef GADAPT_TAIL
     if (int rc = check_launch("step_tail")) return rc;
-    // the composite coefficients of the UPDATED weights for the next step's forward (the launch that used to open every step)
-    const int c2 = c * c, n_out = c2 + c;
-#define GADAPT_CFS(CC) case CC: hipLaunchKernelGGL(coeffs_fwd_step_kernel<CC>, dim3((n_out + 255) / 256), dim3(256), 0, st, param, param + c2, param + c2 + c, \
-                                                   a_out, p0_out, state); break;
-    switch (c) { GADAPT_CFS(4) GADAPT_CFS(8) GADAPT_CFS(16) GADAPT_CFS(32) GADAPT_CFS(64) GADAPT_CFS(128) default: break; }
-#undef GADAPT_CFS
-    return check_launch("coeffs_fwd_step_kernel");
+    // the composite coefficients of the UPDATED weights for the next step's forward - unless that forward computes them itself
+    // (a_out = p0_out = NULL: gadapt_forward_computes_coeffs)
+    if (!a_out) return GADAPT_OK;
+    const int c2 = c * c;
+    return gadapt_coeffs_forward(param, param + c2, param + c2 + c, a_out, p0_out, c, stream);
 }
 
 extern "C" int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols, const float* alpha_all, const float* g_top, int g_top_cols, int n_layers,

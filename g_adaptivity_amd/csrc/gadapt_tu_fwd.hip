@@ -26,7 +26,7 @@ static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_ou
     p.stamps = g_stamp_buf;
 #endif
     if (ex) {
-        if (x_cols) { p.fs = ex->fs; p.x0c = ex->x0c; }
+        if (x_cols) { p.fs = ex->fs; p.x0c = ex->x0c; p.cw = ex->cw; p.a_out = ex->a_out; p.p0_out = ex->p0_out; }
         if (!x_out && !x_cols && ex->loss.target) { p.loss = ex->loss; if (ex->n_partials_out) *ex->n_partials_out = 8 * wide_grid(n_steps); }
     }
     ProfScope prof(0, st, (x_cols ? 2 : 0) | (x_out ? 0 : 4));
@@ -44,12 +44,19 @@ static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_ou
     return check_launch("wide::fwd_kernel");
 }
 
+static bool wide_takes(const gadapt_graph* g) {
+    return g->ell_t && (g->wide_deg_t > 0 || (g->wide_big_deg_t > 0 && g->wide_big_deg_t <= 7)) && wide_enabled();
+}
+// 1: the layer-0 launch of a fused training step on this graph at this hidden size is the wide kernel, which computes the composite
+// coefficients itself (FwdExtra::cw); 0: they must be given (a coefficient launch ends the step)
+int gadapt_forward_computes_coeffs_c(const gadapt_graph* g, int c) { return (c == 64 && g && wide_takes(g)) ? 1 : 0; }
+
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                                        const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st, const FwdExtra* ex) {
     using K = Cfg<C>;
     if (x_cols != 0 && x_cols != 4) return fail(GADAPT_E_BADARG, "compact layer input: 4 columns");
     if constexpr (C == 64) {
-        if (g->ell_t && (g->wide_deg_t > 0 || (g->wide_big_deg_t > 0 && g->wide_big_deg_t <= 7)) && wide_enabled())
+        if (wide_takes(g))
             return launch_wide_fwd(g, x_in, x_out, a, p0, lp, alpha_out, residual_only, x_cols, x_top4, st, ex);
     }
     FwdArgs p{x_in, x_out, a, p0, lp, g->rowptr_t, g->col_t, meta_for<K::TM>(g->meta_t), alpha_out, g->n_nodes,

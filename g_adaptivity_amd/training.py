@@ -35,9 +35,10 @@ TOPOLOGY_FIELDS = ('edge_index', 'to_boundary_edge_mask', 'to_corner_nodes_mask'
 
 class FusedIteration:
     """The training iteration of `src/run_GNN.py:99-131` for a weight-shared GRAND / GRAND_plus model behind the identity encoder as
-    13 launches on preallocated buffers, straight over the C-ABI (no autograd): `gadapt_block_forward_loss` (layer 0 reads the node
+    13 or 14 launches on preallocated buffers, straight over the C-ABI (no autograd): `gadapt_block_forward_loss` (layer 0 reads the node
     fields, the last layer's launch produces the loss derivative and the loss partials), `gadapt_block_backward`, `gadapt_step_tail`
-    (slab sums + chain rule + Adam + the NEXT step's composite coefficients).  The per-layer launches are the ones the autograd path
+    (slab sums; chain rule + Adam; the NEXT step's composite coefficients - unless the next forward computes them itself: hidden 64 on
+    graphs the wide forward kernel takes, `coeffs_in_forward`).  The per-layer launches are the ones the autograd path
     issues, on the same values in the same order, and the Adam / coefficient arithmetic is shared code: parameters and moments are
     bit-identical to the eager loop; the loss value is summed in another (fixed) order.
 
@@ -118,6 +119,9 @@ class FusedIteration:
         cuts = [0, c * c, c * c + c, 2 * c * c + c, 2 * c * c + 2 * c]
         self.grads = [(p, self.flat[cuts[k]:cuts[k + 1]].view_as(p)) for k, p in enumerate(optimizer.active)]
         self.out = self.x_top4[:, :self.d]
+        # hidden 64 on a graph the wide forward takes: the layer-0 launch computes (A, p0) from the live weights itself - no coefficient
+        # launch in the step (13 launches), and nothing to refresh when the weights change behind the step's back
+        self.coeffs_in_forward = bool(lib().gadapt_forward_computes_coeffs(self.graph.c_ref, c))
 
     def refresh_coeffs(self):
         """(A, p0) of the parameters as they are NOW (one launch): before the first step, and after any change of the weights that did
@@ -139,6 +143,7 @@ class FusedIteration:
         st, c, L = current_stream(self.device), self.c, self.L
         a, p0 = self.coeffs
         self.n_part = lib().gadapt_block_forward_loss(self.graph.c_ref, ptr(self.x_all), ptr(self.x_comp), self.d, ptr(self.f), ptr(self.uu), L, ptr(a), ptr(p0),
+                                                      ptr(self.optimizer.bucket) if self.coeffs_in_forward else None,
                                                       ptr(self.lp), ptr(self.alpha), ptr(self.x_top4), ptr(self.target), self.d, int(self.l1),
                                                       ptr(self.seed), ptr(self.partials), c, st)
         check(min(self.n_part, 0), 'gadapt_block_forward_loss')
@@ -155,7 +160,8 @@ class FusedIteration:
         check(lib().gadapt_step_tail(None if gradient_given else ptr(self.slab), self.slab_rows, ptr(self.scratch), ptr(o.bucket), ptr(self.flat),
                                      None if stop_after_gradient else ptr(o.exp_avg), None if stop_after_gradient else ptr(o.exp_avg_sq),
                                      g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], ptr(o._dev_state), scale,
-                                     ptr(self.coeffs[0]), ptr(self.coeffs[1]), None if gradient_given else ptr(self.partials), self.n_part,
+                                     None if self.coeffs_in_forward else ptr(self.coeffs[0]), None if self.coeffs_in_forward else ptr(self.coeffs[1]),
+                                     None if gradient_given else ptr(self.partials), self.n_part,
                                      ptr(self.loss), self.n * self.d, c, current_stream(self.device)), 'gadapt_step_tail')
 
     def finish(self):
@@ -395,17 +401,16 @@ class GraphedTrainStep:
                     continue
                 if src.data_ptr() != dst.data_ptr():         # loaders bound with `static_batch` write in place
                     dst.copy_(src.reshape(dst.shape), non_blocking=True)
-        if c.fused is not None and self._coeffs_stale:
+        if c.fused is not None and self._coeffs_stale and not c.fused.coeffs_in_forward:
             c.fused.refresh_coeffs()                         # (A, p0) of the weights as they are now; from here on the tails keep them current
         c.graph.replay()
         for p, g in c.grads:                                 # `.grad` shows what THIS replay computed (each capture has its own tensors)
             p.grad = g
         if c.fused is not None:
-            if self.capture_optimizer:
-                self._coeffs_stale = False
-            else:
-                c.fused.finish()                             # all-reduce + Adam + next coefficients
-                self._coeffs_stale = False
+            if not self.capture_optimizer:
+                c.fused.finish()                             # all-reduce + Adam (+ next coefficients)
+            # a step whose forward computes the coefficients itself leaves none behind for a capture that needs them given
+            self._coeffs_stale = c.fused.coeffs_in_forward
         elif not self.capture_optimizer:
             self.optimizer.step()                            # all-reduce + fused Adam
             self._coeffs_stale = True

@@ -221,22 +221,29 @@ int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols
  *   - the last layer's head-only launch also writes seed [N,d] = d loss / d x_top4[:, :d] (same arithmetic as gadapt_loss_forward)
  *     and one partial of sum |x_top4[:, :d] - target|^p per wave to loss_partials (gadapt_loss_partials_max() floats): no loss
  *     launch.  Returns the number of partials written (> 0) or a negative error code.
- * (a, p0): the composite coefficients of the shared conv - from gadapt_coeffs_forward before the first step, from the previous
- * step's gadapt_step_tail afterwards. */
+ * (a, p0): the composite coefficients of the shared conv.  param == NULL: INPUTS - from gadapt_coeffs_forward before the first
+ * step, from the previous step's gadapt_step_tail afterwards.  param != NULL (only where gadapt_forward_computes_coeffs(g, c) = 1:
+ * hidden 64 on a graph the wide forward kernel takes): the flat bucket [Wq | bq | Wk | bk] the step trains - the layer-0 launch
+ * computes A = Wk^T Wq, p0 = Wk^T bq itself (gadapt_coeffs_forward's arithmetic; every workgroup for its own operand fragments,
+ * while its window of node rows is in flight) and writes them to a / p0 for the launches that follow: OUTPUTS, and no coefficient
+ * launch anywhere in the step. */
 int gadapt_loss_partials_max(void);
+int gadapt_forward_computes_coeffs(const gadapt_graph* g, int c);
 int gadapt_block_forward_loss(const gadapt_graph* g, float* x_all, const float* x_comp, int dim, const float* f_tensor /*nullable*/,
-                              const float* uu_tensor /*nullable*/, int n_layers, const float* a, const float* p0,
+                              const float* uu_tensor /*nullable*/, int n_layers, float* a, float* p0, const float* param /*nullable*/,
                               const float* layer_params, float* alpha_all, float* x_top4,
                               const float* target, int d, int l1, float* seed, float* loss_partials, int c, void* stream);
-/* Tail of the step.  slab != NULL (one GPU): three launches - the first-level slab sums (as gadapt_slab_reduce_coeffs_backward's
- * first launch; one extra workgroup sums the loss partials in a fixed order: loss_out[0] = sum / loss_count); ONE launch that
- * finishes the sums, applies the chain rule to the flat gradient grad = [dWq | dbq | dWk | dbk] (gadapt_slab_reduce_coeffs_backward's
- * arithmetic) and runs Adam on the flat bucket param = [Wq | bq | Wk | bk] (gadapt_adam_step_dev's arithmetic and state; a workgroup
- * owns whole rows r of Wq / Wk with bq[r], bk[r] - the chain rule of those entries reads only entries the same workgroup owns, so
- * the launch needs no exchange between workgroups); and gadapt_coeffs_forward of the UPDATED weights -> (a_out, p0_out) for the
- * next step.  slab == NULL (data parallel): grad is given - the caller all-reduced it - and two launches do Adam + coefficients;
- * its first half is the same call with slab given and exp_avg = exp_avg_sq = NULL: the two sum launches (loss included), stopping at
- * the flat gradient.  state = int32[2] {steps taken, 0} as for gadapt_adam_step_dev.
+/* Tail of the step.  slab != NULL (one GPU): the first-level slab sums (as gadapt_slab_reduce_coeffs_backward's first launch; one
+ * extra workgroup advances the optimizer's device step count and sums the loss partials in a fixed order: loss_out[0] = sum /
+ * loss_count); ONE launch that finishes the sums, applies the chain rule to the flat gradient grad = [dWq | dbq | dWk | dbk]
+ * (gadapt_slab_reduce_coeffs_backward's arithmetic) and runs Adam on the flat bucket param = [Wq | bq | Wk | bk]
+ * (gadapt_adam_step_dev's arithmetic and state; a workgroup owns whole rows r of Wq / Wk with bq[r], bk[r] - the chain rule of those
+ * entries reads only entries the same workgroup owns, so the launch needs no exchange between workgroups); and, when a_out / p0_out
+ * are given, gadapt_coeffs_forward of the UPDATED weights -> (a_out, p0_out) for the next step (NULL where the next forward computes
+ * them itself: gadapt_forward_computes_coeffs) - 14 or 13 launches per step.  slab == NULL (data parallel): grad is given - the
+ * caller all-reduced it - and the launches are step count, Adam (+ coefficients); its first half is the same call with slab given and
+ * exp_avg = exp_avg_sq = NULL: the two sum launches (loss included), stopping at the flat gradient.
+ * state = int32[2] {steps taken, 0} as for gadapt_adam_step_dev.
  * Bit-identical parameters, moments and coefficients to the separate launches (tests/test_gpu_training.py). */
 int gadapt_step_tail(const float* slab /*nullable*/, int n_rows, float* scratch, float* param, float* grad, float* exp_avg,
                      float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t* state,

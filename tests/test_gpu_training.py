@@ -280,8 +280,9 @@ def test_graphed_train_step_is_the_eager_loop(gpu_device, into, fused):
 def test_fused_iteration_is_the_autograd_iteration(gpu_device, mesh_n, batch, hidden, layers, conv, f, l1, monkeypatch):
     """`training.FusedIteration` issued EAGERLY (no capture) against the autograd iteration on the same batch: after three steps the
     parameters, both Adam moments and the device step count are bit-identical, so are the model output and the parameter gradients of
-    every step; the loss value within 1e-6 relative; and the composite coefficients the tail leaves for the next step are the ones
-    `gadapt_coeffs_forward` computes from the updated weights.  Tiled and wide forward, hidden 8 ... 128, 3 and 4 feature columns,
+    every step; the loss value within 1e-6 relative; and the composite coefficients the next step's forward works with - left by the tail,
+    or computed by the wide layer-0 launch itself (`coeffs_in_forward`) - are bit for bit the ones `gadapt_coeffs_forward` computes from the
+    updated weights.  Tiled and wide forward, hidden 8 ... 128, 3 and 4 feature columns,
     MSE and L1 (`src/run_GNN.py:80-84`)."""
     import g_adaptivity_amd.functional as Fn_mod
     from g_adaptivity_amd import l1_loss, mse_loss, unit_gradient
@@ -322,6 +323,8 @@ def test_fused_iteration_is_the_autograd_iteration(gpu_device, mesh_n, batch, hi
                 rec.append((it.out.clone(), it.loss.clone(), [g.clone() for _, g in it.grads]))
             else:
                 rec.append(autograd_step())
+        if route == 'fused' and it.coeffs_in_forward:                  # (A, p0) come from the NEXT forward's layer-0 launch: issue one
+            it.forward_backward()
         torch.cuda.synchronize()
         runs[route] = (rec, [p.detach().clone() for p in optim.active], optim.exp_avg.clone(), optim.exp_avg_sq.clone(), optim.state_dict()['step'],
                        it.coeffs if route == 'fused' else Fn_mod.composite_coeffs(*[p.detach() for p in optim.active[:3]]))
