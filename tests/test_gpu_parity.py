@@ -37,6 +37,17 @@ PARITY_ROUND = 'r06'
 PARITY_LOG = os.path.join(_ROOT, 'gpurun_out', f'{PARITY_ROUND}_parity.json')
 
 
+def kernel_sources_sha16(root=_ROOT):
+    """Fingerprint of the kernel sources the record was made with (csrc/ + the C-ABI header): tests/test_profiles.py compares it with
+    the tree's - a parity record older than the kernels fails the CPU suite."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(root, 'g_adaptivity_amd', 'csrc', '*'))) + [os.path.join(root, 'include', 'gadapt_hip.h')]:
+        if os.path.isfile(path) and not path.endswith(('.o', '.so')):
+            h.update(os.path.basename(path).encode()); h.update(open(path, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def _record(case_id, rows, coord):
     """Append one case's margins to gpurun_out/<round>_parity.json (rewritten whole each time: the file stays valid JSON)."""
     os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
@@ -46,6 +57,7 @@ def _record(case_id, rows, coord):
         log = {'rule': 'e64 <= max(1e-4, 1.5 * noise); noise = fp32 oracle vs its fp64 twin (one run); the worst of five edge orders '
                        '("band") only in a noisy case: one whose single-run noise reaches 5e-5 (half the floor) on some parameter', 'grad_tol': GRAD_TOL, 'coord_tol': COORD_TOL, 'cases': {}}
     log['cases'][case_id] = {'coordinates': coord, 'gradients': rows}
+    log['kernel_sources_sha16'] = kernel_sources_sha16()
     with open(PARITY_LOG, 'w') as fh:
         json.dump(log, fh, indent=1, sort_keys=True)
 

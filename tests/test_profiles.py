@@ -99,19 +99,15 @@ def test_parity_margins_are_committed_for_every_case():
 
 
 def test_parity_record_is_not_older_than_the_kernels():
-    """the committed parity record must come from a run of the kernels as they are - the newest commit that touched
-    `g_adaptivity_amd/csrc/` may not be younger than the newest commit that touched the newest `profiles/rNN_parity.json`.  (In a tree
-    without git history - the GPU box's snapshot - there is nothing to compare.)"""
-    import subprocess
+    """the committed parity record must come from a run of the kernels as they are: it carries a fingerprint of
+    `g_adaptivity_amd/csrc/` + `include/gadapt_hip.h` taken on the GPU box when it was written; any later change of a kernel source
+    fails this test until tests/test_gpu_parity.py has run again and `gpurun_out/<round>_parity.json` is committed to `profiles/`."""
     path = _newest_parity_record()
-    if path is None or not os.path.isdir(os.path.join(ROOT, '.git')):
-        pytest.skip("no parity record or no git history here")
-
-    def last_commit_time(rel):
-        out = subprocess.run(['git', 'log', '-1', '--format=%ct', '--', rel], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-        return int(out) if out else None
-    t_rec, t_src = last_commit_time(os.path.relpath(path, ROOT)), last_commit_time('g_adaptivity_amd/csrc')
-    if t_rec is None:
-        pytest.skip("the parity record is not committed yet")
-    assert t_src is None or t_rec >= t_src, (f"{os.path.basename(path)} was committed before the last change of g_adaptivity_amd/csrc: re-run "
-                                            "tests/test_gpu_parity.py on the GPU and commit gpurun_out/<round>_parity.json to profiles/")
+    if path is None:
+        pytest.skip("no parity record committed yet")
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import test_gpu_parity as tp
+    log = json.load(open(path))
+    assert log.get('kernel_sources_sha16') == tp.kernel_sources_sha16(ROOT), (
+        f"{os.path.basename(path)} was recorded with other kernel sources than this tree's: re-run tests/test_gpu_parity.py on the GPU and "
+        "commit gpurun_out/<round>_parity.json to profiles/")
