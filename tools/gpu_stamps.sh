@@ -5,5 +5,5 @@ cd ${GRAFT_REPO_ROOT:-.}
 for N in 64 32; do
   echo "== ${N}x${N} meshes, batch 32, hidden 64"
   GADAPT_LIB=variants/stamps.so STAMP_N=$N timeout -k 10 200 python tools/stamp_bwd.py 2>&1 | tail -14
-done > gpurun_out/r6_stamps_backward.txt 2>&1
-cat gpurun_out/r6_stamps_backward.txt
+done > gpurun_out/r06_stamps_backward.txt 2>&1
+cat gpurun_out/r06_stamps_backward.txt
