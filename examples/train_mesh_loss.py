@@ -36,7 +36,8 @@ def main(opt, dataset, log=print):
         loss_fn = F.mse_loss if opt['loss_fn'] == 'mse' else F.l1_loss
     optimizer = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=graphed)
     model.train()
-    step = GraphedTrainStep(model, optimizer, loss_fn=loss_fn) if graphed else None
+    # (GADAPT_FUSED=0: the captured autograd iteration instead of the fused 13-launch one - A/B runs)
+    step = GraphedTrainStep(model, optimizer, loss_fn=loss_fn, fused=os.environ.get('GADAPT_FUSED', '1') != '0') if graphed else None
     if opt.get('device_loader', True):     # samples stacked on the GPU, batches assembled there (no per-step host collation)
         loader = DeviceMeshLoader(dataset, batch_size=opt['batch_size'], shuffle=shuffle, device=opt['device'],
                                   fields=('x_comp', 'x_phys', 'f_tensor', 'uu_tensor'),
