@@ -49,4 +49,8 @@ for name, s, names in (('backward_target (last launch = layer 0)', allb[1], ['st
         last = s[:, (ntile - 1) * 8 + 7]
         print(f"  workgroup: entry -> prologue done {np.median(pro[ok] - ent[ok]):.0f}  -> first tile start {np.median(first[ok] - pro[ok]):.0f}  "
               f"last stamped tile end -> slab row flushed {np.median(end[ok] - last[ok]):.0f}  | entry -> end {np.median(end[ok] - ent[ok]):.0f}")
+        if ntile == 1:
+            seq = [30, 8, 9, 10, 11, 12, 29, 0]
+            lab = ['entry', 'chunk known', 'vector requests out', 'meta (scalar trip)', 'A fragments built', 'window commits', 'barrier', 'first tile loads in']
+            print("  prologue: " + "  ".join(f"{lab[k]} +{np.median(s[ok, seq[k]] - s[ok, seq[k - 1]]):.0f}" for k in range(1, len(seq))))
         print(f"  launch: first entry -> last end {end[ok].max() - ent[ok].min():.0f} cycles; entry spread (max - min) {ent[ok].max() - ent[ok].min():.0f}; end spread {end[ok].max() - end[ok].min():.0f}")
