@@ -232,10 +232,10 @@ extern "C" int gadapt_slab_reduce_coeffs_backward(const float* slab, int n_rows,
     const int lds = (c * (c + 1) + c) * 4;
     int blocks = (2 * c * c + 2 * c + 1023) / 1024;
     if (blocks > 33) blocks = 33;                               // every workgroup repeats the second-level sums
-#define GADAPT_R2CB(CC) case CC: allow_lds(reduce2_coeffs_bwd_kernel<CC>, lds); \
+#define CASE_C(CC) case CC: allow_lds(reduce2_coeffs_bwd_kernel<CC>, lds); \
         hipLaunchKernelGGL(reduce2_coeffs_bwd_kernel<CC>, dim3(blocks), dim3(1024), lds, st, scratch, wq, bq, wk, d_wq, d_bq, d_wk, d_bk); break;
-    switch (c) { GADAPT_R2CB(4) GADAPT_R2CB(8) GADAPT_R2CB(16) GADAPT_R2CB(32) GADAPT_R2CB(64) GADAPT_R2CB(128) default: break; }
-#undef GADAPT_R2CB
+    switch (c) { CASE_C(4) CASE_C(8) CASE_C(16) CASE_C(32) CASE_C(64) CASE_C(128) default: break; }
+#undef CASE_C
     return check_launch("slab_reduce_coeffs_backward");
 }
 
@@ -244,9 +244,9 @@ extern "C" int gadapt_coeffs_forward(const float* wq, const float* bq, const flo
     if (!gadapt_supported_hidden_dim(c)) return fail(GADAPT_E_BADARG, "coeffs_forward: unsupported hidden_dim");
     const int n = c * c + c;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define GADAPT_COEFFS_F(CC) case CC: hipLaunchKernelGGL(coeffs_fwd_kernel<CC>, dim3((n + 255) / 256), dim3(256), 0, st, wq, bq, wk, a_out, p0_out); break;
-    switch (c) { GADAPT_COEFFS_F(4) GADAPT_COEFFS_F(8) GADAPT_COEFFS_F(16) GADAPT_COEFFS_F(32) GADAPT_COEFFS_F(64) GADAPT_COEFFS_F(128) default: break; }
-#undef GADAPT_COEFFS_F
+#define CASE_C(CC) case CC: hipLaunchKernelGGL(coeffs_fwd_kernel<CC>, dim3((n + 255) / 256), dim3(256), 0, st, wq, bq, wk, a_out, p0_out); break;
+    switch (c) { CASE_C(4) CASE_C(8) CASE_C(16) CASE_C(32) CASE_C(64) CASE_C(128) default: break; }
+#undef CASE_C
     return check_launch("coeffs_fwd_kernel");
 }
 extern "C" int gadapt_coeffs_backward(const float* wq, const float* bq, const float* wk, const float* d_a, const float* d_p0,
@@ -255,9 +255,9 @@ extern "C" int gadapt_coeffs_backward(const float* wq, const float* bq, const fl
     if (!gadapt_supported_hidden_dim(c)) return fail(GADAPT_E_BADARG, "coeffs_backward: unsupported hidden_dim");
     const int n = 2 * c * c + 2 * c;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define GADAPT_COEFFS_B(CC) case CC: hipLaunchKernelGGL(coeffs_bwd_kernel<CC>, dim3((n + 255) / 256), dim3(256), 0, st, wq, bq, wk, d_a, d_p0, d_wq, d_bq, d_wk, d_bk); break;
-    switch (c) { GADAPT_COEFFS_B(4) GADAPT_COEFFS_B(8) GADAPT_COEFFS_B(16) GADAPT_COEFFS_B(32) GADAPT_COEFFS_B(64) GADAPT_COEFFS_B(128) default: break; }
-#undef GADAPT_COEFFS_B
+#define CASE_C(CC) case CC: hipLaunchKernelGGL(coeffs_bwd_kernel<CC>, dim3((n + 255) / 256), dim3(256), 0, st, wq, bq, wk, d_a, d_p0, d_wq, d_bq, d_wk, d_bk); break;
+    switch (c) { CASE_C(4) CASE_C(8) CASE_C(16) CASE_C(32) CASE_C(64) CASE_C(128) default: break; }
+#undef CASE_C
     return check_launch("coeffs_bwd_kernel");
 }
 
@@ -278,11 +278,11 @@ static int launch_encode(const float* feats, int f0, const float* e1, const floa
         return check_launch("encode_linear_kernel");
     }
     const int cblocks = (cf->c * cf->c + cf->c + 255) / 256;
-#define GADAPT_ENC_CF(CC) case CC: hipLaunchKernelGGL(encode_coeffs_kernel<CC>, dim3((unsigned)blocks + cblocks), dim3(256), 0, static_cast<hipStream_t>(stream), \
+#define CASE_C(CC) case CC: hipLaunchKernelGGL(encode_coeffs_kernel<CC>, dim3((unsigned)blocks + cblocks), dim3(256), 0, static_cast<hipStream_t>(stream), \
                                                       p, (int)blocks, cf->wq, cf->bq, cf->wk, cf->a, cf->p0); break;
-    switch (cf->c) { GADAPT_ENC_CF(4) GADAPT_ENC_CF(8) GADAPT_ENC_CF(16) GADAPT_ENC_CF(32) GADAPT_ENC_CF(64) GADAPT_ENC_CF(128)
+    switch (cf->c) { CASE_C(4) CASE_C(8) CASE_C(16) CASE_C(32) CASE_C(64) CASE_C(128)
                      default: return fail(GADAPT_E_BADARG, "encode_features_coeffs: unsupported hidden_dim"); }
-#undef GADAPT_ENC_CF
+#undef CASE_C
     return check_launch("encode_coeffs_kernel");
 }
 extern "C" int gadapt_encode_linear(const float* feats, const float* w, const float* b, float* x0, int64_t n_nodes, int f, int c, void* stream) {
@@ -502,18 +502,18 @@ extern "C" int gadapt_step_tail(const float* slab, int n_rows, float* scratch, f
     }
     if (gradient_only) {                                            // second-level sums + chain rule, as gadapt_slab_reduce_coeffs_backward
         const int c2 = c * c, lds2 = (c * (c + 1) + c) * 4;
-#define GADAPT_R2(CC) case CC: allow_lds(reduce2_coeffs_bwd_kernel<CC>, lds2); \
+#define CASE_C(CC) case CC: allow_lds(reduce2_coeffs_bwd_kernel<CC>, lds2); \
         hipLaunchKernelGGL(reduce2_coeffs_bwd_kernel<CC>, dim3(blocks), dim3(1024), lds2, st, scratch, param, param + c2, param + c2 + c, \
                            grad, grad + c2, grad + c2 + c, grad + 2 * c2 + c); break;
-        switch (c) { GADAPT_R2(4) GADAPT_R2(8) GADAPT_R2(16) GADAPT_R2(32) GADAPT_R2(64) GADAPT_R2(128) default: break; }
-#undef GADAPT_R2
+        switch (c) { CASE_C(4) CASE_C(8) CASE_C(16) CASE_C(32) CASE_C(64) CASE_C(128) default: break; }
+#undef CASE_C
         return check_launch("step_tail (gradient)");
     }
     TailArgs p{slab ? scratch : nullptr, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, state};
-#define GADAPT_TAIL(CC) case CC: { constexpr int lds = tail_lds_floats<CC>() * 4; allow_lds(step_tail_kernel<CC>, lds); \
+#define CASE_C(CC) case CC: { constexpr int lds = tail_lds_floats<CC>() * 4; allow_lds(step_tail_kernel<CC>, lds); \
         hipLaunchKernelGGL(step_tail_kernel<CC>, dim3(tail_blocks<CC>()), dim3(1024), lds, st, p); } break;
-    switch (c) { GADAPT_TAIL(4) GADAPT_TAIL(8) GADAPT_TAIL(16) GADAPT_TAIL(32) GADAPT_TAIL(64) GADAPT_TAIL(128) default: break; }
-#undef GADAPT_TAIL
+    switch (c) { CASE_C(4) CASE_C(8) CASE_C(16) CASE_C(32) CASE_C(64) CASE_C(128) default: break; }
+#undef CASE_C
     if (int rc = check_launch("step_tail")) return rc;
     // the composite coefficients of the UPDATED weights for the next step's forward - unless that forward computes them itself
     // (a_out = p0_out = NULL: gadapt_forward_computes_coeffs)

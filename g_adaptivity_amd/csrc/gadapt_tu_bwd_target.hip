@@ -31,8 +31,10 @@ template <int C> static int launch_bwd_target(const gadapt_graph* g, const float
     const dim3 grid(grid_for(n_tiles, resident_blocks_bwd_t<C>(GADAPT_BWD_T_MAX_BLOCKS)));
     if (x_cols) {                                                // layer 0 on the compact [N,4] input: one node per lane
         ProfScope prof(1, st, 2);
+        pt.ell = g->ell_t;
         if (sums_out && sums_sc_out) hipLaunchKernelGGL((grand_bwd_target_compact_kernel<2>), grid, dim3(256), 0, st, pt);
         else if (sums_out) hipLaunchKernelGGL((grand_bwd_target_compact_kernel<1>), grid, dim3(256), 0, st, pt);
+        else if (pt.ell) hipLaunchKernelGGL((grand_bwd_target_compact_kernel<0, true>), grid, dim3(256), 0, st, pt);
         else hipLaunchKernelGGL((grand_bwd_target_compact_kernel<0>), grid, dim3(256), 0, st, pt);
         return check_launch("grand_bwd_target_compact_kernel");
     }

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from g_adaptivity_amd import _native, MeshDataset, collate, hot_path_opt, GNN
 handle = C.CDLL(_native.LIB_PATH)
 dev = torch.device('cuda:0')
-n, B, Cc, L = 64, 32, 64, 4
+n, B, Cc, L = int(os.environ.get("STAMP_N", "64")), int(os.environ.get("STAMP_B", "32")), 64, 4
 opt = hot_path_opt(mesh_dims=[n, n], hidden_dim=Cc, num_layers=L, device='cuda:0', show_mesh_evol_plots='False')
 ds = MeshDataset([n, n], B, seed=0); data = collate(ds.samples).to(dev)
 model = GNN(ds, opt).to(dev).train()
