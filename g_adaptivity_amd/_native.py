@@ -19,7 +19,7 @@ class GadaptGraph(C.Structure):
                 ('rowptr_s', C.c_void_p), ('col_s', C.c_void_p), ('perm_s', C.c_void_p), ('tpos_s', C.c_void_p),
                 ('meta_t', C.c_void_p * 3), ('meta_s', C.c_void_p * 3),
                 ('ell_t', C.c_void_p), ('ell_s', C.c_void_p), ('wide_deg_t', C.c_int32), ('wide_deg_s', C.c_int32),
-                ('wide_big_deg_t', C.c_int32)]
+                ('wide_big_deg_t', C.c_int32), ('wide_half_deg_t', C.c_int32)]
 
 
 TILE_HEIGHTS = (64, 128, 256)
@@ -37,7 +37,7 @@ PROTOTYPES = {
     'gadapt_csr_build_host': (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P]),
     'gadapt_tile_meta_host': (_I, [_P, _P, _L, _I, _P]),
     'gadapt_ell_build_host': (_I, [_P, _P, _L, _P, _P]),
-    'gadapt_wide_window_host': (_I, [_P, _P, _L, _I, _I, _P]),
+    'gadapt_wide_window_host': (_I, [_P, _P, _L, _I, _I, _I, _P]),
     'gadapt_coeffs_forward': (_I, [_P, _P, _P, _P, _P, _I, _P]),
     'gadapt_coeffs_backward': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'gadapt_encode_linear': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),

@@ -74,20 +74,20 @@ extern "C" int gadapt_ell_build_host(const int32_t* rowptr, const int32_t* col, 
         const int32_t e0 = rowptr[i], d = rowptr[i + 1] - e0;
         for (int32_t k = 0; k < d && k < 8; ++k) ell_out[8 * i + k] = col[e0 + k];
     }
-    return gadapt_wide_window_host(rowptr, col, n_nodes, 64, 8, max_deg_out);
+    return gadapt_wide_window_host(rowptr, col, n_nodes, 256, 64, 8, max_deg_out);
 }
 
-// The wide kernels' locality test for a window of 256 + 2 * halo rows: *max_deg_out = the longest row if every row has at most
-// max_row entries and every neighbour of node i lies in rows [256*(i/256) - halo, 256*(i/256) + 256 + halo), else 0.
-extern "C" int gadapt_wide_window_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int halo, int max_row, int32_t* max_deg_out) {
-    if (!rowptr || !col || !max_deg_out || n_nodes <= 0 || halo < 0 || max_row <= 0) return GADAPT_E_BADARG;
+// The wide kernels' locality test for steps of `step` nodes and a window of step + 2 * halo rows: *max_deg_out = the longest row if every
+// row has at most max_row entries and every neighbour of node i lies in rows [step*(i/step) - halo, step*(i/step) + step + halo), else 0.
+extern "C" int gadapt_wide_window_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int step, int halo, int max_row, int32_t* max_deg_out) {
+    if (!rowptr || !col || !max_deg_out || n_nodes <= 0 || step <= 0 || halo < 0 || max_row <= 0) return GADAPT_E_BADARG;
     int32_t longest = 0;
     bool ok = true;
     for (int64_t i = 0; i < n_nodes && ok; ++i) {
         const int32_t e0 = rowptr[i], d = rowptr[i + 1] - e0;
         if (d > max_row) { ok = false; break; }
         if (d > longest) longest = d;
-        const int64_t lo = i / 256 * 256 - halo, hi = lo + 256 + 2 * (int64_t)halo;
+        const int64_t lo = i / step * step - halo, hi = lo + step + 2 * (int64_t)halo;
         for (int32_t k = 0; k < d; ++k) {
             const int32_t j = col[e0 + k];
             if (j < lo || j >= hi) { ok = false; break; }

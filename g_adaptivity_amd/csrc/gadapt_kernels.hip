@@ -36,7 +36,7 @@ int gadapt_check_launch_(const char* what) {
     return GADAPT_OK;
 }
 extern "C" const char* gadapt_last_error(void) { return g_err; }
-extern "C" int gadapt_abi_version(void) { return 8; }   // 8 (round 6): the wide backward, the strided tile walk and their graph fields / host helpers are gone (measured level twice: docs/measurements.md F, G); + fused training-step entry points
+extern "C" int gadapt_abi_version(void) { return 9; }   // 9: gadapt_graph::wide_half_deg_t, gadapt_wide_window_host(step); 8 (round 6): the wide backward, the strided tile walk and their graph fields / host helpers are gone (measured level twice: docs/measurements.md F, G); + fused training-step entry points
 extern "C" int gadapt_clear_error(void) { g_err[0] = 0; return (int)hipGetLastError(); }
 extern "C" int gadapt_supported_hidden_dim(int c) {
     return c == 4 || c == 8 || c == 16 || c == 32 || c == 64 || c == 128;

@@ -16,26 +16,41 @@ static inline int wide_grid(int n_steps) {
     if (g > 256) g = 256;                                       // one 512-thread workgroup per CU
     return g;
 }
+// Four-wave workgroups on steps of 128 nodes (wide::W<false, 4>): when the 256-node steps would leave half of the CUs without a
+// workgroup and the graph qualifies for the narrower window (gadapt_graph::wide_half_deg_t)
+static bool wide_half(const gadapt_graph* g) {
+    return g->wide_deg_t > 0 && g->wide_half_deg_t > 0 && (g->n_nodes + wide::STEP - 1) / wide::STEP <= 128;
+}
 static int launch_wide_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                            const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st, const FwdExtra* ex) {
-    const int n_steps = (g->n_nodes + wide::STEP - 1) / wide::STEP;
     const bool big = g->wide_deg_t <= 0;                        // 512-row window (meshes with up to 128 nodes per row)
+    const bool half = !big && wide_half(g);
+    const int step = half ? wide::STEP_HALF : wide::STEP, nwv = half ? 4 : 8;
+    const int n_steps = (g->n_nodes + step - 1) / step;
     wide::FwdArgs p{x_in, x_out, a, p0, lp, g->ell_t, g->rowptr_t, alpha_out, g->n_nodes, n_steps, residual_only,
-                    big ? g->wide_big_deg_t : g->wide_deg_t, nullptr, x_top4};
+                    big ? g->wide_big_deg_t : (half ? g->wide_half_deg_t : g->wide_deg_t), nullptr, x_top4};
 #ifdef GADAPT_STAMPS
     p.stamps = g_stamp_buf;
 #endif
     if (ex) {
-        if (x_cols) { p.fs = ex->fs; p.x0c = ex->x0c; p.cw = ex->cw; p.a_out = ex->a_out; p.p0_out = ex->p0_out; }
-        if (!x_out && !x_cols && ex->loss.target) { p.loss = ex->loss; if (ex->n_partials_out) *ex->n_partials_out = 8 * wide_grid(n_steps); }
+        if (x_cols) {
+            p.fs = ex->fs; p.x0c = ex->x0c;
+            if (!half) { p.cw = ex->cw; p.a_out = ex->a_out; p.p0_out = ex->p0_out; }
+            else if (ex->cw) return fail(GADAPT_E_BADARG, "wide forward on four-wave workgroups: the coefficients are given (gadapt_forward_computes_coeffs)");
+        }
+        if (!x_out && !x_cols && ex->loss.target) { p.loss = ex->loss; if (ex->n_partials_out) *ex->n_partials_out = nwv * wide_grid(n_steps); }
     }
     ProfScope prof(0, st, (x_cols ? 2 : 0) | (x_out ? 0 : 4));
-    auto go = [&](auto kern, int lds) { allow_lds(kern, lds); hipLaunchKernelGGL(kern, dim3(wide_grid(n_steps)), dim3(512), lds, st, p); };
+    auto go = [&](auto kern, int lds) { allow_lds(kern, lds); hipLaunchKernelGGL(kern, dim3(wide_grid(n_steps)), dim3(64 * nwv), lds, st, p); };
     const bool head = !x_out && !x_cols;                        // head-only output: its own instantiation (aggregates one chunk)
     if (big) {
         if (x_cols) go(wide::fwd_kernel<true, true>, wide::fwd_lds_bytes<true>());
         else if (head) go(wide::fwd_kernel<false, true, true>, wide::fwd_lds_bytes<true>());
         else go(wide::fwd_kernel<false, true>, wide::fwd_lds_bytes<true>());
+    } else if (half) {
+        if (x_cols) go(wide::fwd_kernel<true, false, false, 4>, wide::fwd_lds_bytes<false, 4>());
+        else if (head) go(wide::fwd_kernel<false, false, true, 4>, wide::fwd_lds_bytes<false, 4>());
+        else go(wide::fwd_kernel<false, false, false, 4>, wide::fwd_lds_bytes<false, 4>());
     } else {
         if (x_cols) go(wide::fwd_kernel<true, false>, wide::fwd_lds_bytes<false>());
         else if (head) go(wide::fwd_kernel<false, false, true>, wide::fwd_lds_bytes<false>());
@@ -49,7 +64,7 @@ static bool wide_takes(const gadapt_graph* g) {
 }
 // 1: the layer-0 launch of a fused training step on this graph at this hidden size is the wide kernel, which computes the composite
 // coefficients itself (FwdExtra::cw); 0: they must be given (a coefficient launch ends the step)
-int gadapt_forward_computes_coeffs_c(const gadapt_graph* g, int c) { return (c == 64 && g && wide_takes(g)) ? 1 : 0; }
+int gadapt_forward_computes_coeffs_c(const gadapt_graph* g, int c) { return (c == 64 && g && wide_takes(g) && !wide_half(g)) ? 1 : 0; }
 
 template <int C> static int launch_fwd(const gadapt_graph* g, const float* x_in, float* x_out, const float* a, const float* p0,
                                        const float* lp, float* alpha_out, int residual_only, int x_cols, float* x_top4, hipStream_t st, const FwdExtra* ex) {

@@ -177,7 +177,7 @@ class GNN(nn.Module):
             # the loop nodes appended by GNN.py:209-218 come from `batch` (mesh count / per-mesh node counts)
             tensors += [data.to_boundary_edge_mask, data.to_corner_nodes_mask, data.diff_boundary_edges_mask, data.batch]
         key = (num_nodes, self.dim, ckey, fix, bool(self.opt.get('self_loops')), str(device),
-               _graph_mod.content_fingerprint(tensors), _graph_mod.WIDE_KERNELS, _graph_mod.WIDE_MIN_NODES)
+               _graph_mod.content_fingerprint(tensors), _graph_mod.WIDE_KERNELS, _graph_mod.WIDE_MIN_NODES, _graph_mod.WIDE_HALF_MAX_NODES)
         g = self._graphs.get(key)
         if g is None:
             ei = prepare_edge_index(data, self.dim, self.mesh_dims[0], fix, bool(self.opt.get('self_loops')), num_nodes,

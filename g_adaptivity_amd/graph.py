@@ -141,6 +141,9 @@ WIDE_KERNELS = True
 # batch too small to fill the 256 CUs does not earn back (forward of 64x64 meshes, hidden 64, 4 layers as one hipGraph:
 # batch 1 / 4 / 8 / 16 = 78.6 / 80.7 / 85.7 / 93.2 us wide against 74.5 / 74.1 / 87.1 / 110.1 us tiled).
 WIDE_MIN_NODES = 24576
+# ... and up to this many on four-wave workgroups, steps of 128 nodes (csrc/gadapt_wide.inc, NWV = 4): the launcher takes them when the
+# 256-node steps would fill at most half of the CUs
+WIDE_HALF_MAX_NODES = 32768
 
 
 class MeshGraph:
@@ -183,9 +186,16 @@ class MeshGraph:
         self.wide_big_deg = 0
         if WIDE_KERNELS and n >= WIDE_MIN_NODES and wide_deg['t'] == 0:
             md = C.c_int32(0)
-            if _native.lib().gadapt_wide_window_host(rowptr_t.data_ptr(), col_t.data_ptr(), n, 128, 7, C.addressof(md)) != 0:
+            if _native.lib().gadapt_wide_window_host(rowptr_t.data_ptr(), col_t.data_ptr(), n, 256, 128, 7, C.addressof(md)) != 0:
                 raise _native.NativeError("gadapt_wide_window_host failed")
             self.wide_big_deg = int(md.value)
+        # steps of 128 nodes on four-wave workgroups (batches that would leave half of the CUs without a 256-node step)
+        self.wide_half_deg = 0
+        if wide_deg['t'] > 0 and n <= WIDE_HALF_MAX_NODES:
+            md = C.c_int32(0)
+            if _native.lib().gadapt_wide_window_host(rowptr_t.data_ptr(), col_t.data_ptr(), n, 128, 64, 8, C.addressof(md)) != 0:
+                raise _native.NativeError("gadapt_wide_window_host failed")
+            self.wide_half_deg = int(md.value)
         self._cpu_csr_t = (rowptr_t, col_t)                 # host copies for mesh_partition()
         self._partitions: Dict[Tuple, Optional[Tuple]] = {}
         self.edge_index = edge_index                        # as given (original order/device)
@@ -197,7 +207,7 @@ class MeshGraph:
                                     self.tpos_s.data_ptr(),
                                     (C.c_void_p * 3)(*[metas[('t', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]),
                                     (C.c_void_p * 3)(*[metas[('s', tm)].data_ptr() for tm in _native.TILE_HEIGHTS]),
-                                    ells['t'].data_ptr(), ells['s'].data_ptr(), wide_deg['t'], wide_deg['s'], self.wide_big_deg)
+                                    ells['t'].data_ptr(), ells['s'].data_ptr(), wide_deg['t'], wide_deg['s'], self.wide_big_deg, self.wide_half_deg)
         self.c_ref = C.byref(self.c_struct)
 
     def mesh_partition(self, batch: Optional[torch.Tensor]):
@@ -271,7 +281,7 @@ class GraphCache:
 
     @staticmethod
     def _key(edge_index: torch.Tensor, num_nodes: int, device) -> Tuple:
-        return (int(num_nodes), str(device), content_fingerprint([edge_index]), WIDE_KERNELS, WIDE_MIN_NODES)
+        return (int(num_nodes), str(device), content_fingerprint([edge_index]), WIDE_KERNELS, WIDE_MIN_NODES, WIDE_HALF_MAX_NODES)
 
     def get(self, edge_index: torch.Tensor, num_nodes: int, device) -> MeshGraph:
         key = self._key(edge_index, num_nodes, device)

@@ -93,7 +93,10 @@ typedef struct gadapt_graph {
     int32_t wide_deg_t;        /* longest in-row if the target orientation qualifies for the wide kernels, else 0 */
     int32_t wide_deg_s;        /* same for the source orientation */
     int32_t wide_big_deg_t;    /* longest in-row if the target orientation qualifies for the 512-row window of the wide forward
-                                  (gadapt_wide_window_host(halo 128, rows <= 7): meshes with up to 128 nodes per row), else 0 */
+                                  (gadapt_wide_window_host(step 256, halo 128, rows <= 7): meshes with up to 128 nodes per row), else 0 */
+    int32_t wide_half_deg_t;   /* ABI 9: longest in-row if the target orientation also qualifies for steps of 128 nodes with a 64-row halo
+                                  (gadapt_wide_window_host(step 128, halo 64, rows <= 8)), else 0: batches of at most 32 768 nodes then run
+                                  the wide forward on four-wave workgroups, twice as many of them */
 } gadapt_graph;
 
 /* ELL-8 copy of one CSR orientation (host pointers).  The wide kernels (hidden size 64: one wave owns 32 consecutive
@@ -102,10 +105,11 @@ typedef struct gadapt_graph {
  * batches do; any other graph takes the tiled kernels.  ell_out: round_up(N,256)*8 int32; *max_deg_out = longest
  * row when the orientation qualifies, else 0. */
 int gadapt_ell_build_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t* ell_out, int32_t* max_deg_out);
-/* The same locality test for a window of 256 + 2*halo rows and rows of at most max_row entries: *max_deg_out = longest row when
- * every neighbour of node i lies in rows [256*(i/256) - halo, 256*(i/256) + 256 + halo), else 0.  halo 128 / max_row 7 is what
- * the wide forward's 512-row window takes (row-major meshes with up to 128 nodes per mesh row: BASELINE config 5). */
-int gadapt_wide_window_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int halo, int max_row, int32_t* max_deg_out);
+/* The same locality test for steps of `step` nodes, a window of step + 2*halo rows and rows of at most max_row entries: *max_deg_out =
+ * longest row when every neighbour of node i lies in rows [step*(i/step) - halo, step*(i/step) + step + halo), else 0.  step 256 / halo
+ * 128 / max_row 7 is what the wide forward's 512-row window takes (row-major meshes with up to 128 nodes per mesh row: BASELINE config
+ * 5); step 128 / halo 64 / max_row 8 what its four-wave form takes (gadapt_graph::wide_half_deg_t). */
+int gadapt_wide_window_host(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int step, int halo, int max_row, int32_t* max_deg_out);
 
 /* ------------------------------------------------------------------ weights
  * A[o][c] = sum_r Wk[r][o] Wq[r][c],  p0[o] = sum_r Wk[r][o] bq[r].

@@ -540,6 +540,39 @@ def test_wide_kernels_match_tiled_kernels(gpu_device, mesh_n, batch):
 
 @pytest.mark.one_dispatch
 @pytest.mark.gpu
+@pytest.mark.parametrize("mesh_n,batch", [(32, 32), (48, 10), (23, 9), (64, 1)], ids=['32x32-b32', '48x48-b10', '23x23-b9', '64x64-b1'])
+def test_wide_forward_four_wave_workgroups_are_the_eight_wave_ones(gpu_device, mesh_n, batch):
+    """Batches of at most 32 768 nodes run the wide forward on FOUR-wave workgroups, steps of 128 nodes, a 256-row window
+    (`wide::fwd_kernel<..., 4>`, `gadapt_graph::wide_half_deg_t`): twice the workgroups where the 256-node steps would leave half of the
+    CUs idle.  A node's arithmetic is the same in both forms, so the full model - compact layer-0 input, dense layers, head-only last
+    output, backward through the stored alpha - gives bit-identical results: one step per workgroup on every CU (32x32 b32), mesh rows
+    that do not divide the step (48 wide), a ragged last step (23x23 b9), fewer steps than XCDs x 4 (64x64 b1)."""
+    from g_adaptivity_amd import graph as graph_mod
+    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=64, num_layers=3, device=str(gpu_device), show_mesh_evol_plots=True)
+    ds = MeshDataset([mesh_n, mesh_n], batch, seed=7)
+    data = collate(ds.samples).to(gpu_device)
+    keep = graph_mod.WIDE_MIN_NODES, graph_mod.WIDE_HALF_MAX_NODES
+    res = {}
+    try:
+        for half_max in (keep[1], 0):
+            graph_mod.WIDE_MIN_NODES, graph_mod.WIDE_HALF_MAX_NODES = 0, half_max
+            torch.manual_seed(3)
+            model = GNN(ds, opt).to(gpu_device).train()
+            g = model._graph(data, data.x_comp.shape[0], gpu_device)
+            assert g.wide_deg['t'] > 0 and (g.wide_half_deg > 0) == (half_max > 0)
+            out = model(data)
+            F.mse_loss(out, data.x_phys).backward()
+            torch.cuda.synchronize()
+            res[half_max > 0] = [out.detach().clone()] + [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    finally:
+        graph_mod.WIDE_MIN_NODES, graph_mod.WIDE_HALF_MAX_NODES = keep
+    assert len(res[True]) == len(res[False]) >= 4
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.one_dispatch
+@pytest.mark.gpu
 @pytest.mark.parametrize("mesh_n,batch,layers", [(128, 16, 2), (128, 3, 3), (100, 5, 2), (65, 7, 2), (96, 2, 4)],
                          ids=['128x128-b16', '128x128-b3', '100x100-b5', '65x65-b7', '96x96-b2'])
 def test_wide_forward_512_row_window_matches_tiled_kernels(gpu_device, mesh_n, batch, layers):

@@ -83,7 +83,7 @@ def test_every_declared_symbol_is_exported():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/gadapt_hip.h but not exported"
     assert declared == set(_native.PROTOTYPES), declared ^ set(_native.PROTOTYPES)
-    assert _native.lib().gadapt_abi_version() == 8
+    assert _native.lib().gadapt_abi_version() == 9
     # argument checks need no GPU: the gradient-exchange entry point refuses a null communicator before it looks for RCCL
     assert _native.lib().gadapt_allreduce_flat(None, None, 0, 0, None) == -1
     assert b'allreduce_flat' in _native.lib().gadapt_last_error()
@@ -324,22 +324,28 @@ def test_fingerprint_separates_diagonal_flip():
 
 
 def test_wide_window_locality_test():
-    """gadapt_wide_window_host: row-major meshes with up to 64 nodes per mesh row fit the 384-row window (halo 64), 65..128 only
-    the 512-row one (halo 128); a mesh 129 wide fits neither; the ELL copy is complete either way."""
+    """gadapt_wide_window_host: row-major meshes with up to 64 nodes per mesh row fit the 384-row window (steps of 256 nodes, halo 64) and
+    the 256-row one of the four-wave form (steps of 128, halo 64; a 48-wide mesh, whose rows do not divide the step, included), 65..128
+    only the 512-row one (halo 128); a mesh 129 wide fits none; the ELL copy is complete either way."""
     import ctypes as C
     lib = _native.lib()
-    for n, want64, want128 in ((64, True, True), (65, False, True), (128, False, True), (129, False, False)):
+    for n, want64, want128, want_half in ((32, True, True, True), (48, True, True, True), (64, True, True, True), (65, False, True, False),
+                                          (128, False, True, False), (129, False, False, False)):
         m = square_mesh(n)
         d = collate([m]); d.corner_nodes = [m.corner_nodes]
         ei = prepare_edge_index(d, 2, n, True, False, n * n)
         g = MeshGraph(ei, n * n, 'cpu')
         got = {}
-        for halo, rows in ((64, 8), (128, 7)):
+        for key, step, halo, rows in ((64, 256, 64, 8), (128, 256, 128, 7), ('half', 128, 64, 8)):
             md = C.c_int32(0)
-            assert lib.gadapt_wide_window_host(g.rowptr_t.data_ptr(), g.col_t.data_ptr(), n * n, halo, rows, C.addressof(md)) == 0
-            got[halo] = md.value
-        assert (got[64] > 0) == want64 and (got[128] > 0) == want128, (n, got)
+            assert lib.gadapt_wide_window_host(g.rowptr_t.data_ptr(), g.col_t.data_ptr(), n * n, step, halo, rows, C.addressof(md)) == 0
+            got[key] = md.value
+        assert (got[64] > 0) == want64 and (got[128] > 0) == want128 and (got['half'] > 0) == want_half, (n, got)
         assert got[128] in (0, 6)
+        # brute force: the rule itself, for the four-wave form
+        rp, cl = g.rowptr_t.tolist(), g.col_t.tolist()
+        ok = all(128 * (i // 128) - 64 <= j < 128 * (i // 128) + 192 for i in range(n * n) for j in cl[rp[i]:rp[i + 1]])
+        assert ok == (got['half'] > 0), n
         ell = g._ells['t'].view(-1, 8)[:n * n]
         deg = (g.rowptr_t[1:] - g.rowptr_t[:-1]).long()
         assert torch.equal((ell >= 0).sum(1), deg)                              # complete even where the 384-row test fails
