@@ -66,6 +66,7 @@ PROTOTYPES = {
     'gadapt_step_tail': (_I, [_P, _I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P, _F, _P, _P, _P, _I, _P, _L, _I, _P]),
     'gadapt_small_forward_lds_bytes': (_L, [_I, _I, _I]),
     'gadapt_small_forward': (_I, [_G, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _L, _L, _P, _I, _P, _I, _P, _P, _I, _P]),
+    'gadapt_small_forward_loss': (_I, [_G, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _L, _L, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     'gadapt_small_backward_lds_bytes': (_L, [_I, _I, _I]),
     'gadapt_small_backward': (_I, [_G, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _L, _L, _P, _I, _P, _I, _P]),
     'gadapt_layer_params_reduce': (_I, [_P, _I, _I, _I, _P, _P]),

@@ -392,6 +392,7 @@ class DeviceMeshLoader:
                        for k in (fields or self.NODE_FIELDS) if hasattr(dataset.samples[0], k)}
         self._templates = {}
         self.into, self._static = into, {}
+        self._gather_plans = {}
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
@@ -405,24 +406,35 @@ class DeviceMeshLoader:
             t = self._templates[b] = t.to(self.device)
         return t
 
-    def _gather(self, idx: torch.Tensor, dsts) -> None:
+    def _gather(self, idx: torch.Tensor, dsts, cache_key=None) -> None:
         """dst_k[b] = field_k[idx[b]] for every field: ONE launch (`gadapt_gather_fields`) for the fp32 fields on the GPU, torch's
-        index_select for anything else."""
-        native = self.device.type == 'cuda' and all(s_.dtype == torch.float32 and s_.is_contiguous() and d_.is_contiguous()
-                                                     for s_, d_ in zip(self.fields.values(), dsts)) and len(dsts) <= 8
-        if not native:
-            for stacked, dst in zip(self.fields.values(), dsts):
-                torch.index_select(stacked, 0, idx, out=dst.view(idx.numel(), *stacked.shape[1:]))
-            return
-        import ctypes as C
-        from . import _native
-        k = len(dsts)
-        src = (C.c_void_p * k)(*[s_.data_ptr() for s_ in self.fields.values()])
-        dst = (C.c_void_p * k)(*[d_.data_ptr() for d_ in dsts])
-        rows = (C.c_int64 * k)(*[s_[0].numel() for s_ in self.fields.values()])
-        idx = idx.to(torch.int64).contiguous()
-        _native.check(_native.lib().gadapt_gather_fields(k, src, dst, rows, idx.data_ptr(), int(idx.numel()),
-                                                        _native.current_stream(self.device)), 'gadapt_gather_fields')
+        index_select for anything else.  `cache_key`: the destinations are the tensors of a static batch - their argument arrays are
+        built once (a captured small-mesh step is four short launches: the loop is bound by what the host does per batch)."""
+        plan = self._gather_plans.get(cache_key) if cache_key is not None else None
+        if plan is not None and plan[6] != [d_.data_ptr() for d_ in dsts]:   # the static batch was rebuilt: other tensors behind the key
+            plan = None
+        if plan is None:
+            native = self.device.type == 'cuda' and all(s_.dtype == torch.float32 and s_.is_contiguous() and d_.is_contiguous()
+                                                         for s_, d_ in zip(self.fields.values(), dsts)) and len(dsts) <= 8
+            if not native:
+                for stacked, dst in zip(self.fields.values(), dsts):
+                    torch.index_select(stacked, 0, idx, out=dst.view(idx.numel(), *stacked.shape[1:]))
+                return
+            import ctypes as C
+            from . import _native
+            k = len(dsts)
+            plan = (k, (C.c_void_p * k)(*[s_.data_ptr() for s_ in self.fields.values()]), (C.c_void_p * k)(*[d_.data_ptr() for d_ in dsts]),
+                    (C.c_int64 * k)(*[s_[0].numel() for s_ in self.fields.values()]), _native.lib().gadapt_gather_fields, _native.current_stream,
+                    [d_.data_ptr() for d_ in dsts])
+            if cache_key is not None:
+                self._gather_plans[cache_key] = plan
+        k, src, dst, rows, fn, stream_of, _ = plan
+        if idx.dtype != torch.int64 or not idx.is_contiguous():
+            idx = idx.to(torch.int64).contiguous()
+        rc = fn(k, src, dst, rows, idx.data_ptr(), int(idx.numel()), stream_of(self.device))
+        if rc != 0:
+            from . import _native
+            _native.check(rc, 'gadapt_gather_fields')
 
     def __iter__(self) -> Iterable[MeshData]:
         n = len(self.dataset)
@@ -439,7 +451,7 @@ class DeviceMeshLoader:
             if static is not None and owner is not None and hasattr(owner, 'owns') and not owner.owns(static):
                 static = self._static.pop(b, None) and None           # gather into fresh tensors below and ask the step again
             if static is not None:                                    # gathers land in the captured step's input buffers
-                self._gather(idx, [getattr(static, k) for k in self.fields])
+                self._gather(idx, [getattr(static, k) for k in self.fields], cache_key=b)
                 static.idx = idx
                 yield static
                 continue

@@ -55,15 +55,15 @@ class FusedIteration:
         dev = torch.device(o['device'])
         if loss_fn not in (mse_loss, l1_loss):
             return 'loss is not the native mse_loss / l1_loss'
-        if not (model._fusable() and o['share_conv'] and o.get('compact_slots', True) and o['num_layers'] >= 2 and o['hidden_dim'] >= 8):
-            return 'not a fusable weight-shared block of >= 2 layers at hidden >= 8 with compact slots'
+        if not (model._fusable() and o['share_conv']):
+            return 'not a fusable weight-shared block'
         if o.get('learn_step') or o.get('softmax_temp_type') == 'learnable_a' or o['loss_type'] != 'mesh_loss':
             return 'learnable steps / temperature or a loss other than mesh_loss'
         if o.get('gnn_inc_glob_feat_f') or o.get('gnn_inc_glob_feat_uu') or o.get('gnn_normalize'):
             return 'global features / field normalisation'
         if not (isinstance(model.enc, nn.Linear) and model.enc.bias is None and not model.enc.weight.requires_grad
-                and model.enc.weight.shape[1] <= 4 and model._enc_is_zero_pad() and isinstance(model.dec, nn.Identity)):
-            return 'encoder is not the frozen zero-pad identity (or the decoder not Identity)'
+                and model.enc.weight.shape[1] <= 4 and isinstance(model.dec, nn.Identity)):
+            return 'encoder is not a frozen bias-free Linear of at most 4 columns (or the decoder not Identity)'
         x_comp, tgt = data.x_comp, getattr(data, target_field, None)
         if not (torch.is_tensor(x_comp) and x_comp.is_cuda and x_comp.dtype == torch.float32 and x_comp.dim() == 2 and x_comp.is_contiguous()
                 and x_comp.shape[1] == model.dim and torch.is_tensor(tgt) and tgt.is_cuda and tgt.dtype == torch.float32 and tgt.is_contiguous()
@@ -83,9 +83,14 @@ class FusedIteration:
             return 'optimizer is not a laid-out FlatAdam(capturable=True) over exactly [Wq | bq | Wk | bk]'
         graph = model._graph(data, x_comp.shape[0], dev)
         with torch.enable_grad():
-            if model._small_plan(data, graph, x_comp, getattr(data, 'f_tensor', None) if o['gnn_inc_feat_f'] else None,
-                                 getattr(data, 'uu_tensor', None) if o['gnn_inc_feat_uu'] else None) is not None:
-                return 'small-mesh batch: the one-launch pair runs it'
+            plan = model._small_plan(data, graph, x_comp, getattr(data, 'f_tensor', None) if o['gnn_inc_feat_f'] else None,
+                                     getattr(data, 'uu_tensor', None) if o['gnn_inc_feat_uu'] else None)
+        if plan is not None:                                            # small-mesh batch: the one-launch pair, 4 launches a step
+            if plan['part'][1] * 16 > lib().gadapt_loss_partials_max():
+                return 'small-mesh batch of more meshes than the loss partials (one per wave) allow'
+            return None
+        if not (o.get('compact_slots', True) and o['num_layers'] >= 2 and o['hidden_dim'] >= 8 and model._enc_is_zero_pad()):
+            return 'per-layer kernels: not >= 2 layers at hidden >= 8 with compact slots behind the zero-pad identity encoder'
         return None
 
     def __init__(self, model, optimizer: FlatAdam, loss_fn, data, target_field: str, coeffs=None):
@@ -103,6 +108,11 @@ class FusedIteration:
         e = max(self.graph.num_edges, 1)
         f32 = dict(device=dev, dtype=torch.float32)
         self.lp = model._layer_params(dev).contiguous()
+        with torch.enable_grad():
+            self.small = model._small_plan(data, self.graph, self.x_comp, self.f, self.uu)
+        if self.small is not None:
+            self._init_small(optimizer, f32)
+            return
         # activations: slot l = input of layer l (slot 0: the compact [N,4] rows at its start); the last layer writes the head only
         self.x_all = torch.empty(L, n, c, **f32)
         self.alpha = torch.empty(L, e, **f32)
@@ -123,9 +133,34 @@ class FusedIteration:
         # launch in the step (13 launches), and nothing to refresh when the weights change behind the step's back
         self.coeffs_in_forward = bool(lib().gadapt_forward_computes_coeffs(self.graph.c_ref, c))
 
+    def _init_small(self, optimizer, f32):
+        """Small-mesh batches (csrc/gadapt_smallmesh.inc): the whole forward is ONE launch - encoder, composite coefficients, every
+        layer, the head, and with `gadapt_small_forward_loss` the loss derivative and partial sums - the backward another, then the slab
+        sums and the chain rule + Adam launch: 4 launches a step (the captured autograd iteration: 7)."""
+        n, c, L, pl = self.n, self.c, self.L, self.small
+        e = max(self.graph.num_edges, 1)
+        n_meshes = pl['part'][1]
+        self.x_all, self.alpha = torch.empty(L, n, c, **f32), torch.empty(L, e, **f32)
+        self.out = torch.empty(n, self.d, **f32)
+        self.seed = torch.empty(n, self.d, **f32)
+        self.partials = torch.zeros(lib().gadapt_loss_partials_max(), **f32)
+        self.loss = torch.zeros((), **f32)
+        self.slab_rows, self.slab = n_meshes, torch.empty(n_meshes * (c * c + c), **f32)
+        self.scratch = torch.empty(32 * (c * c + c), **f32)
+        self.flat = torch.empty(2 * c * c + 2 * c, **f32)
+        cuts = [0, c * c, c * c + c, 2 * c * c + c, 2 * c * c + 2 * c]
+        self.grads = [(p, self.flat[cuts[k]:cuts[k + 1]].view_as(p)) for k, p in enumerate(optimizer.active)]
+        self.coeffs, self.coeffs_in_forward = None, True               # the forward launch computes them: nothing to keep or refresh
+        self.enc_w = pl['enc_w']
+        if pl['store']:                                                 # GRAND_plus.py:253-256, :381: the layers show the stored attention
+            for l, layer in enumerate(self.model.conv_layers):
+                layer.stored_ei, layer._stored = self.graph.edge_index, (self.graph, self.alpha[l])
+
     def refresh_coeffs(self):
         """(A, p0) of the parameters as they are NOW (one launch): before the first step, and after any change of the weights that did
         not come from `finish()` (an eager optimizer step, `load_state_dict`, a restored snapshot)."""
+        if self.small is not None:
+            return
         b, c = self.optimizer.bucket, self.c
         check(lib().gadapt_coeffs_forward(ptr(b), ptr(b[c * c:]), ptr(b[c * c + c:]), ptr(self.coeffs[0]), ptr(self.coeffs[1]), c, current_stream(self.device)),
               'gadapt_coeffs_forward')
@@ -141,6 +176,21 @@ class FusedIteration:
         """zero_grad + model(data) + loss + backward: 4 + 7 launches at 4 layers (the gradient of the conv parameters is still in
         the slab: `finish()` sums it).  Data parallel: also the slab sums + chain rule, so that `flat` holds this rank's gradient."""
         st, c, L = current_stream(self.device), self.c, self.L
+        if self.small is not None:
+            mesh_ptr, n_meshes, max_nodes, max_edges = self.small['part']
+            b = self.optimizer.bucket                                   # [Wq | bq | Wk | bk]: the live parameters
+            wq, bq, wk = ptr(b), ptr(b[c * c:]), ptr(b[c * c + c:])
+            self.n_part = lib().gadapt_small_forward_loss(self.graph.c_ref, ptr(mesh_ptr[0]), ptr(mesh_ptr[1]), n_meshes, max_nodes, max_edges,
+                                                          ptr(self.x_comp), self.d, ptr(self.f), ptr(self.uu), ptr(self.enc_w), self.enc_w.shape[1],
+                                                          wq, bq, wk, 0, 0, ptr(self.lp), L, ptr(self.out), self.d, ptr(self.alpha), ptr(self.x_all),
+                                                          ptr(self.target), int(self.l1), ptr(self.seed), ptr(self.partials), c, st)
+            check(min(self.n_part, 0), 'gadapt_small_forward_loss')
+            check(lib().gadapt_small_backward(self.graph.c_ref, ptr(mesh_ptr[0]), ptr(mesh_ptr[1]), n_meshes, max_nodes, max_edges, ptr(self.x_all), ptr(self.alpha),
+                                              ptr(self.seed), self.d, wq, bq, wk, 0, 0, ptr(self.lp), L, ptr(self.slab), c, st), 'gadapt_small_backward')
+            self.model.end_MLmodel = time.time()               # GNN.py:301
+            if self._world() > 1:
+                self._tail(stop_after_gradient=True)
+            return
         a, p0 = self.coeffs
         self.n_part = lib().gadapt_block_forward_loss(self.graph.c_ref, ptr(self.x_all), ptr(self.x_comp), self.d, ptr(self.f), ptr(self.uu), L, ptr(a), ptr(p0),
                                                       ptr(self.optimizer.bucket) if self.coeffs_in_forward else None,
@@ -160,7 +210,7 @@ class FusedIteration:
         check(lib().gadapt_step_tail(None if gradient_given else ptr(self.slab), self.slab_rows, ptr(self.scratch), ptr(o.bucket), ptr(self.flat),
                                      None if stop_after_gradient else ptr(o.exp_avg), None if stop_after_gradient else ptr(o.exp_avg_sq),
                                      g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], ptr(o._dev_state), scale,
-                                     None if self.coeffs_in_forward else ptr(self.coeffs[0]), None if self.coeffs_in_forward else ptr(self.coeffs[1]),
+                                     None if self.coeffs_in_forward else ptr(self.coeffs[0]), None if self.coeffs_in_forward else ptr(self.coeffs[1]),   # (small: none)
                                      None if gradient_given else ptr(self.partials), self.n_part,
                                      ptr(self.loss), self.n * self.d, c, current_stream(self.device)), 'gadapt_step_tail')
 

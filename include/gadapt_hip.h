@@ -273,6 +273,16 @@ int gadapt_small_forward(const gadapt_graph* g, const int32_t* mesh_ptr, const i
                          const float* x_comp, int dim, const float* f, const float* uu, const float* enc_w, int n_feat,
                          const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
                          const float* layer_params, int n_layers, float* out, int out_cols, float* alpha_all, float* x_all, int c, void* stream);
+/* The same launch as the head of a fused training step on a small-mesh batch (ABI 9): x_all / alpha_all are kept for
+ * gadapt_small_backward, and the launch also writes seed = d loss / d out [N,out_cols] (loss = mean squared error over all N*out_cols
+ * entries against target [N,out_cols], or mean absolute error when l1 != 0: run_GNN.py:80-84,106; the arithmetic of
+ * gadapt_loss_forward, bit-identical gradients) and one partial sum of the loss per wave to loss_partials (gadapt_loss_partials_max()
+ * floats; gadapt_step_tail sums them).  Returns the number of partials (> 0) or a negative error code.  1 <= out_cols <= 4. */
+int gadapt_small_forward_loss(const gadapt_graph* g, const int32_t* mesh_ptr, const int32_t* mesh_eptr, int n_meshes, int max_mesh_nodes, int max_mesh_edges,
+                              const float* x_comp, int dim, const float* f, const float* uu, const float* enc_w, int n_feat,
+                              const float* wq, const float* bq, const float* wk, int64_t w_stride, int64_t b_stride,
+                              const float* layer_params, int n_layers, float* out, int out_cols, float* alpha_all, float* x_all,
+                              const float* target, int l1, float* seed, float* loss_partials, int c, void* stream);
 /* x_all (nullable) [L,N,c]: when given, the input rows of every layer are kept for gadapt_small_backward (training; alpha_all must
  * be given too).
  * Backward of the same block in ONE launch, one workgroup per mesh (autograd of GRAND_plus.py:225-343 + GNN.py:288-291 through the

@@ -342,6 +342,63 @@ def test_fused_iteration_is_the_autograd_iteration(gpu_device, mesh_n, batch, hi
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims,batch,hidden,layers,conv,f,l1", [
+    ([11, 11], 8, 8, 4, 'GRAND_plus', True, False), ([13, 13], 5, 16, 3, 'GRAND', False, True), ([23, 23], 6, 8, 4, 'GRAND_plus', True, False),
+    ([15, 15], 4, 8, 2, 'GRAND_plus', True, False), ([9, 9], 70, 4, 3, 'GRAND_plus', False, True)],
+    ids=['11x11-C8', '13x13-C16-GRAND-xyu-l1', '23x23-C8', '15x15-C8-L2', '9x9-b70-C4-l1'])
+def test_fused_iteration_on_small_meshes_is_the_autograd_iteration(gpu_device, dims, batch, hidden, layers, conv, f, l1):
+    """Small-mesh batches (the reference's own sizes: `src/params.py:37,130-134`): the fused iteration is FOUR launches - the one-launch
+    forward with the loss inside (`gadapt_small_forward_loss`), the one-launch backward, slab sums, chain rule + Adam - against the
+    autograd iteration over the same one-launch pair (seven): outputs, gradients, parameters and both Adam moments bit-identical after
+    every one of three steps, the loss value within 1e-6 relative (another fixed summation order)."""
+    from g_adaptivity_amd import l1_loss, mse_loss, unit_gradient
+    from g_adaptivity_amd.training import FusedIteration
+    opt = hot_path_opt(mesh_dims=dims, hidden_dim=hidden, num_layers=layers, conv_type=conv, gnn_inc_feat_f=f, lr=1e-3, decay=1e-4,
+                       device=str(gpu_device), show_mesh_evol_plots='False')
+    ds = MeshDataset(dims, batch, seed=3)
+    data = collate(ds.samples).to(gpu_device)
+    loss_fn = l1_loss if l1 else mse_loss
+    torch.manual_seed(2)
+    state = copy.deepcopy(GNN(ds, opt).to(gpu_device).state_dict())
+    runs = {}
+    for route in ('autograd', 'fused'):
+        model = GNN(ds, opt).to(gpu_device).train(); model.load_state_dict(copy.deepcopy(state))
+        optim = FlatAdam(model.parameters(), lr=opt['lr'], weight_decay=opt['decay'], capturable=True)
+
+        def autograd_step():
+            optim.zero_grad()
+            out = model(data)
+            loss = loss_fn(out, data.x_phys)
+            loss.backward(gradient=unit_gradient(gpu_device))
+            optim.step()
+            return out.detach().clone(), loss.detach().clone(), [p.grad.clone() for p in optim.active]
+
+        rec = [autograd_step()]                                         # lays the optimizer's bucket out (both routes)
+        if route == 'fused':
+            assert FusedIteration.eligible(model, optim, loss_fn, data, 'x_phys') is None
+            it = FusedIteration(model, optim, loss_fn, data, 'x_phys')
+            assert it.small is not None                                 # the one-launch pair, not the per-layer kernels
+        for _ in range(3):
+            if route == 'fused':
+                it.run()
+                rec.append((it.out.clone(), it.loss.clone(), [g.clone() for _, g in it.grads]))
+            else:
+                rec.append(autograd_step())
+        torch.cuda.synchronize()
+        runs[route] = (rec, [p.detach().clone() for p in optim.active], optim.exp_avg.clone(), optim.exp_avg_sq.clone(), optim.state_dict()['step'])
+    (ra, pa, ma, va, sa), (rf, pf, mf, vf, sf) = runs['autograd'], runs['fused']
+    assert sa == sf == 4
+    for k, ((oa, la, ga), (of, lf, gf)) in enumerate(zip(ra, rf)):
+        assert torch.equal(oa, of), k
+        assert abs(la.item() - lf.item()) <= 1e-6 * abs(la.item()), (k, la.item(), lf.item())
+        for x, y in zip(ga, gf):
+            assert torch.equal(x.reshape(-1), y.reshape(-1)), k
+    for x, y in zip(pa, pf):
+        assert torch.equal(x, y)
+    assert torch.equal(ma, mf) and torch.equal(va, vf)
+
+
+@pytest.mark.gpu
 def test_graphed_train_step_refreshes_coefficients_after_foreign_weight_changes(gpu_device):
     """The fused captures keep (A, p0) across steps; eager steps between replays and `refresh()` after `load_state_dict` must make the
     next replay recompute them: a run that mixes replays, eager steps and a reloaded checkpoint equals the all-eager run bit for bit."""
