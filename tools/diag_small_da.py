@@ -28,7 +28,7 @@ for seed in range(3):
     slab = torch.empty(1, n_meshes, c * c + c, device=dev)
     dbg = torch.zeros(4096, device=dev)
     import ctypes as C_
-    h = lib() if hasattr(lib(), 'gadapt_debug_set_stamp_buffer') else None     # a -DGADAPT_STAMPS build (GADAPT_LIB=build/diag/lib_stamps.so)
+    h = lib() if hasattr(lib(), 'gadapt_debug_set_stamp_buffer') else None     # a -DGADAPT_STAMPS build (make EXTRA=-DGADAPT_STAMPS LIB=variants/stamps.so OBJDIR=build/obj_stamps; GADAPT_LIB=variants/stamps.so)
     if h is not None:
         h.gadapt_debug_set_stamp_buffer(C_.c_void_p(dbg.data_ptr()))
     check(lib().gadapt_small_backward(graph.c_ref, ptr(mesh_ptr[0]), ptr(mesh_ptr[1]), n_meshes, mn, me, ptr(x_all), ptr(alpha), ptr(g_top), 1, ptr(wq), ptr(bq), ptr(wk), 0, 0,

@@ -1,3 +1,5 @@
+#!/bin/bash
+# GPU box: captured / eager training loop at the reference's sizes, per-layer kernels against the one-launch pair (round 5; profiles/r05_train_small_mesh.txt).
 mkdir -p gpurun_out
 {
 for cfg in "--mesh 11 --hidden 8 --num_train 512 --batch_size 8" "--mesh 11 --hidden 8 --num_train 2048 --batch_size 64" "--mesh 23 --hidden 8 --num_train 512 --batch_size 16"; do

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Diagnostic: phase timeline of the wide forward kernel from in-kernel s_memtime stamps (needs a -DGADAPT_STAMPS build:
-GADAPT_LIB=build/diag/lib_stamps.so python tools/stamp_wide.py)."""
+make EXTRA=-DGADAPT_STAMPS LIB=variants/stamps.so OBJDIR=build/obj_stamps; GADAPT_LIB=variants/stamps.so python tools/stamp_wide.py)."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
