@@ -352,6 +352,44 @@ def test_wide_window_locality_test():
         assert torch.equal(ell[ell >= 0].long(), g.col_t[:int(deg.sum())].long())
 
 
+def test_integration_md_ctypes_stub_matches_the_library():
+    """INTEGRATION.md section 2 shows the ctypes stub a maintainer of the reference would add.  Its `Graph` structure must BE
+    `struct gadapt_graph` (field for field, like `_native.GadaptGraph`), and its `build_graph` must run against the built library and
+    fill the structure the way `MeshGraph` does (host-side calls only: no GPU here)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if 'class Graph(C.Structure)' in b)
+    ns, cwd = {}, os.getcwd()
+    os.chdir(root)                                                   # the stub opens the library by its in-tree path
+    try:
+        exec(compile(stub, 'INTEGRATION.md', 'exec'), ns)
+    finally:
+        os.chdir(cwd)
+    assert [(n, t) for n, t in ns['Graph']._fields_] == [(n, t) for n, t in _native.GadaptGraph._fields_]
+    assert C.sizeof(ns['Graph']) == C.sizeof(_native.GadaptGraph)
+    for mesh_n, batch in ((16, 2), (70, 1)):                         # 64-row window (and the four-wave one) / the 512-row window
+        ds = MeshDataset([mesh_n, mesh_n], batch, seed=0)
+        d = collate(ds.samples)
+        ei = masked_edge_index(d, 2, mesh_n)
+        n = d.x_comp.shape[0]
+        from g_adaptivity_amd import graph as graph_mod
+        keep = graph_mod.WIDE_MIN_NODES
+        graph_mod.WIDE_MIN_NODES = 0
+        try:
+            mg = MeshGraph(ei, n, 'cpu')
+        finally:
+            graph_mod.WIDE_MIN_NODES = keep
+        g, _bufs = ns['build_graph'](ei.to(torch.int64).cpu().contiguous(), n, 'cpu')
+        ref = mg.c_struct
+        for name in ('n_nodes', 'n_edges', 'wide_deg_t', 'wide_deg_s', 'wide_big_deg_t', 'wide_half_deg_t'):
+            assert getattr(g, name) == getattr(ref, name), (mesh_n, name, getattr(g, name), getattr(ref, name))
+        assert (g.wide_deg_t > 0) == (mesh_n <= 64) and (g.wide_half_deg_t > 0) == (mesh_n <= 64) and (g.wide_big_deg_t > 0) == (mesh_n > 64)
+        for name, ref_t in (('rowptr_t', mg.rowptr_t), ('col_t', mg.col_t), ('rowptr_s', mg.rowptr_s), ('tpos_s', mg.tpos_s)):
+            got = torch.frombuffer((C.c_int32 * ref_t.numel()).from_address(getattr(g, name)), dtype=torch.int32)
+            assert torch.equal(got, ref_t.cpu()), name
+
+
 def test_grand_plus_conv_option_surface():
     """Constructor options of `GRAND_plusConv` beyond what `get_conv` passes (`src/GRAND_plus.py:114-183`): parameter names and
     shapes follow the reference (`lin_skip` [H C, in] with concat, `lin_beta` [1, 3 H C], `sm_temp_a` [1,H,1]); `edge_dim` and the
