@@ -90,6 +90,39 @@ def test_every_declared_symbol_is_exported():
     assert [c for c in (3, 4, 8, 16, 32, 64, 128, 256) if _native.lib().gadapt_supported_hidden_dim(c)] == [4, 8, 16, 32, 64, 128]
 
 
+def test_ctypes_prototypes_follow_the_header():
+    """Every prototype `_native.py` binds has the parameter list `include/gadapt_hip.h` declares: the same count, pointers where the
+    header has pointers (the graph structure by reference), 64-bit integers, ints and floats where it has those, and the return type -
+    a ctypes call with one argument too few or an `int` where the header has `int64_t` passes garbage without a word."""
+    header = open(os.path.join(ROOT, 'include', 'gadapt_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', ' ', header, flags=re.S)
+    header = re.sub(r'//[^\n]*', ' ', header)
+    decls = re.findall(r'([A-Za-z_][A-Za-z0-9_ ]*?[\s\*]+)(gadapt_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;', header)
+    assert len(decls) >= 40
+    seen = set()
+
+    def kind(param: str):
+        param = param.strip()
+        if '*' in param:
+            return 'graph' if 'gadapt_graph' in param else 'ptr'
+        t = param.rsplit(' ', 1)[0] if ' ' in param else param
+        t = t.replace('const', '').replace('unsigned', '').strip()
+        return {'int': 'int', 'int32_t': 'int', 'int64_t': 'long', 'float': 'float', 'size_t': 'long'}.get(t, t)
+
+    want = {C.c_void_p: 'ptr', C.c_char_p: 'ptr', C.c_int: 'int', C.c_int64: 'long', C.c_float: 'float', _native._G: 'graph'}
+    for ret, name, params in decls:
+        seen.add(name)
+        restype, argtypes = _native.PROTOTYPES[name]
+        plist = [] if params.strip() in ('', 'void') else [x for x in params.split(',')]
+        assert len(plist) == len(argtypes), (name, len(plist), len(argtypes))
+        for k, (par, at) in enumerate(zip(plist, argtypes)):
+            got = want.get(at, 'ptr' if hasattr(at, 'contents') or issubclass(at, C._Pointer) else None)   # POINTER(c_double), ...: a pointer
+            assert kind(par) == got, (name, k, par.strip(), at)
+        rk = 'ptr' if '*' in ret else kind(ret.strip() + ' x')
+        assert rk == want[restype], (name, ret.strip(), restype)
+    assert seen == set(_native.PROTOTYPES), seen ^ set(_native.PROTOTYPES)
+
+
 def test_bad_arguments_return_codes_not_aborts():
     lib = _native.lib()
     assert lib.gadapt_backward_slab_rows(0, 64) < 0
