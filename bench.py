@@ -138,6 +138,9 @@ def main():
     ap.add_argument('--torch-loss', action='store_true', help='torch F.mse_loss instead of the one-launch native loss')
     ap.add_argument('--plain-backward', action='store_true', help='loss.backward() without the preallocated root gradient')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--launch', choices=['auto', 'graph', 'eager'], default='auto',
+                    help="how the fused step is issued: replayed as one hipGraph, as its 3 C-ABI calls (13 launches), or (auto) whichever a "
+                         "short A/B in set-up finds faster on one GPU / issued under data parallelism (nothing to capture around the all-reduce)")
     ap.add_argument('--no-fused-step', action='store_true',
                     help='the captured autograd iteration (16 launches) instead of the fused 13-launch iteration (training.FusedIteration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -292,7 +295,12 @@ def main():
                 optim.step()
 
         graph, cap_all = None, capture_all
-        if not args.no_graph:
+        # the fused step under data parallelism: issued (3 C-ABI calls + the all-reduce per step), unless --launch graph asks for the capture
+        want_graph = not (args.no_graph or args.launch == 'eager' or (fused is not None and world > 1 and args.launch == 'auto'))
+        launch_ab = None
+        if not want_graph:
+            cap_all = world == 1
+        if want_graph:
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
@@ -321,18 +329,42 @@ def main():
                     pass
                 _native.clear_error()                                 # the invalidated capture left HIP's per-thread last error set
 
-        def step():
-            if graph is not None:
-                graph.replay()                                        # forward + loss + backward (+ all-reduce + Adam when captured)
-                if not cap_all:
-                    optim_run()                                       # all-reduce + fused Adam
-            elif fused is not None:
+        def step_replayed():
+            graph.replay()                                            # forward + loss + backward (+ all-reduce + Adam when captured)
+            if not cap_all:
+                optim_run()                                           # all-reduce + fused Adam
+
+        def step_issued():
+            if fused is not None:
                 fused.run()
             else:
                 eager_step()
 
+        # One GPU, fused step, --launch auto: a fused iteration is 3 C-ABI calls, so the host stays ahead of the GPU without a graph, and a
+        # replay costs ~8 us of idle GPU per launch of the graph (docs/measurements.md K): time both ways (set-up, before the warm-up) and
+        # keep the faster.  The steps are the same launches on the same buffers either way.
+        if graph is not None and fused is not None and world == 1 and args.launch == 'auto':
+            t_ab = {}
+            for name, fn in (('replayed', step_replayed), ('issued', step_issued)) * 2:
+                fn(); torch.cuda.synchronize()
+                n_ab = 48
+                t0 = time.perf_counter()
+                for _ in range(n_ab):
+                    fn()
+                torch.cuda.synchronize()
+                t_ab[name] = min(t_ab.get(name, 1e9), (time.perf_counter() - t0) / n_ab)
+            launch_ab = {'replayed_ms_per_step': round(1e3 * t_ab['replayed'], 4), 'issued_ms_per_step': round(1e3 * t_ab['issued'], 4)}
+            if t_ab['issued'] < 0.99 * t_ab['replayed']:                # (the two timings repeat to about 0.3 %)
+                graph = None
+
+        def step():
+            if graph is not None:
+                step_replayed()
+            else:
+                step_issued()
+
         return {'opt': opt, 'model': model, 'optim': optim, 'step': step, 'fwd_bwd': (fused.forward_backward if fused is not None else fwd_bwd), 'graph': graph,
-                'capture_all': cap_all, 'fused': fused is not None, 'fused_reason': fused_reason}
+                'capture_all': cap_all, 'fused': fused is not None, 'fused_reason': fused_reason, 'launch_ab': launch_ab}
 
     def barrier():
         if world > 1:
@@ -359,8 +391,10 @@ def main():
         (MAX over ranks).  Returns (per-window seconds PER K-STEP BLOCK, R)."""
         for _ in range(args.warmup):
             step_fn()
-        probe = timed_block(step_fn, 1)
-        blocks = max(1, min(4096, int(MIN_WINDOW_S / max(probe, 1e-6)) + 1))
+        # (the shorter of two probes, and 20 % of headroom: a K-step block of a few steps is mostly its two synchronisations, so a probe
+        # over-estimates the block and the windows came out at 45 instead of 50 ms)
+        probe = min(timed_block(step_fn, 1), timed_block(step_fn, 1))
+        blocks = max(1, min(4096, int(1.2 * MIN_WINDOW_S / max(probe, 1e-6)) + 1))
         return [timed_block(step_fn, blocks) / blocks for _ in range(max(n_windows or args.windows, 1))], blocks
 
     def summarise(timed):
@@ -525,7 +559,7 @@ def main():
             o_kernels, o_roof = instrument(run, wo, name)
             keep = ('kernel', 'variant', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_us', 'alg_bytes_per_launch', 'profile')
             other_workloads[name] = {'value': round(wo['batch'] * args.steps / o_el, 1), 'unit': 'meshes/s', 'ms_per_step': round(1e3 * o_el / args.steps, 4),
-                                     'windows': o_win, 'launch': 'hipgraph+adam' if run['graph'] is not None else 'eager',
+                                     'windows': o_win, 'launch': 'hipgraph+adam' if run['graph'] is not None else ('issued: 3 C-ABI calls per step' if run['fused'] else 'eager'), 'launch_ab': run.get('launch_ab'),
                                      'config': {'mesh': f"{wo['n']}x{wo['n']}", 'meshes_per_gpu': wo['batch'], 'mp_layers': wo['layers'], 'hidden': wo['hidden'],
                                                 'conv_type': wo['conv']},
                                      'roofline': None if o_roof is None else {k_: o_roof[k_] for k_ in keep},
@@ -677,7 +711,7 @@ def main():
             'config': {'workload': args.workload, 'mesh': f"{w['n']}x{w['n']}", 'meshes_per_gpu': w['batch'],
                        'global_batch': w['batch'] * world, 'mp_layers': w['layers'], 'hidden': w['hidden'],
                        'conv_type': w['conv'], 'parallelism': f'dp{world}',
-                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'fused_step': main_run['fused'], 'fused_step_off_reason': main_run['fused_reason'], 'loss': 'torch' if args.torch_loss else 'native', 'root_gradient': 'created per step (loss.backward())' if root is None else 'preallocated (unit_gradient)', 'slots': 'dense' if args.dense_slots else 'compact', 'slots_note': None if args.dense_slots else 'identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the [N,4] encoder output in forward and backward, layer 1 hands it the 4 gradient columns it reads, the last layer writes the [N,4] head the model returns (GNN.py:299) and takes the compact top gradient; --dense-slots runs the literal dense flow', 'launch': ('hipgraph+adam' if world == 1 else ('hipgraph+allreduce+adam' if capture_all else 'hipgraph, then allreduce+adam')) if graph is not None else 'eager'},
+                       'step': 'zero_grad+forward+mse+backward+allreduce+adam', 'fused_step': main_run['fused'], 'fused_step_off_reason': main_run['fused_reason'], 'loss': 'torch' if args.torch_loss else 'native', 'root_gradient': 'created per step (loss.backward())' if root is None else 'preallocated (unit_gradient)', 'slots': 'dense' if args.dense_slots else 'compact', 'slots_note': None if args.dense_slots else 'identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the [N,4] encoder output in forward and backward, layer 1 hands it the 4 gradient columns it reads, the last layer writes the [N,4] head the model returns (GNN.py:299) and takes the compact top gradient; --dense-slots runs the literal dense flow', 'launch': ('hipgraph+adam' if world == 1 else ('hipgraph+allreduce+adam' if capture_all else 'hipgraph, then allreduce+adam')) if graph is not None else ('issued: 3 C-ABI calls (13 launches)' + (' + all-reduce' if world > 1 else '') + ' per step' if main_run['fused'] else 'eager'), 'launch_ab': main_run.get('launch_ab')},
             'roofline': roofline, 'roofline_mfma': roofline_mfma, 'kernels': kernels, 'cpu_baseline': cpu, 'train_loop': train_loop,
             'gat_plus': gat_plus, 'other_workloads': other_workloads,
         }

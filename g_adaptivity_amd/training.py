@@ -234,7 +234,7 @@ class FusedIteration:
 
 
 class _Captured:
-    __slots__ = ('static', 'graph', 'loss', 'out', 'grads', 'fused')
+    __slots__ = ('static', 'graph', 'loss', 'out', 'grads', 'fused', 'eager', 'replay_ab')
 
 
 class GraphedTrainStep:
@@ -248,13 +248,22 @@ class GraphedTrainStep:
 
     Returns the STATIC 0-d loss tensor of the captured graph (overwritten by the next call: accumulate or clone it).
 
+    `replay`: how a FUSED step is issued once it is captured.  A fused iteration is three C-ABI calls (13 launches), so the host stays far
+    ahead of a step of 100 us and more without a graph, while every hipGraph replay costs about 8 us of idle GPU on this platform
+    (docs/measurements.md K: BASELINE config 2 231.6k meshes/s replayed, 242.5k issued).  'auto' (default): one GPU - both ways are timed on
+    the static batch when a topology is captured (parameters and optimizer state restored afterwards) and the faster one is kept;
+    data parallel - the rule the timing confirms on one GPU, the same on every rank: issue the per-layer form, replay the four-launch
+    small-mesh form (its host cost is its GPU time).  'graph' / 'eager' force one.  The autograd iteration is always replayed.
+
     Under data parallelism every rank must call the step once per iteration (as with any all-reduce); WHEN a rank captures is its
     own business - a capture's warm-up issues no collective.  Hyper-parameters of the captured Adam launch (lr, betas, eps,
     weight_decay) are kernel arguments: a change of `optimizer.param_groups[0]` drops the captures and the next call re-captures.
     """
 
     def __init__(self, model, optimizer: FlatAdam, loss_fn: Callable = mse_loss, target_field: str = 'x_phys', warmup: int = 2,
-                 capture_optimizer: bool = True, max_graphs: int = 4, fused: bool = True):
+                 capture_optimizer: bool = True, max_graphs: int = 4, fused: bool = True, replay: str = 'auto'):
+        if replay not in ('auto', 'graph', 'eager'):
+            raise ValueError("replay: 'auto', 'graph' or 'eager'")
         if not isinstance(optimizer, FlatAdam) or not optimizer.capturable:
             raise TypeError("GraphedTrainStep needs FlatAdam(capturable=True): the step count must live on the device")
         if not model.training:
@@ -283,6 +292,7 @@ class GraphedTrainStep:
         # tail leaves those of the updated weights - in buffers shared by all captures; `_coeffs_stale` marks them for recomputation
         # whenever the weights change by any other route (eager steps, a capture's warm-up, refresh()).
         self.fused = bool(fused)
+        self.replay = replay
         self._coeffs = None
         self._coeffs_stale = True
         self.fused_reason: Optional[str] = None              # why the last capture did not take the fused route (None: it did)
@@ -415,7 +425,51 @@ class GraphedTrainStep:
             c.grads = [(p, p.grad) for p in self.optimizer.params]
         if self._pool is None:
             self._pool = c.graph.pool()                      # later captures share the private pool (one step runs at a time)
+        c.eager, c.replay_ab = False, None
+        if c.fused is not None and self.replay != 'graph':
+            if self.replay == 'eager' or multi:
+                c.eager = self.replay == 'eager' or c.fused.small is None
+            else:
+                c.eager = self._issue_beats_replay(c)
         return c
+
+    def _run_captured(self, c):
+        """One step of a capture: the replay, or - fused steps that are faster issued (`replay`) - its launches."""
+        if c.eager:
+            c.fused.forward_backward()
+            if self.capture_optimizer:
+                c.fused.finish()
+        else:
+            c.graph.replay()
+
+    def _issue_beats_replay(self, c, n: int = 24) -> bool:
+        """Times n steps replayed and n steps issued on the static batch (wall clock around a synchronisation: the host's share is the
+        point), restores parameters and optimizer state, returns True when issuing is at least 1 % faster (the timings repeat to about 0.3 %)."""
+        dev = self.device
+        snap = self._snapshot()
+        dp, self.optimizer.data_parallel = self.optimizer.data_parallel, False
+        times = {}
+        try:
+            for eager in (False, True, False, True):
+                c.eager = eager
+                if not c.fused.coeffs_in_forward:
+                    c.fused.refresh_coeffs()
+                self._run_captured(c)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    self._run_captured(c)
+                    if not self.capture_optimizer:
+                        c.fused.finish()
+                torch.cuda.synchronize(dev)
+                times[eager] = min(times.get(eager, 1e9), (time.perf_counter() - t0) / n)
+        finally:
+            self.optimizer.data_parallel = dp
+            c.eager = False
+            self._restore(snap)
+            self._coeffs_stale = True
+        c.replay_ab = {'replayed_ms_per_step': round(times[False] * 1e3, 4), 'issued_ms_per_step': round(times[True] * 1e3, 4)}
+        return times[True] < 0.99 * times[False]
 
     # ------------------------------------------------------------------ per step
     def _hyper(self) -> Tuple:
@@ -453,7 +507,7 @@ class GraphedTrainStep:
                     dst.copy_(src.reshape(dst.shape), non_blocking=True)
         if c.fused is not None and self._coeffs_stale and not c.fused.coeffs_in_forward:
             c.fused.refresh_coeffs()                         # (A, p0) of the weights as they are now; from here on the tails keep them current
-        c.graph.replay()
+        self._run_captured(c)
         for p, g in c.grads:                                 # `.grad` shows what THIS replay computed (each capture has its own tensors)
             p.grad = g
         if c.fused is not None:
