@@ -108,6 +108,8 @@ class FusedIteration:
         e = max(self.graph.num_edges, 1)
         f32 = dict(device=dev, dtype=torch.float32)
         self.lp = model._layer_params(dev).contiguous()
+        self._fw = self._bw = self._tl = None                           # argument lists of the C-ABI calls (built on first use: _plans)
+        self._bucket_ptr = None
         with torch.enable_grad():
             self.small = model._small_plan(data, self.graph, self.x_comp, self.f, self.uu)
         if self.small is not None:
@@ -172,52 +174,80 @@ class FusedIteration:
             return dist.get_world_size(o.group)
         return 1
 
-    def forward_backward(self):
-        """zero_grad + model(data) + loss + backward: 4 + 7 launches at 4 layers (the gradient of the conv parameters is still in
-        the slab: `finish()` sums it).  Data parallel: also the slab sums + chain rule, so that `flat` holds this rank's gradient."""
-        st, c, L = current_stream(self.device), self.c, self.L
+    def _plans(self):
+        """The argument lists of the step's C-ABI calls, built once: every pointer in them is fixed for the life of this object (its own
+        buffers, the static batch's fields, the optimizer's laid-out bucket and moments) - per call only the stream, the number of loss
+        partials and the optimizer's hyper-parameters are filled in.  (Issued rather than replayed, a step's host cost is what is left of
+        the launch path: 34 us with the lists rebuilt per call, `data_ptr()` by `data_ptr()`.)"""
+        o, c, L, L_ = self.optimizer, self.c, self.L, lib()
+        b = o.bucket                                                    # [Wq | bq | Wk | bk]: the live parameters
+        self._bucket_ptr = b.data_ptr()
         if self.small is not None:
             mesh_ptr, n_meshes, max_nodes, max_edges = self.small['part']
-            b = self.optimizer.bucket                                   # [Wq | bq | Wk | bk]: the live parameters
             wq, bq, wk = ptr(b), ptr(b[c * c:]), ptr(b[c * c + c:])
-            self.n_part = lib().gadapt_small_forward_loss(self.graph.c_ref, ptr(mesh_ptr[0]), ptr(mesh_ptr[1]), n_meshes, max_nodes, max_edges,
-                                                          ptr(self.x_comp), self.d, ptr(self.f), ptr(self.uu), ptr(self.enc_w), self.enc_w.shape[1],
-                                                          wq, bq, wk, 0, 0, ptr(self.lp), L, ptr(self.out), self.d, ptr(self.alpha), ptr(self.x_all),
-                                                          ptr(self.target), int(self.l1), ptr(self.seed), ptr(self.partials), c, st)
-            check(min(self.n_part, 0), 'gadapt_small_forward_loss')
-            check(lib().gadapt_small_backward(self.graph.c_ref, ptr(mesh_ptr[0]), ptr(mesh_ptr[1]), n_meshes, max_nodes, max_edges, ptr(self.x_all), ptr(self.alpha),
-                                              ptr(self.seed), self.d, wq, bq, wk, 0, 0, ptr(self.lp), L, ptr(self.slab), c, st), 'gadapt_small_backward')
-            self.model.end_MLmodel = time.time()               # GNN.py:301
-            if self._world() > 1:
-                self._tail(stop_after_gradient=True)
-            return
-        a, p0 = self.coeffs
-        self.n_part = lib().gadapt_block_forward_loss(self.graph.c_ref, ptr(self.x_all), ptr(self.x_comp), self.d, ptr(self.f), ptr(self.uu), L, ptr(a), ptr(p0),
-                                                      ptr(self.optimizer.bucket) if self.coeffs_in_forward else None,
-                                                      ptr(self.lp), ptr(self.alpha), ptr(self.x_top4), ptr(self.target), self.d, int(self.l1),
-                                                      ptr(self.seed), ptr(self.partials), c, st)
-        check(min(self.n_part, 0), 'gadapt_block_forward_loss')
-        check(lib().gadapt_block_backward(self.graph.c_ref, ptr(self.x_all), 4, ptr(self.alpha), ptr(self.seed), self.d, L, ptr(a), 0, ptr(p0), 0,
-                                          ptr(self.lp), ptr(self.g_ws), ptr(self.dxd_ws), ptr(self.edge_ws), ptr(self.slab), None, 0, None, c, st),
-              'gadapt_block_backward')
+            self._fw = (L_.gadapt_small_forward_loss, [self.graph.c_ref, ptr(mesh_ptr[0]), ptr(mesh_ptr[1]), n_meshes, max_nodes, max_edges,
+                                                       ptr(self.x_comp), self.d, ptr(self.f), ptr(self.uu), ptr(self.enc_w), self.enc_w.shape[1],
+                                                       wq, bq, wk, 0, 0, ptr(self.lp), L, ptr(self.out), self.d, ptr(self.alpha), ptr(self.x_all),
+                                                       ptr(self.target), int(self.l1), ptr(self.seed), ptr(self.partials), c, None], 'gadapt_small_forward_loss')
+            self._bw = (L_.gadapt_small_backward, [self.graph.c_ref, ptr(mesh_ptr[0]), ptr(mesh_ptr[1]), n_meshes, max_nodes, max_edges, ptr(self.x_all),
+                                                   ptr(self.alpha), ptr(self.seed), self.d, wq, bq, wk, 0, 0, ptr(self.lp), L, ptr(self.slab), c, None],
+                        'gadapt_small_backward')
+            a_ptr = p0_ptr = None
+        else:
+            a, p0 = self.coeffs
+            self._fw = (L_.gadapt_block_forward_loss, [self.graph.c_ref, ptr(self.x_all), ptr(self.x_comp), self.d, ptr(self.f), ptr(self.uu), L, ptr(a), ptr(p0),
+                                                       ptr(b) if self.coeffs_in_forward else None, ptr(self.lp), ptr(self.alpha), ptr(self.x_top4),
+                                                       ptr(self.target), self.d, int(self.l1), ptr(self.seed), ptr(self.partials), c, None],
+                        'gadapt_block_forward_loss')
+            self._bw = (L_.gadapt_block_backward, [self.graph.c_ref, ptr(self.x_all), 4, ptr(self.alpha), ptr(self.seed), self.d, L, ptr(a), 0, ptr(p0), 0,
+                                                   ptr(self.lp), ptr(self.g_ws), ptr(self.dxd_ws), ptr(self.edge_ws), ptr(self.slab), None, 0, None, c, None],
+                        'gadapt_block_backward')
+            a_ptr, p0_ptr = (None, None) if self.coeffs_in_forward else (ptr(a), ptr(p0))
+        # gadapt_step_tail in its three forms: (slab given, moments given) = the whole tail; (slab, no moments) = this rank's gradient;
+        # (no slab, moments) = the gradient is given (all-reduced)
+        def tail(slab, moments):
+            return [ptr(self.slab) if slab else None, self.slab_rows, ptr(self.scratch), ptr(b), ptr(self.flat),
+                    ptr(o.exp_avg) if moments else None, ptr(o.exp_avg_sq) if moments else None, 0.0, 0.0, 0.0, 0.0, 0.0, ptr(o._dev_state), 1.0,
+                    a_ptr, p0_ptr, ptr(self.partials) if slab else None, 0, ptr(self.loss), self.n * self.d, c, None]
+        self._tl = {(False, False): tail(True, True), (True, False): tail(True, False), (False, True): tail(False, True)}
+        self._fn_tail = L_.gadapt_step_tail
+
+    def forward_backward(self):
+        """zero_grad + model(data) + loss + backward: 4 + 7 launches at 4 layers (small-mesh batches: 1 + 1; the gradient of the conv
+        parameters is still in the slab: `finish()` sums it).  Data parallel: also the slab sums + chain rule, so that `flat` holds this
+        rank's gradient."""
+        if self._fw is None or self._bucket_ptr != self.optimizer.bucket.data_ptr():
+            self._plans()
+        st = current_stream(self.device)
+        fn, args, name = self._fw
+        args[-1] = st
+        self.n_part = fn(*args)
+        if self.n_part < 0:
+            check(self.n_part, name)
+        fn, args, name = self._bw
+        args[-1] = st
+        rc = fn(*args)
+        if rc:
+            check(rc, name)
         self.model.end_MLmodel = time.time()                   # GNN.py:301
-        if self._world() > 1:
+        if self.optimizer.data_parallel and self._world() > 1:
             self._tail(stop_after_gradient=True)
 
     def _tail(self, stop_after_gradient=False, gradient_given=False, scale=1.0):
-        o, c = self.optimizer, self.c
-        g = o.param_groups[0]
-        check(lib().gadapt_step_tail(None if gradient_given else ptr(self.slab), self.slab_rows, ptr(self.scratch), ptr(o.bucket), ptr(self.flat),
-                                     None if stop_after_gradient else ptr(o.exp_avg), None if stop_after_gradient else ptr(o.exp_avg_sq),
-                                     g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], ptr(o._dev_state), scale,
-                                     None if self.coeffs_in_forward else ptr(self.coeffs[0]), None if self.coeffs_in_forward else ptr(self.coeffs[1]),   # (small: none)
-                                     None if gradient_given else ptr(self.partials), self.n_part,
-                                     ptr(self.loss), self.n * self.d, c, current_stream(self.device)), 'gadapt_step_tail')
+        if self._fw is None or self._bucket_ptr != self.optimizer.bucket.data_ptr():
+            self._plans()
+        g = self.optimizer.param_groups[0]
+        args = self._tl[(stop_after_gradient, gradient_given)]
+        args[7], (args[8], args[9]), args[10], args[11], args[13], args[17] = g['lr'], g['betas'], g['eps'], g['weight_decay'], scale, self.n_part
+        args[-1] = current_stream(self.device)
+        rc = self._fn_tail(*args)
+        if rc:
+            check(rc, 'gadapt_step_tail')
 
     def finish(self):
         """optimizer.step(): one GPU - slab sums + chain rule + Adam + next coefficients (2 launches); data parallel - all-reduce of
         the flat gradient, then Adam + next coefficients (1 launch)."""
-        world = self._world()
+        world = self._world() if self.optimizer.data_parallel else 1
         if world == 1:
             self._tail()
         else:
@@ -442,13 +472,13 @@ class GraphedTrainStep:
         else:
             c.graph.replay()
 
-    def _issue_beats_replay(self, c, n: int = 24) -> bool:
+    def _issue_beats_replay(self, c, n: int = 12) -> bool:
         """Times n steps replayed and n steps issued on the static batch (wall clock around a synchronisation: the host's share is the
-        point), restores parameters and optimizer state, returns True when issuing is at least 1 % faster (the timings repeat to about 0.3 %)."""
+        point), restores parameters and optimizer state, returns True when issuing is at least 1 % faster (the timings repeat to about 0.3 %) and queues a step in at most 60 % of its GPU time."""
         dev = self.device
         snap = self._snapshot()
         dp, self.optimizer.data_parallel = self.optimizer.data_parallel, False
-        times = {}
+        times, host_share = {}, 1.0
         try:
             for eager in (False, True, False, True):
                 c.eager = eager
@@ -461,15 +491,21 @@ class GraphedTrainStep:
                     self._run_captured(c)
                     if not self.capture_optimizer:
                         c.fused.finish()
+                t_issue = time.perf_counter() - t0                # the host's part: everything is queued
                 torch.cuda.synchronize(dev)
                 times[eager] = min(times.get(eager, 1e9), (time.perf_counter() - t0) / n)
+                if eager:
+                    host_share = min(host_share, t_issue / max(time.perf_counter() - t0, 1e-9))
         finally:
             self.optimizer.data_parallel = dp
             c.eager = False
             self._restore(snap)
             self._coeffs_stale = True
-        c.replay_ab = {'replayed_ms_per_step': round(times[False] * 1e3, 4), 'issued_ms_per_step': round(times[True] * 1e3, 4)}
-        return times[True] < 0.99 * times[False]
+        c.replay_ab = {'replayed_ms_per_step': round(times[False] * 1e3, 4), 'issued_ms_per_step': round(times[True] * 1e3, 4),
+                       'issued_host_share': round(host_share, 3)}
+        # ... and only while the host has room left for what else a loop does per batch (a loader's gather, logging): issuing a step
+        # costs the host ~4 us per launch, a replay ~8 us per step
+        return times[True] < 0.99 * times[False] and host_share <= 0.6
 
     # ------------------------------------------------------------------ per step
     def _hyper(self) -> Tuple:
