@@ -195,7 +195,9 @@ def main():
     # GADAPT_BENCH_CAPTURE_ALLREDUCE=1 / 0 force the choice without the rehearsal.
     env_cap = os.environ.get('GADAPT_BENCH_CAPTURE_ALLREDUCE')
     probe_ok = None
-    if world > 1 and backend == 'nccl' and env_cap not in ('0', '1'):
+    # (--launch auto, the default: the fused step under data parallelism is issued, its all-reduce is an ordinary stream-ordered
+    # collective - no capture of a collective, so no rehearsal either; --launch graph asks for both)
+    if world > 1 and backend == 'nccl' and env_cap not in ('0', '1') and args.launch == 'graph':
         from g_adaptivity_amd.rccl_probe import rehearse
         probe_ok = rehearse()
     torch.cuda.set_device(local_rank)
@@ -223,6 +225,8 @@ def main():
             return False
         if env_cap in ('0', '1'):
             return env_cap == '1'
+        if probe_ok is None:                                          # not rehearsed (--launch auto / eager): collectives stay outside captures
+            return False
         t = torch.tensor([1.0 if probe_ok else 0.0], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)                      # every rank's rehearsal must have passed
         return bool(t.item() == 1.0)
