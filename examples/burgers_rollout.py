@@ -83,7 +83,8 @@ def main():
                     torch.cuda.synchronize()
                     dev_ms += e0.elapsed_time(e1)
             results[(flow, mode)] = (mesh_time / args.steps, torch.stack(outs))
-            print(f"{flow:19s} {mode:9s}: {1e6 * mesh_time / args.steps:8.1f} us host-visible per model call, {1e3 * dev_ms / args.steps:7.1f} us between "
+            how = '' if runner is None else (' [one kernel, launched directly]' if runner.direct else ' [one C-ABI call, issued]' if runner.issued else ' [replayed capture]')
+            print(f"{flow:19s} {mode:9s}{how}: {1e6 * mesh_time / args.steps:8.1f} us host-visible per model call, {1e3 * dev_ms / args.steps:7.1f} us between "
                   f"HIP events ({args.steps} calls, {data.x_comp.shape[0]} nodes, graphs built: {len(model._graphs)})")
         diff = (results[(flow, 'eager')][1] - results[(flow, 'hipgraph')][1]).abs().max().item()
         print(f"{flow:19s} max |eager - hipgraph| over the rollout: {diff:.3e}")

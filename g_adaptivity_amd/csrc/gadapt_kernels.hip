@@ -465,15 +465,17 @@ extern "C" int gadapt_block_forward_loss(const gadapt_graph* g, float* x_all, co
                                          const float* target, int d, int l1, float* seed, float* loss_partials, int c, void* stream) {
     if (!x_comp || dim < 1 || dim > 4 || dim + (f_tensor ? 1 : 0) + (uu_tensor ? 1 : 0) > 4)
         return fail(GADAPT_E_BADARG, "block_forward_loss: 1..4 coordinates, coordinates + extras <= 4 columns");
-    if (!x_top4 || !target || !seed || !loss_partials || d < 1 || d > 4) return fail(GADAPT_E_BADARG, "block_forward_loss: head rows, target, seed, partials; 1 <= d <= 4");
+    // target == NULL: no loss - the evaluation forward on the node fields (inference.GraphedForward issues it as this one call)
+    if (!x_top4 || (target && (!seed || !loss_partials || d < 1 || d > 4))) return fail(GADAPT_E_BADARG, "block_forward_loss: head rows; with a target: seed, partials, 1 <= d <= 4");
     if (!g || g->n_nodes <= 0) return fail(GADAPT_E_BADARG, "bad graph");
     int n_partials = 0;
     // x_all slot 0 starts with the compact [N,4] layer-0 input (written by the layer-0 launch for the layer-0 backward)
     if (param && !gadapt_forward_computes_coeffs_c(g, c))
         return fail(GADAPT_E_BADARG, "block_forward_loss: param given, but this graph / hidden size does not compute the coefficients in its layer-0 launch (gadapt_forward_computes_coeffs)");
     FwdExtra ex{FieldSrc{x_comp, f_tensor, uu_tensor, dim}, x_all,
-                LossArgs{target, seed, loss_partials, d, l1 ? 1 : 0, 1.0f / (float)((int64_t)g->n_nodes * d)}, &n_partials, param, a, p0};
+                LossArgs{target, seed, loss_partials, d, l1 ? 1 : 0, 1.0f / (float)((int64_t)g->n_nodes * (d > 0 ? d : 1))}, &n_partials, param, a, p0};
     if (int rc = block_forward(g, x_all, 4, n_layers, a, 0, p0, 0, layer_params, alpha_all, x_top4, c, stream, &ex)) return rc;
+    if (!target) return 0;
     if (n_partials <= 0 || n_partials > GADAPT_LOSS_PARTIALS_MAX) return fail(GADAPT_E_RUNTIME, "block_forward_loss: loss partial count out of range");
     return n_partials;
 }

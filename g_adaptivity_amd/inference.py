@@ -45,6 +45,7 @@ class GraphedForward:
         # every replay.
         if self._plan is not None and not (o['share_conv'] and not o.get('learn_step') and o.get('softmax_temp_type') != 'learnable_a'):
             self._plan = None
+        self.issued = False
         if self._plan is not None:                         # one kernel per call: launched directly, nothing to capture
             self.direct = True
             self._use_f, self._use_uu = bool(o['gnn_inc_feat_f']), bool(o['gnn_inc_feat_uu'])
@@ -52,6 +53,12 @@ class GraphedForward:
             self._prepare_direct()
             return
         self._warmup = warmup
+        if self._issuable():                               # the whole forward as ONE C-ABI call on the caller's tensors (see _prepare_issued)
+            self.issued = True
+            self._use_f, self._use_uu = bool(o['gnn_inc_feat_f']), bool(o['gnn_inc_feat_uu'])
+            self._last = {}
+            self._prepare_issued()
+            return
         self._capture()
         self._last = {}                                    # field -> (source tensor, its version) of the last copy
 
@@ -70,6 +77,85 @@ class GraphedForward:
         with torch.no_grad(), torch.cuda.graph(self.graph, stream=side):
             self.out = model(self.static)
         self._live = [(t, t.data_ptr()) for t in model.parameters()]
+
+    # ------------------------------------------------------------------ weight-shared blocks behind the identity encoder: one C-ABI call
+    def _issuable(self) -> bool:
+        """The model side of `training.FusedIteration.eligible`: the block `gadapt_block_forward_loss` runs with the node fields read by
+        its layer-0 launch - a fusable weight-shared GRAND / GRAND_plus block of >= 2 layers at hidden >= 8, constant steps and temperature,
+        the frozen zero-pad identity encoder, no decoder, no global features or normalisation, compact slots."""
+        import torch.nn as nn
+        m, o = self.model, self.model.opt
+        x = self.static.x_comp
+        return bool(m._fusable() and o['share_conv'] and o.get('compact_slots', True) and o['num_layers'] >= 2 and o['hidden_dim'] >= 8
+                    and not o.get('learn_step') and o.get('softmax_temp_type') != 'learnable_a'
+                    and not (o.get('gnn_inc_glob_feat_f') or o.get('gnn_inc_glob_feat_uu') or o.get('gnn_normalize'))
+                    and isinstance(m.enc, nn.Linear) and m.enc.bias is None and m.enc.weight.shape[1] <= 4 and m._enc_is_zero_pad()
+                    and isinstance(m.dec, nn.Identity) and o['conv_type'] != 'GRAND' and not isinstance(o.get('show_mesh_evol_plots'), bool)
+                    and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == m.dim)
+
+    def _prepare_issued(self):
+        """A replay of the captured forward costs about 8 us of idle GPU before its four launches start (docs/measurements.md K); the same
+        four launches issued by ONE C-ABI call (`gadapt_block_forward_loss` without a target: layer 0 reads the node fields itself, the
+        last layer writes the head rows) cost the host ~20 us and the GPU nothing extra - and they read the caller's field tensors in place,
+        so there are no static buffers to copy into.  The composite coefficients come from the layer-0 launch where it computes them
+        (hidden 64 on graphs the wide forward takes), else from a coefficient launch per call: always those of the weights as they are."""
+        from . import _native
+        from .functional import current_stream
+        m, o, dev = self.model, self.model.opt, self.device
+        xc = self.static.x_comp
+        n, c, L = int(xc.shape[0]), int(o['hidden_dim']), int(o['num_layers'])
+        self._n = n
+        graph = self._graph_obj = m._graph(self.static, n, dev)
+        f32 = dict(device=dev, dtype=torch.float32)
+        self._x_all = torch.empty(L, n, c, **f32)
+        self._x_top4 = torch.empty(n, 4, **f32)
+        self.out = self._x_top4[:, :m.dim]
+        self._coeffs = (torch.empty(c, c, **f32), torch.empty(c, **f32))
+        self._lp = m._layer_params(dev).contiguous()
+        conv = m.conv_layers[0]
+        self._w = (conv.lin_query.weight, conv.lin_query.bias, conv.lin_key.weight)
+        lib = _native.lib()
+        self._in_forward = bool(lib.gadapt_forward_computes_coeffs(graph.c_ref, c)) and self._flat_bucket() is not None
+        self._fn, self._fn_coeffs, self._stream = lib.gadapt_block_forward_loss, lib.gadapt_coeffs_forward, current_stream
+        self._args = [graph.c_ref, self._x_all.data_ptr(), None, m.dim, None, None, L, self._coeffs[0].data_ptr(), self._coeffs[1].data_ptr(), None,
+                      self._lp.data_ptr(), None, self._x_top4.data_ptr(), None, 0, 0, None, None, c, None]
+        self._c = c
+        self._live = [(t, t.data_ptr()) for t in self._w]
+
+    def _flat_bucket(self):
+        """Address of [Wq | bq | Wk] when the three tensors lie back to back in that order (FlatAdam's bucket), else None."""
+        wq, bq, wk = self._w
+        c = wq.shape[0]
+        ok = wq.is_contiguous() and bq.is_contiguous() and wk.is_contiguous() and bq.data_ptr() == wq.data_ptr() + 4 * c * c \
+            and wk.data_ptr() == bq.data_ptr() + 4 * c
+        return wq.data_ptr() if ok else None
+
+    def _issued_call(self, data, fields, sync):
+        if any(t.data_ptr() != ptr_ for t, ptr_ in self._live):     # parameter storage moved (FlatAdam laid its bucket out, ...)
+            self._prepare_issued()
+        a = self._args
+        xc = self._field('x_comp', data, fields, True)
+        f = self._field('f_tensor', data, fields, self._use_f)
+        uu = self._field('uu_tensor', data, fields, self._use_uu)
+        st = self._stream(self.device)
+        a[2], a[4], a[5] = xc.data_ptr(), None if f is None else f.data_ptr(), None if uu is None else uu.data_ptr()
+        if self._in_forward:
+            a[9] = self._flat_bucket()
+        if a[9] is None:                                            # the weights as they are now -> (A, p0): one launch
+            wq, bq, wk = self._w
+            rc = self._fn_coeffs(wq.data_ptr(), bq.data_ptr(), wk.data_ptr(), a[7], a[8], self._c, st)
+            if rc != 0:
+                from . import _native
+                _native.check(rc, 'gadapt_coeffs_forward')
+        a[-1] = st
+        rc = self._fn(*a)
+        if rc != 0:
+            from . import _native
+            _native.check(min(rc, -1), 'gadapt_block_forward_loss')
+        if sync:
+            torch.cuda.current_stream(self.device).synchronize()
+        self.model.end_MLmodel = time.time()               # same stamp the eager forward leaves (GNN.py:301)
+        return self.out
 
     # ------------------------------------------------------------------ small meshes: one kernel, launched directly
     def _prepare_direct(self):
@@ -116,6 +202,9 @@ class GraphedForward:
     def refresh(self):
         """Rebuild the direct launch's argument list / capture the graph again from the model as it is now (parameter storage that
         moved)."""
+        if self.issued:
+            self._prepare_issued()
+            return
         if not self.direct:
             self._capture()
             return
@@ -158,6 +247,8 @@ class GraphedForward:
         Returns the static output tensor (overwritten by the next call; clone it to keep it)."""
         if self.direct:
             return self._direct_call(data, fields, sync)
+        if self.issued:
+            return self._issued_call(data, fields, sync)
         if any(t.data_ptr() != ptr_ for t, ptr_ in self._live):
             self.refresh()
         for name in FIELDS:

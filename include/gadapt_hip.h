@@ -224,7 +224,8 @@ int gadapt_block_backward(const gadapt_graph* g, const float* x_all, int x0_cols
  *     the start of x_all's slot 0, where the layer-0 backward reads it: no encoder launch;
  *   - the last layer's head-only launch also writes seed [N,d] = d loss / d x_top4[:, :d] (same arithmetic as gadapt_loss_forward)
  *     and one partial of sum |x_top4[:, :d] - target|^p per wave to loss_partials (gadapt_loss_partials_max() floats): no loss
- *     launch.  Returns the number of partials written (> 0) or a negative error code.
+ *     launch.  Returns the number of partials written (> 0) or a negative error code.  target == NULL (seed, loss_partials unused): no
+ *     loss, returns 0 - the evaluation forward on the node fields as one call (the layer-0 launch reads them, x_top4 is the result).
  * (a, p0): the composite coefficients of the shared conv.  param == NULL: INPUTS - from gadapt_coeffs_forward before the first
  * step, from the previous step's gadapt_step_tail afterwards.  param != NULL (only where gadapt_forward_computes_coeffs(g, c) = 1:
  * hidden 64 on a graph the wide forward kernel takes): the flat bucket [Wq | bq | Wk | bk] the step trains - the layer-0 launch

@@ -109,6 +109,45 @@ def test_graphed_forward_follows_weight_changes(gpu_device, share):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mesh_n,batch,hidden,conv,f", [(16, 4, 64, 'GRAND_plus', True), (20, 3, 32, 'GRAND_plus', False), (64, 8, 64, 'GRAND_plus', True)],
+                         ids=['16x16-C64', '20x20-C32-xyu', '64x64-b8-C64'])
+def test_graphed_forward_issued_as_one_call(gpu_device, mesh_n, batch, hidden, conv, f):
+    """Weight-shared blocks behind the identity encoder: `GraphedForward` issues the whole evaluation forward as ONE C-ABI call
+    (`gadapt_block_forward_loss` without a target; layer 0 reads the caller's field tensors in place) instead of replaying a capture.
+    Same kernels on the same values as `model(data)`: bit-identical output - for the batch it was built on, for new field tensors
+    (a rollout: `src/utils_eval_Burgers.py:282-300`), after in-place weight updates, after parameter storage moved into FlatAdam's
+    bucket (from where the wide layer-0 launch computes the coefficients itself), and with the tiled forward (`GADAPT_WIDE` off)."""
+    from g_adaptivity_amd.inference import GraphedForward
+    from g_adaptivity_amd import mse_loss
+    opt = hot_path_opt(mesh_dims=[mesh_n, mesh_n], hidden_dim=hidden, num_layers=3, conv_type=conv, gnn_inc_feat_f=f, device=str(gpu_device),
+                       show_mesh_evol_plots='False')
+    ds = MeshDataset([mesh_n, mesh_n], batch, seed=2)
+    data = collate(ds.samples).to(gpu_device)
+    torch.manual_seed(3)
+    model = GNN(ds, opt).to(gpu_device).eval()
+    runner = GraphedForward(model, data)
+    assert runner.issued and not runner.direct
+    with torch.no_grad():
+        assert torch.equal(runner(data).clone(), model(data))
+        d2 = data.clone()
+        d2.uu_tensor = data.uu_tensor * 0.5 + 0.1
+        d2.x_comp = (data.x_comp + 0.01 * torch.sin(7 * data.x_comp)).contiguous()
+        assert torch.equal(runner(d2).clone(), model(d2))
+        assert torch.equal(runner(uu_tensor=data.uu_tensor, x_comp=data.x_comp).clone(), model(data))     # fields as keywords
+        for p in model.conv_layers.parameters():                        # in place, raw (what the Adam kernels do)
+            p.data.mul_(1.25)
+        assert torch.equal(runner(data).clone(), model(data))
+    # parameter storage moves into FlatAdam's bucket: [Wq | bq | Wk | bk] back to back
+    model.train()
+    optim = FlatAdam(model.parameters(), lr=1e-3, capturable=True)
+    optim.zero_grad(); mse_loss(model(data), data.x_phys).backward(); optim.step()
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(runner(data).clone(), model(data))
+        assert runner._flat_bucket() is not None
+
+
+@pytest.mark.gpu
 def test_compact_encoder_output_equals_dense(gpu_device):
     """Identity encoder = zero-pad (GNN.py:75-82): layer 0 reads the compact [N,4] features and the top layer's backward
     the compact [N,dim] gradient.  The forward gives exactly what the dense [N,C] matrices give (same kernels, same order).
