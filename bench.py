@@ -16,7 +16,9 @@ Extra objects on the JSON line:
   windows      - `value` / `ms_per_step` are the MEDIAN of --windows (5) timed windows of exactly K steps; min / max beside it.
   value_dense_slots / ms_per_step_dense_slots - the same run's timing of the literal dense-slot flow.
   train_loop   - N=1: the reference's training loop (src/run_GNN.py:95-131) on SHUFFLED, CHANGING batches through
-                 training.GraphedTrainStep + DeviceMeshLoader (the headline replays one static batch).
+                 training.GraphedTrainStep + DeviceMeshLoader (the headline steps on one static batch).
+  config.launch / config.launch_ab - how the step is issued: as one hipGraph replay, or (the fused step, --launch auto, where a short A/B
+                 in set-up finds it faster on this box; N > 1: always) as its three C-ABI calls - the same launches on the same buffers.
 """
 import argparse
 import json
